@@ -1,0 +1,201 @@
+/*
+ * fpc_numerics.h -- canonical fp32 numerics of the fpcodec hot path.
+ *
+ * This header is the *specification* of every transcendental and rounding
+ * step used by the LPCNet-style vocoder loop and by cepstrum->LPC.  It is
+ * compiled unchanged by gcc (CPU oracle under oracle/) and by hipcc for gfx950
+ * (kernels under feature-predictor-for-speech-codec_amd/csrc/), so that both sides
+ * produce bit-identical fp32 results: only IEEE-754 correctly rounded
+ * primitives are used (+, -, *, /, fmaf, rintf, integer bit moves).  Hardware
+ * approximations (v_exp_f32, v_rcp_f32, ...) are deliberately not used.
+ *
+ * Build both sides with -ffp-contract=off so that no extra fusing happens
+ * beyond the explicit fmaf() calls written here.
+ *
+ * Reference pins (haiciyang/Feature-predictor-for-speech-codec @ /root/reference):
+ *   mu-law         src/utils.py:16-31   (l2u / u2l; LPCNet's ulaw.py adds round())
+ *   pdf shaping    src/train.py:79-92   (constants 1.5, .5, 1e-18, .002, 1e-8)
+ *   period index   src/synthesis.py:103 (.1 + 50*f18 + 100 -> int)
+ *   de-emphasis    src/models/wavenet.py:188 (0.85)
+ */
+#ifndef FPC_NUMERICS_H
+#define FPC_NUMERICS_H
+
+#include <stdint.h>
+#include <math.h>
+#include <string.h>
+
+#if defined(__HIPCC__)
+#define FPC_HD __host__ __device__ __forceinline__
+#else
+#define FPC_HD static inline
+#endif
+
+#define FPC_FRAME_SIZE 160
+#define FPC_LPC_ORDER 16
+#define FPC_NB_FEATURES 36
+#define FPC_NB_USED_FEATURES 20
+#define FPC_PREEMPH 0.85f
+
+FPC_HD float fpc_u2f(uint32_t u) {
+    float f;
+    memcpy(&f, &u, 4);
+    return f;
+}
+FPC_HD uint32_t fpc_f2u(float f) {
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    return u;
+}
+
+/* tanh: odd/even rational minimax (13,6), the form Eigen/TensorFlow-CPU evaluate
+ * for float32 tanh; |err| < 4e-7 absolute over the whole range. */
+FPC_HD float fpc_tanhf(float x) {
+    const float lim = 7.90531110763549805f;
+    x = x > lim ? lim : x;
+    x = x < -lim ? -lim : x;
+    const float x2 = x * x;
+    float p = fmaf(x2, -2.76076847742355e-16f, 2.00018790482477e-13f);
+    p = fmaf(x2, p, -8.60467152213735e-11f);
+    p = fmaf(x2, p, 5.12229709037114e-08f);
+    p = fmaf(x2, p, 1.48572235717979e-05f);
+    p = fmaf(x2, p, 6.37261928875436e-04f);
+    p = fmaf(x2, p, 4.89352455891786e-03f);
+    p = x * p;
+    float q = fmaf(x2, 1.19825839466702e-06f, 1.18534705686654e-04f);
+    q = fmaf(x2, q, 2.26843463243900e-03f);
+    q = fmaf(x2, q, 4.89352518554385e-03f);
+    return p / q;
+}
+
+/* logistic via the exact identity sigma(x) = 1/2 + 1/2 tanh(x/2) */
+FPC_HD float fpc_sigmoidf(float x) {
+    return fmaf(0.5f, fpc_tanhf(0.5f * x), 0.5f);
+}
+
+/* exp: Cephes-style range reduction + degree-5 polynomial, result scaled by
+ * integer exponent insertion.  Relative error < 2e-7 on [-87, 88]. */
+FPC_HD float fpc_expf(float x) {
+    x = x > 88.0f ? 88.0f : x;
+    x = x < -87.0f ? -87.0f : x;
+    const float n = rintf(x * 1.44269504088896341f);
+    float r = fmaf(n, -0.693359375f, x);
+    r = fmaf(n, 2.12194440e-4f, r);
+    float p = 1.9875691500e-4f;
+    p = fmaf(p, r, 1.3981999507e-3f);
+    p = fmaf(p, r, 8.3334519073e-3f);
+    p = fmaf(p, r, 4.1665795894e-2f);
+    p = fmaf(p, r, 1.6666665459e-1f);
+    p = fmaf(p, r, 5.0000001201e-1f);
+    const float r2 = r * r;
+    p = fmaf(p, r2, r) + 1.0f;
+    const int32_t e = (int32_t)n;
+    return p * fpc_u2f((uint32_t)(e + 127) << 23);
+}
+
+/* natural log for normal positive x (Cephes logf).  x <= 0 returns -87.33655f
+ * (log of the smallest normal), so that exp(e*log(0)) underflows cleanly. */
+FPC_HD float fpc_logf(float x) {
+    if (!(x >= 1.17549435e-38f)) return -87.33655f;
+    uint32_t ix = fpc_f2u(x);
+    int32_t e = (int32_t)(ix >> 23) - 126;
+    float m = fpc_u2f((ix & 0x007fffffu) | 0x3f000000u); /* [0.5,1) */
+    if (m < 0.707106781186547524f) {
+        e -= 1;
+        m = m + m;
+    }
+    m = m - 1.0f;
+    const float z = m * m;
+    float p = 7.0376836292e-2f;
+    p = fmaf(p, m, -1.1514610310e-1f);
+    p = fmaf(p, m, 1.1676998740e-1f);
+    p = fmaf(p, m, -1.2420140846e-1f);
+    p = fmaf(p, m, 1.4249322787e-1f);
+    p = fmaf(p, m, -1.6668057665e-1f);
+    p = fmaf(p, m, 2.0000714765e-1f);
+    p = fmaf(p, m, -2.4999993993e-1f);
+    p = fmaf(p, m, 3.3333331174e-1f);
+    p = p * m * z;
+    const float fe = (float)e;
+    p = fmaf(fe, -2.12194440e-4f, p);
+    p = fmaf(-0.5f, z, p);
+    float r = m + p;
+    r = fmaf(fe, 0.693359375f, r);
+    return r;
+}
+
+/* 10**x (cepstrum -> band energy, src/ceps2lpc/ceps2lpc_vct.py:134) */
+FPC_HD float fpc_exp10f(float x) {
+    return fpc_expf(x * 2.30258509299404568f);
+}
+
+/* mu-law companding, LPCNet ulaw.py semantics: formula of src/utils.py:19-24
+ * followed by round-half-even and clip to [0,255]. */
+FPC_HD int fpc_lin2ulaw(float x) {
+    const float a = fabsf(x);
+    const float l = fpc_logf(fmaf(255.0f / 32768.0f, a, 1.0f));
+    float u = rintf(l * 23.0831206542234f); /* 128/ln(256) */
+    u = x < 0.0f ? -u : u;
+    u = 128.0f + u;
+    u = u < 0.0f ? 0.0f : u;
+    u = u > 255.0f ? 255.0f : u;
+    return (int)u;
+}
+
+/* inverse mu-law (src/utils.py:26-31); the vocoder uses the 256-entry table
+ * produced by this function, never the function itself in the sample loop. */
+FPC_HD float fpc_ulaw2lin(int u) {
+    const float v = (float)u - 128.0f;
+    const float a = fabsf(v);
+    const float m = (32768.0f / 255.0f) * (fpc_expf(a * 0.0433216987849966f) - 1.0f); /* ln256/128 */
+    return v < 0.0f ? -m : m;
+}
+
+/* pitch-period embedding index (src/synthesis.py:103, src/train.py:123) */
+FPC_HD int fpc_period_index(float f18) {
+    int p = (int)(0.1f + 50.0f * f18 + 100.0f);
+    p = p < 0 ? 0 : p;
+    p = p > 255 ? 255 : p;
+    return p;
+}
+
+/* pdf sharpening exponent for a frame (src/train.py:82): max(0, 1.5*corr - .5) */
+FPC_HD float fpc_shape_exponent(float pitch_corr) {
+    const float e = fmaf(1.5f, pitch_corr, -0.5f);
+    return e > 0.0f ? e : 0.0f;
+}
+
+/* p * p**e  (src/train.py:82) with the canonical log/exp above */
+FPC_HD float fpc_shape_pow(float p, float e) {
+    return p * fpc_expf(e * fpc_logf(p));
+}
+
+/* float PCM -> int16 with round-half-even and saturation */
+FPC_HD int16_t fpc_pcm16(float v) {
+    v = v > 32767.0f ? 32767.0f : v;
+    v = v < -32768.0f ? -32768.0f : v;
+    return (int16_t)rintf(v);
+}
+
+/* Philox4x32-10 counter RNG: one uniform in [0,1) per (seed, sample index). */
+FPC_HD uint32_t fpc_mulhi32(uint32_t a, uint32_t b) {
+    return (uint32_t)(((uint64_t)a * (uint64_t)b) >> 32);
+}
+FPC_HD float fpc_philox_uniform(uint64_t seed, uint32_t t) {
+    uint32_t c0 = t, c1 = 0u, c2 = 0u, c3 = 0u;
+    uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+    for (int i = 0; i < 10; ++i) {
+        const uint32_t h0 = fpc_mulhi32(0xD2511F53u, c0), l0 = 0xD2511F53u * c0;
+        const uint32_t h1 = fpc_mulhi32(0xCD9E8D57u, c2), l1 = 0xCD9E8D57u * c2;
+        const uint32_t n0 = h1 ^ c1 ^ k0, n2 = h0 ^ c3 ^ k1;
+        c0 = n0;
+        c1 = l1;
+        c2 = n2;
+        c3 = l0;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    return (float)(c0 >> 8) * 5.9604644775390625e-08f; /* 2^-24 */
+}
+
+#endif /* FPC_NUMERICS_H */

@@ -1,0 +1,184 @@
+/*
+ * fpcodec.h -- C ABI of libfpcodec.so (MI355X / gfx950).
+ *
+ * Drop-in boundary for the inference hot path of
+ * haiciyang/Feature-predictor-for-speech-codec.  The reference has no FFI of its
+ * own (pure Python); every entry point below names the reference interface it
+ * replaces (file:line under /root/reference) and is what a ctypes binding on the
+ * reference side calls.
+ *
+ * Conventions
+ *  - every function returns 0 (FPC_OK) or a negative fpc_status; nothing throws
+ *  - fpc_last_error() returns the text of the last failure on the calling thread
+ *  - "dev" pointers are device (HIP) pointers, "host" pointers are host memory
+ *  - handles are bound to the device that was current at creation
+ *  - launches are asynchronous on the given hipStream_t (passed as void*;
+ *    NULL = the null stream); no hidden synchronisation in the *_run calls
+ *  - there is NO CPU fallback: without a HIP device every create call fails
+ */
+#ifndef FPCODEC_H
+#define FPCODEC_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FPC_ABI_VERSION 1
+
+typedef enum {
+    FPC_OK = 0,
+    FPC_ERR_INVALID = -1, /* bad argument / shape */
+    FPC_ERR_HIP = -2,     /* HIP runtime error (text in fpc_last_error) */
+    FPC_ERR_NO_DEVICE = -3,
+    FPC_ERR_CAPACITY = -4 /* model does not fit the on-chip layout */
+} fpc_status;
+
+typedef void* fpc_stream; /* hipStream_t */
+
+const char* fpc_last_error(void);
+int fpc_abi_version(void);
+/* number of visible HIP devices (0 on a CPU-only host); never fails */
+int fpc_device_count(void);
+
+/* ------------------------------------------------------------------------
+ * Feature predictor  (src/models/wavernn.py:24-52 parameters,
+ *                     :63-102 forward, :165-256 encoder)
+ * Weight pointers are HOST pointers in the PyTorch state_dict layout
+ * (row-major, GRU gate rows ordered [r; z; n]).
+ * ---------------------------------------------------------------------- */
+typedef struct {
+    int in_features; /* 20 */
+    int gru_units1;  /* 384 */
+    int gru_units2;  /* 128 */
+    int fc_units;    /* 18  */
+    const float* rnn1_weight_ih; /* [3*H1, in]  rnn1.weight_ih_l0 */
+    const float* rnn1_weight_hh; /* [3*H1, H1]  rnn1.weight_hh_l0 */
+    const float* rnn1_bias_ih;   /* [3*H1] */
+    const float* rnn1_bias_hh;   /* [3*H1] */
+    const float* rnn2_weight_ih; /* [3*H2, H1]  rnn2.weight_ih_l0 */
+    const float* rnn2_weight_hh; /* [3*H2, H2] */
+    const float* rnn2_bias_ih;   /* [3*H2] */
+    const float* rnn2_bias_hh;   /* [3*H2] */
+    const float* fc_weight;      /* [fc, H2]    dual_fc.0.weight */
+    const float* fc_bias;        /* [fc]        dual_fc.0.bias */
+} fpc_predictor_weights;
+
+typedef struct fpc_predictor fpc_predictor;
+
+int fpc_predictor_create(const fpc_predictor_weights* w, fpc_predictor** out);
+void fpc_predictor_destroy(fpc_predictor* p);
+
+/* Wavernn.forward (wavernn.py:63-102): x [B,L,in] -> y [B,L,fc]; h1 [B,H1],
+ * h2 [B,H2] are read as initial state and overwritten with the final state.
+ * All pointers are device pointers. */
+int fpc_predictor_forward(fpc_predictor* p, const float* x_dev, int B, int L,
+                          float* h1_dev, float* h2_dev, float* y_dev, fpc_stream s);
+
+/* Codebooks (src/quantization/vq_func.py:134-185; file formats written by
+ * src/train_cb.py:125-130,217-221).  HOST pointers, float64.
+ *   vq_hi : S_hi stages (1 or 2), stage s has N_hi[s] rows of 17 doubles, stages
+ *           stored back to back                      (cfg['cb_path'])
+ *   vq_lo : one stage, N_lo rows of 17 (may be NULL/0) (cfg['bl_cb_path'])
+ *   scl_hi: n_hi scalars                              (cfg['scl_cb_path'])
+ *   scl_lo: n_lo scalars (may be NULL/0)              (cfg['bl_scl_cb_path'])
+ */
+typedef struct fpc_codebooks fpc_codebooks;
+int fpc_codebooks_create(const double* vq_hi, int S_hi, const int* N_hi,
+                         const double* vq_lo, int N_lo,
+                         const double* scl_hi, int n_hi,
+                         const double* scl_lo, int n_lo, fpc_codebooks** out);
+void fpc_codebooks_destroy(fpc_codebooks* c);
+
+/* Histogram block layout of fpc_encode's `hist` (= cb_tot of wavernn.py:189):
+ * [n_hi | n_lo | N_hi[0] | N_hi[1] | N_lo] unsigned 64-bit counters, absent
+ * codebooks contribute zero-length segments. */
+int fpc_codebooks_hist_size(const fpc_codebooks* c);
+
+/* Wavernn.encoder (wavernn.py:165-256), mask=None.  Device pointers.
+ *   feat   [B,L,20]   normalised features (cepstrum/24.1, pitch/24.1)
+ *   c_in   [B,L,20]   = reference c_in[:,1:,:]
+ *   r, r_qtz, r_under [B,L,18]
+ *   ind1, ind2 [B,L]  float 0/1 (reference ind1_mask/ind2_mask)
+ *   idx    [B,L,4]    int32 {scalar idx, vq stage-1, vq stage-2, below-thr vq idx};
+ *                     -1 where not coded; scalar idx is offset by +n_hi when it
+ *                     came from the below-threshold scalar codebook. May be NULL.
+ *   hist   see above; ADDED to (caller zeroes). May be NULL.
+ * qtz=0 reproduces the un-quantised branch (wavernn.py:244-252); cb may then be NULL. */
+int fpc_encode(fpc_predictor* p, const fpc_codebooks* cb, const float* feat_dev, int B, int L,
+               float l1, float l2, int qtz, float* c_in_dev, float* r_dev, float* r_qtz_dev,
+               float* r_under_dev, float* ind1_dev, float* ind2_dev, int32_t* idx_dev,
+               unsigned long long* hist_dev, fpc_stream s);
+
+/* Stand-alone quantizers with the reference call shapes
+ * (vq_quantize vq_func.py:134, scl_quantize vq_func.py:167).  Device pointers.
+ *   which = 0: above-threshold codebook, 1: below-threshold codebook
+ *   r [n,17] float32 -> qr [n,17] float64, idx [n,2] int32 (stage 2 = -1 if absent) */
+int fpc_vq_quantize(const fpc_codebooks* cb, int which, const float* r_dev, int n,
+                    double* qr_dev, int32_t* idx_dev, fpc_stream s);
+/*   x [n] float32 -> q [n] float64, idx [n] int32 */
+int fpc_scl_quantize(const fpc_codebooks* cb, int which, const float* x_dev, int n,
+                     double* q_dev, int32_t* idx_dev, fpc_stream s);
+
+/* ceps2lpc_v (src/ceps2lpc/ceps2lpc_vct.py:122-162): ceps [N,stride] float32
+ * (first 18 columns used, un-normalised i.e. already x24.1) -> lpc [N,16]. */
+int fpc_ceps2lpc(const float* ceps_dev, int N, int stride, float* lpc_dev, fpc_stream s);
+
+/* ------------------------------------------------------------------------
+ * LPCNet-style vocoder (NOT in /root/reference: xiph/LPCNet training_tf2/
+ * lpcnet.py + test_lpcnet.py, call site README.md:47; spec in DESIGN.md).
+ * Weight pointers are HOST pointers in Keras layouts.
+ * ---------------------------------------------------------------------- */
+typedef struct {
+    const float* embed_pitch;     /* [256,64]            */
+    const float* conv1_kernel;    /* [3,84,128]  (tap,in,out) */
+    const float* conv1_bias;      /* [128] */
+    const float* conv2_kernel;    /* [3,128,128] */
+    const float* conv2_bias;      /* [128] */
+    const float* dense1_kernel;   /* [128,128] (in,out) */
+    const float* dense1_bias;     /* [128] */
+    const float* dense2_kernel;   /* [128,128] */
+    const float* dense2_bias;     /* [128] */
+    const float* embed_sig;       /* [256,128] */
+    const float* gru_a_kernel;    /* [512,1152] rows: sig|pred|exc|cfeat, cols z|r|h */
+    const float* gru_a_recurrent; /* [384,1152] dense storage, block-sparse content */
+    const float* gru_a_bias;      /* [2,1152]   (input bias ; recurrent bias) */
+    const float* gru_b_kernel;    /* [512,48]   rows: gru_a out(384)|cfeat(128) */
+    const float* gru_b_recurrent; /* [16,48] */
+    const float* gru_b_bias;      /* [2,48] */
+    const float* md_kernel;       /* [256,16,2] MDense kernel (unit,in,channel) */
+    const float* md_bias;         /* [256,2] */
+    const float* md_factor;       /* [256,2] */
+} fpc_lpcnet_weights;
+
+typedef struct fpc_lpcnet fpc_lpcnet;
+
+int fpc_lpcnet_create(const fpc_lpcnet_weights* w, fpc_lpcnet** out);
+void fpc_lpcnet_destroy(fpc_lpcnet* m);
+
+/* bytes of device workspace fpc_lpcnet_synthesize needs for (B,T) */
+long long fpc_lpcnet_workspace_bytes(const fpc_lpcnet* m, int B, int T);
+
+/* test_lpcnet.py loop.  Device pointers.
+ *   features [B,T,36] float32 (un-normalised: cepstrum, pitch, corr, 16 LPC)
+ *   seeds    [B]      uint64  (Philox key of each utterance)
+ *   pcm      [B,T*160] int16  de-emphasised output; the first 17 samples of each
+ *                             utterance are 0 (test_lpcnet.py skips order+1)
+ *   workspace: at least fpc_lpcnet_workspace_bytes(B,T) bytes */
+int fpc_lpcnet_synthesize(fpc_lpcnet* m, const float* features_dev, int B, int T,
+                          const uint64_t* seeds_dev, int16_t* pcm_dev, void* workspace_dev,
+                          fpc_stream s);
+
+/* frame-rate conditioning only (enc of lpcnet.py): cfeat [B,T,128] */
+int fpc_lpcnet_condition(fpc_lpcnet* m, const float* features_dev, int B, int T,
+                         float* cfeat_dev, void* workspace_dev, fpc_stream s);
+
+/* average duration (ms) of the last decode-kernel launch measured with HIP
+ * events on the launch stream; synchronises on those events. <0 if none. */
+float fpc_lpcnet_last_decode_ms(fpc_lpcnet* m);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FPCODEC_H */
