@@ -1,0 +1,157 @@
+#!/usr/bin/env python3
+"""Benchmark of the hot path: LPCNet synthesis samples/s on synthetic 3-second utterances.
+
+    python bench.py --gpus 1 --steps 3 --warmup 1
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+A step = one pass of the vocoder (frame-rate conditioning kernels + persistent decode kernel)
+over one batch of --streams independent 3 s utterances per GPU (BASELINE config 3: 256
+utterances on one MI355X; with N GPUs every rank decodes its own 256: config 4, weak scaling,
+no collective in the data path - RCCL only gathers the timings).  Inputs (features, seeds,
+weights) are resident in HBM before the timed region.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FLOP_PER_SAMPLE = 145600.0      # 2 x 72 797 MAC per output sample per stream
+HBM_BYTES_PER_SAMPLE = 2.9      # 2 B PCM out + 144 B features / 160 samples
+PEAK_F32_TFLOPS = 157.3         # MI355X_MICROARCH.md: FP32 vector == f32 MFMA dense peak
+PEAK_HBM_GBS = 8000.0
+
+
+def cpu_baseline(frames=64):
+    """the CPU oracle (C restatement, single thread) on a bounded sample of the same workload"""
+    import fpcodec_amd
+    from oracle import oracle as O
+    synth = fpcodec_amd.synth
+    w = synth.lpcnet_weights()
+    orc = O.LPCNet(w)
+    f = synth.vocoder_features_raw(1, frames)[0]
+    f[:, 20:] = O.ceps2lpc(f[:, :20])[0]
+    n, t0 = 0, time.time()
+    reps = 0
+    while time.time() - t0 < 12.0:
+        orc.synthesize(f, 1004 + reps)
+        n += frames * 160 - 17
+        reps += 1
+    dt = time.time() - t0
+    return {"value": n / dt, "unit": "samples/s", "cores": 1, "kind": "port",
+            "sample": f"{reps} x one {frames}-frame utterance ({n} samples) through oracle/fpc_oracle.c "
+                      f"(orc_lpcnet_synthesize), single thread"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--streams", type=int, default=256, help="utterances per GPU per step")
+    ap.add_argument("--secs", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import fpcodec_amd
+    from fpcodec_amd import _lib
+    from fpcodec_amd.ceps2lpc import ceps2lpc_v
+    from fpcodec_amd.lpcnet import LPCNet
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    _lib.require_gpu()
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+
+    synth = fpcodec_amd.synth
+    B, T = args.streams, args.secs * 100
+    # synthetic features: distinct utterances per rank; a few distinct ones tiled to B keep
+    # host-side generation short without changing the device work (every stream has its own seed)
+    nuniq = min(B, 16)
+    base = synth.vocoder_features_raw(nuniq, T, utt0=rank * 100000)
+    feats = torch.from_numpy(np.tile(base, ((B + nuniq - 1) // nuniq, 1, 1))[:B].copy()).cuda()
+    lpc = ceps2lpc_v(feats.reshape(-1, 36)[:, :20].contiguous())[1]
+    feats[:, :, 20:] = lpc.reshape(B, T, 16)
+    seeds = torch.from_numpy(synth.seeds(B, utt0=rank * 100000).astype(np.int64)).cuda()
+    voc = LPCNet(synth.lpcnet_weights())
+    pcm = torch.empty(B, T * 160, dtype=torch.int16, device="cuda")
+
+    def step():
+        voc.synthesize(feats, seeds, out=pcm)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    dec_ms = []
+    for _ in range(args.steps):
+        step()
+        dec_ms.append(voc.last_decode_ms())  # HIP events around the decode kernel on its stream
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if dist:
+        tt = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+
+    samples_step = B * (T * 160 - 17)
+    total = samples_step * args.steps * world
+    value = total / dt
+    dec_s = float(np.mean(dec_ms)) / 1e3
+    dec_rate = samples_step / dec_s  # per GPU, decode kernel only
+
+    out = {
+        "metric": "LPCNet synthesis samples/sec (16 kHz RTF) per GPU; 1/2/4/8-GPU throughput",
+        "value": value, "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"BASELINE config 3/4: {B} independent {args.secs} s utterances per GPU "
+                               f"(T={T} frames, {T * 160} samples each), GRU_A=384 block-sparse, fixed Philox RNG",
+                   "streams_per_gpu": B, "frames": T},
+        "rtf_aggregate": value / 16000.0,
+        "rtf_per_stream": dec_rate / B / 16000.0,
+        "roofline": {
+            "bound": "mfma", "note": "f32 VALU sparse mat-vec; f32 vector peak == f32 MFMA dense peak (157.3 TF)",
+            "kernel": "k_decode", "achieved": dec_rate * FLOP_PER_SAMPLE / 1e12, "peak": PEAK_F32_TFLOPS,
+            "unit": "TFLOP/s", "frac": dec_rate * FLOP_PER_SAMPLE / 1e12 / PEAK_F32_TFLOPS,
+            "traffic": None, "launch_ms": dec_s * 1e3,
+            "hbm": {"achieved": dec_rate * HBM_BYTES_PER_SAMPLE / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                    "frac": dec_rate * HBM_BYTES_PER_SAMPLE / 1e9 / PEAK_HBM_GBS},
+        },
+    }
+    if rank == 0:
+        # single-stream latency view (BASELINE config 2), outside the timed region
+        one = torch.empty(1, T * 160, dtype=torch.int16, device="cuda")
+        voc.synthesize(feats[:1], seeds[:1], out=one)
+        torch.cuda.synchronize()
+        voc.synthesize(feats[:1], seeds[:1], out=one)
+        ms1 = voc.last_decode_ms()
+        out["single_stream"] = {"decode_ms": ms1, "samples_per_s": (T * 160 - 17) / (ms1 / 1e3),
+                                "rtf": (T * 160 - 17) / (ms1 / 1e3) / 16000.0}
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out), flush=True)
+    if dist:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

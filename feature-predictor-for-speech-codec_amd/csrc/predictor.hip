@@ -1,0 +1,632 @@
+// predictor.hip -- GRU feature predictor, closed-loop residual encoder and the
+// scalar / multi-stage M-best vector quantizers, hand-written HIP for gfx950.
+//
+// Reference interfaces replaced (paths under /root/reference/src):
+//   Wavernn.forward        models/wavernn.py:63-102
+//   Wavernn.encoder        models/wavernn.py:165-256   (mask=None)
+//   vq_quantize_mbest      quantization/vq_func.py:10-24
+//   quantize_mstage        quantization/vq_func.py:82-131 (S in {1,2})
+//   vq_quantize            quantization/vq_func.py:134-164
+//   scl_quantize           quantization/vq_func.py:167-185
+//
+// One workgroup per utterance runs the whole closed loop (predict -> residual ->
+// threshold -> quantize -> feed back) on chip: the reference's per-frame, per-element
+// device->host->NumPy->device round trip (wavernn.py:217-238) is gone.  Matrix rows are
+// evaluated as k-ordered fmaf chains from the bias (what a gfx950 f32 MFMA accumulates),
+// distances in float64 with numpy's pairwise association, so results match the CPU
+// oracle bit for bit and the reference's indices exactly.
+#include "fpc_common.h"
+
+namespace {
+
+constexpr int NT = 576;  // 9 wave64; 2 x 576 = 1152 gate rows of GRU1
+constexpr int NW = NT / 64;
+constexpr int MAX_H1 = 512, MAX_H2 = 256, MAX_IN = 64, MAX_FC = 32;
+constexpr int NDIM = 17, SURV = 5;
+
+struct PredDev {
+    int in, h1, h2, fc;
+    const float *w1i, *w1h, *b1i, *b1h;  // transposed: [K][3H]
+    const float *w2i, *w2h, *b2i, *b2h;
+    const float *fcw, *fcb;  // [H2][fc]
+};
+
+struct CbDev {
+    int S_hi, N_hi0, N_hi1, N_lo, n_hi, n_lo;
+    const double *vq_hi0, *vq_hi1, *vq_lo;     // transposed [17][N]
+    const double *vq_hi0_r, *vq_hi1_r, *vq_lo_r;  // row-major [N][17] (entry fetch)
+    const double *scl_hi, *scl_lo;
+};
+
+struct __attribute__((aligned(16))) PredLds {
+    float x[MAX_IN];
+    float h1[MAX_H1];
+    float h2[MAX_H2];
+    float gi[3 * MAX_H1];
+    float gh[3 * MAX_H1];
+    float relu[MAX_H2];
+    float fo[MAX_FC];
+    float rs[MAX_FC];
+    double xq[SURV][NDIM];      // search targets (stage 1: xq[0]; stage 2: 5 residuals)
+    double wd[SURV][NW][SURV];  // per-wave M-best lists
+    int wi[SURV][NW][SURV];
+    double od[SURV][SURV];      // merged M-best lists
+    int oi[SURV][SURV];
+    double sd[NW];              // scalar arg-min scratch
+    int si[NW];
+    int res_i[4];
+    double qv[NDIM];
+    double qs;
+};
+
+// ---- GRU layer: both mat-vecs as k-ordered fmaf chains, two rows per thread ----
+__device__ void gru_layer(const float* __restrict__ wiT, const float* __restrict__ whT,
+                          const float* __restrict__ bi, const float* __restrict__ bh,
+                          const float* x, int K, float* h, int H, float* gi, float* gh, int tid) {
+    const int R = 3 * H;
+    for (int r0 = tid; r0 < R; r0 += 2 * NT) {
+        const int r1 = r0 + NT;
+        const bool two = r1 < R;
+        const int r1c = two ? r1 : r0;
+        float ai0 = bi[r0], ai1 = bi[r1c], ah0 = bh[r0], ah1 = bh[r1c];
+        for (int k = 0; k < K; ++k) {
+            const float xv = x[k];
+            ai0 = fmaf(xv, wiT[(size_t)k * R + r0], ai0);
+            ai1 = fmaf(xv, wiT[(size_t)k * R + r1c], ai1);
+        }
+#pragma unroll 4
+        for (int k = 0; k < H; ++k) {
+            const float hv = h[k];
+            ah0 = fmaf(hv, whT[(size_t)k * R + r0], ah0);
+            ah1 = fmaf(hv, whT[(size_t)k * R + r1c], ah1);
+        }
+        gi[r0] = ai0;
+        gh[r0] = ah0;
+        if (two) {
+            gi[r1] = ai1;
+            gh[r1] = ah1;
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < H; i += NT) {  // torch.nn.GRU gate rows [r; z; n]
+        const float r = fpc_sigmoidf(gi[i] + gh[i]);
+        const float z = fpc_sigmoidf(gi[H + i] + gh[H + i]);
+        const float n = fpc_tanhf(fmaf(r, gh[2 * H + i], gi[2 * H + i]));
+        h[i] = fmaf(z, h[i] - n, n);
+    }
+    __syncthreads();
+}
+
+// one frame of Wavernn.forward: L.x -> L.fo, states in L.h1/L.h2
+__device__ void pred_step(const PredDev& P, PredLds& L, int tid) {
+    gru_layer(P.w1i, P.w1h, P.b1i, P.b1h, L.x, P.in, L.h1, P.h1, L.gi, L.gh, tid);
+    gru_layer(P.w2i, P.w2h, P.b2i, P.b2h, L.h1, P.h1, L.h2, P.h2, L.gi, L.gh, tid);
+    for (int i = tid; i < P.h2; i += NT) L.relu[i] = L.h2[i] > 0.0f ? L.h2[i] : 0.0f;
+    __syncthreads();
+    if (tid < P.fc) {
+        float acc = P.fcb[tid];
+        for (int k = 0; k < P.h2; ++k) acc = fmaf(L.relu[k], P.fcw[(size_t)k * P.fc + tid], acc);
+        const float t = fpc_tanhf(acc);
+        L.fo[tid] = t + t;  // the "dual" FC is the same Linear summed twice (wavernn.py:89-92)
+    }
+    __syncthreads();
+}
+
+// ---- float64 squared distance with numpy's pairwise association (vq_func.py:18) ----
+__device__ __forceinline__ double dist17(const double* x, const double* __restrict__ cbT, int N, int e) {
+    double r[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const double d = x[j] - cbT[(size_t)j * N + e];
+        r[j] = d * d;
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const double d = x[8 + j] - cbT[(size_t)(8 + j) * N + e];
+        const double dd = d * d;
+        r[j] = r[j] + dd;
+    }
+    double res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+    const double d = x[16] - cbT[(size_t)16 * N + e];
+    const double dd = d * d;
+    res = res + dd;
+    return res;
+}
+
+__device__ __forceinline__ void wave_argmin(double& d, int& i) {
+#pragma unroll
+    for (int s = 1; s < 64; s <<= 1) {
+        const double od = __shfl_xor(d, s);
+        const int oi = __shfl_xor(i, s);
+        if (od < d || (od == d && oi < i)) {
+            d = od;
+            i = oi;
+        }
+    }
+}
+
+// per-wave M-best (5 smallest by (distance, index)) of search `srch` -> L.wd/L.wi
+__device__ void wave_mbest(PredLds& L, int srch, const double* __restrict__ cbT, int N, int tid) {
+    const int wave = tid >> 6, lane = tid & 63;
+    double d5[SURV];
+    int i5[SURV];
+#pragma unroll
+    for (int m = 0; m < SURV; ++m) {
+        d5[m] = INFINITY;
+        i5[m] = 0x7fffffff;
+    }
+    for (int e = tid; e < N; e += NT) {  // ascending e: strict < keeps the lower index first
+        double d = dist17(L.xq[srch], cbT, N, e);
+        int ix = e;
+#pragma unroll
+        for (int m = 0; m < SURV; ++m) {
+            if (d < d5[m]) {
+                const double td = d5[m];
+                const int ti = i5[m];
+                d5[m] = d;
+                i5[m] = ix;
+                d = td;
+                ix = ti;
+            }
+        }
+    }
+    for (int rnd = 0; rnd < SURV; ++rnd) {
+        double d = d5[0];
+        int ix = i5[0];
+        wave_argmin(d, ix);
+        if (i5[0] == ix && ix != 0x7fffffff) {  // this lane's head won: pop it
+#pragma unroll
+            for (int m = 0; m < SURV - 1; ++m) {
+                d5[m] = d5[m + 1];
+                i5[m] = i5[m + 1];
+            }
+            d5[SURV - 1] = INFINITY;
+            i5[SURV - 1] = 0x7fffffff;
+        }
+        if (lane == 0) {
+            L.wd[srch][wave][rnd] = d;
+            L.wi[srch][wave][rnd] = ix;
+        }
+    }
+}
+
+// merge the per-wave lists of search `srch` (executed by ONE wave) -> L.od/L.oi
+__device__ void merge_mbest(PredLds& L, int srch, int lane) {
+    double d = INFINITY;
+    int ix = 0x7fffffff;
+    if (lane < NW * SURV) {
+        d = L.wd[srch][lane / SURV][lane % SURV];
+        ix = L.wi[srch][lane / SURV][lane % SURV];
+    }
+    for (int rnd = 0; rnd < SURV; ++rnd) {
+        double md = d;
+        int mi = ix;
+        wave_argmin(md, mi);
+        if (ix == mi) {
+            d = INFINITY;
+            ix = 0x7fffffff;
+        }
+        if (lane == 0) {
+            L.od[srch][rnd] = md;
+            L.oi[srch][rnd] = mi;
+        }
+    }
+}
+
+// quantize_mstage (vq_func.py:82-131) on L.rs[1..17]; result in L.qv, L.res_i[0..1].
+// Block-uniform control flow; ends with a barrier.
+__device__ void vq_mstage(PredLds& L, int S, const double* cb0T, const double* cb0R, int N0,
+                          const double* cb1T, const double* cb1R, int N1, int tid) {
+    const int wave = tid >> 6, lane = tid & 63;
+    if (tid < NDIM) L.xq[0][tid] = (double)L.rs[1 + tid];
+    __syncthreads();
+    wave_mbest(L, 0, cb0T, N0, tid);
+    __syncthreads();
+    if (wave == 0) merge_mbest(L, 0, lane);
+    __syncthreads();
+    if (S == 1) {
+        if (tid < NDIM) L.qv[tid] = cb0R[(size_t)L.oi[0][0] * NDIM + tid];
+        if (tid == 0) {
+            L.res_i[0] = L.oi[0][0];
+            L.res_i[1] = -1;
+        }
+        __syncthreads();
+        return;
+    }
+    // stage 2: residual of every survivor, searched concurrently
+    int s1[SURV];
+#pragma unroll
+    for (int k = 0; k < SURV; ++k) s1[k] = L.oi[0][k];
+    __syncthreads();  // everyone has read stage-1 results before od/oi are reused
+    if (tid < SURV * NDIM) {
+        const int k = tid / NDIM, d = tid % NDIM;
+        L.xq[k][d] = (double)L.rs[1 + d] - cb0R[(size_t)s1[k] * NDIM + d];
+    }
+    __syncthreads();
+    for (int k = 0; k < SURV; ++k) wave_mbest(L, k, cb1T, N1, tid);
+    __syncthreads();
+    if (wave < SURV) merge_mbest(L, wave, lane);
+    __syncthreads();
+    if (tid == 0) {  // merge-insert of candidate paths (vq_func.py:110-125)
+        int b0[SURV], b1[SURV];
+        double glob[SURV];
+        for (int m = 0; m < SURV; ++m) {
+            b0[m] = s1[0];
+            b1[m] = L.oi[0][m];
+            glob[m] = L.od[0][m];
+        }
+        for (int k = 1; k < SURV; ++k) {
+            if (L.od[k][0] < glob[SURV - 1]) {
+                int m = 0;
+                for (int p = 0; p < SURV; ++p) {
+                    if (L.od[k][m] < glob[p]) {
+                        for (int j = SURV - 1; j > p; --j) {
+                            glob[j] = glob[j - 1];
+                            b0[j] = b0[j - 1];
+                            b1[j] = b1[j - 1];
+                        }
+                        glob[p] = L.od[k][m];
+                        b0[p] = s1[k];
+                        b1[p] = L.oi[k][m];
+                        ++m;
+                    }
+                }
+            }
+        }
+        L.res_i[0] = b0[0];
+        L.res_i[1] = b1[0];
+    }
+    __syncthreads();
+    if (tid < NDIM)
+        L.qv[tid] = cb0R[(size_t)L.res_i[0] * NDIM + tid] + cb1R[(size_t)L.res_i[1] * NDIM + tid];
+    __syncthreads();
+}
+
+// scl_quantize (vq_func.py:167-185): first arg-min of (x-c)^2 in float64 -> L.qs, L.res_i[2]
+__device__ void scl_search(PredLds& L, float xv, const double* __restrict__ codes, int n, int tid) {
+    const int wave = tid >> 6, lane = tid & 63;
+    double bd = INFINITY;
+    int bi = 0x7fffffff;
+    const double v = (double)xv;
+    for (int c = tid; c < n; c += NT) {
+        const double df = v - codes[c];
+        const double d = df * df;
+        if (d < bd) {
+            bd = d;
+            bi = c;
+        }
+    }
+    wave_argmin(bd, bi);
+    if (lane == 0) {
+        L.sd[wave] = bd;
+        L.si[wave] = bi;
+    }
+    __syncthreads();
+    if (wave == 0) {
+        double d = lane < NW ? L.sd[lane] : INFINITY;
+        int ix = lane < NW ? L.si[lane] : 0x7fffffff;
+        wave_argmin(d, ix);
+        if (lane == 0) {
+            L.res_i[2] = ix;
+            L.qs = codes[ix];
+        }
+    }
+    __syncthreads();
+}
+
+// ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(NT) void k_forward(const PredDev P, const float* __restrict__ x, int Lf,
+                                                float* h1, float* h2, float* __restrict__ y) {
+    __shared__ PredLds L;
+    const int b = blockIdx.x, tid = threadIdx.x;
+    for (int i = tid; i < P.h1; i += NT) L.h1[i] = h1[(size_t)b * P.h1 + i];
+    for (int i = tid; i < P.h2; i += NT) L.h2[i] = h2[(size_t)b * P.h2 + i];
+    __syncthreads();
+    for (int t = 0; t < Lf; ++t) {
+        if (tid < P.in) L.x[tid] = x[((size_t)b * Lf + t) * P.in + tid];
+        __syncthreads();
+        pred_step(P, L, tid);
+        if (tid < P.fc) y[((size_t)b * Lf + t) * P.fc + tid] = L.fo[tid];
+    }
+    __syncthreads();
+    for (int i = tid; i < P.h1; i += NT) h1[(size_t)b * P.h1 + i] = L.h1[i];
+    for (int i = tid; i < P.h2; i += NT) h2[(size_t)b * P.h2 + i] = L.h2[i];
+}
+
+struct EncArgs {
+    const float* feat;
+    int Lf;
+    float l1, l2;
+    int qtz;
+    float *c_in, *r, *r_qtz, *r_under, *ind1, *ind2;
+    int* idx;
+    unsigned long long* hist;
+};
+
+__global__ __launch_bounds__(NT) void k_encode(const PredDev P, const CbDev C, const EncArgs A) {
+    __shared__ PredLds L;
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int Cc = P.in, F = P.fc;
+    for (int i = tid; i < P.h1; i += NT) L.h1[i] = 0.0f;  // h=None -> zeros (wavernn.py:182)
+    for (int i = tid; i < P.h2; i += NT) L.h2[i] = 0.0f;
+    if (tid < Cc) L.x[tid] = 0.0f;  // c_in[:,0,:] is all zero (wavernn.py:177-178)
+    __syncthreads();
+    const int off_sl = C.n_hi, off_v0 = off_sl + C.n_lo, off_v1 = off_v0 + C.N_hi0,
+              off_vl = off_v1 + (C.S_hi == 2 ? C.N_hi1 : 0);
+    for (int i = 0; i < A.Lf; ++i) {
+        const size_t fi = (size_t)b * A.Lf + i;
+        const float* f = A.feat + fi * Cc;
+        pred_step(P, L, tid);  // wavernn.py:194-195
+        if (tid < F) L.rs[tid] = f[tid] - L.fo[tid];  // :196
+        __syncthreads();
+        float sabs = 0.0f;
+        for (int d = 1; d < F; ++d) sabs += fabsf(L.rs[d]);
+        const int i1 = fabsf(L.rs[0]) > A.l1;  // :202
+        const int i2 = sabs > A.l2;            // :206
+        float rq = 0.0f;                       // this thread's r_qtz[d] (tid < F)
+        int ix0 = -1, ix1 = -1, ix2 = -1, ix3 = -1;
+        if (A.qtz) {
+            if (i1 || C.scl_lo) {  // :218-225
+                scl_search(L, L.rs[0], i1 ? C.scl_hi : C.scl_lo, i1 ? C.n_hi : C.n_lo, tid);
+                if (tid == 0) {
+                    rq = (float)L.qs;
+                    ix0 = L.res_i[2] + (i1 ? 0 : C.n_hi);
+                    if (A.hist) atomicAdd(&A.hist[(i1 ? 0 : off_sl) + L.res_i[2]], 1ull);
+                }
+            }
+            if (i2) {  // :229-234
+                vq_mstage(L, C.S_hi, C.vq_hi0, C.vq_hi0_r, C.N_hi0, C.vq_hi1, C.vq_hi1_r, C.N_hi1, tid);
+                if (tid >= 1 && tid < F) rq = (float)L.qv[tid - 1];
+                if (tid == 0) {
+                    ix1 = L.res_i[0];
+                    ix2 = L.res_i[1];
+                    if (A.hist) {
+                        atomicAdd(&A.hist[off_v0 + ix1], 1ull);
+                        if (C.S_hi == 2) atomicAdd(&A.hist[off_v1 + ix2], 1ull);
+                    }
+                }
+            } else if (C.vq_lo) {  // :235-240
+                vq_mstage(L, 1, C.vq_lo, C.vq_lo_r, C.N_lo, nullptr, nullptr, 0, tid);
+                if (tid >= 1 && tid < F) rq = (float)L.qv[tid - 1];
+                if (tid == 0) {
+                    ix3 = L.res_i[0];
+                    if (A.hist) atomicAdd(&A.hist[off_vl + ix3], 1ull);
+                }
+            }
+        }
+        if (tid < F) {
+            const float rs = L.rs[tid];
+            const int ind = tid == 0 ? i1 : i2;
+            float rv, ru, cn;
+            if (A.qtz) {
+                rv = rs;  // un-thresholded residual (:197)
+                ru = 0.0f;
+                cn = L.fo[tid] + rq;  // :242
+            } else {                  // :244-252
+                ru = rs * (float)(1 - ind);
+                rv = rs * (float)ind;
+                cn = L.fo[tid] + rv;
+            }
+            A.r[fi * F + tid] = rv;
+            A.r_qtz[fi * F + tid] = rq;
+            A.r_under[fi * F + tid] = ru;
+            A.c_in[fi * Cc + tid] = cn;
+            L.x[tid] = cn;
+        } else if (tid < Cc) {  // pitch columns pass through (:178)
+            const float v = f[tid];
+            A.c_in[fi * Cc + tid] = v;
+            L.x[tid] = v;
+        }
+        if (tid == 0) {
+            A.ind1[fi] = (float)i1;
+            A.ind2[fi] = (float)i2;
+            if (A.idx) {
+                A.idx[fi * 4 + 0] = ix0;
+                A.idx[fi * 4 + 1] = ix1;
+                A.idx[fi * 4 + 2] = ix2;
+                A.idx[fi * 4 + 3] = ix3;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// stand-alone quantizers: one workgroup per input row
+__global__ __launch_bounds__(NT) void k_vq(const CbDev C, int which, const float* __restrict__ r, double* qr,
+                                           int* idx) {
+    __shared__ PredLds L;
+    const int n = blockIdx.x, tid = threadIdx.x;
+    if (tid < NDIM) L.rs[1 + tid] = r[(size_t)n * NDIM + tid];
+    __syncthreads();
+    if (which == 0)
+        vq_mstage(L, C.S_hi, C.vq_hi0, C.vq_hi0_r, C.N_hi0, C.vq_hi1, C.vq_hi1_r, C.N_hi1, tid);
+    else
+        vq_mstage(L, 1, C.vq_lo, C.vq_lo_r, C.N_lo, nullptr, nullptr, 0, tid);
+    if (tid < NDIM) qr[(size_t)n * NDIM + tid] = L.qv[tid];
+    if (tid < 2 && idx) idx[n * 2 + tid] = L.res_i[tid];
+}
+
+__global__ __launch_bounds__(NT) void k_scl(const CbDev C, int which, const float* __restrict__ x, double* q,
+                                            int* idx) {
+    __shared__ PredLds L;
+    const int n = blockIdx.x, tid = threadIdx.x;
+    scl_search(L, x[n], which == 0 ? C.scl_hi : C.scl_lo, which == 0 ? C.n_hi : C.n_lo, tid);
+    if (tid == 0) {
+        q[n] = L.qs;
+        if (idx) idx[n] = L.res_i[2];
+    }
+}
+
+}  // namespace
+
+// =====================================================================================
+// host side
+// =====================================================================================
+struct fpc_predictor {
+    PredDev d;
+    fpc::DevBuf buf[10];
+};
+
+struct fpc_codebooks {
+    CbDev d;
+    fpc::DevBuf buf[8];
+    int hist_size = 0;
+};
+
+static std::vector<float> transpose_f(const float* src, int rows, int cols) {
+    std::vector<float> t((size_t)rows * cols);
+    for (int r = 0; r < rows; ++r)
+        for (int c = 0; c < cols; ++c) t[(size_t)c * rows + r] = src[(size_t)r * cols + c];
+    return t;
+}
+
+extern "C" int fpc_predictor_create(const fpc_predictor_weights* w, fpc_predictor** out) {
+    FPC_REQUIRE(w && out, "fpc_predictor_create: null argument");
+    if (!fpc::have_device()) {
+        fpc::set_error("fpc_predictor_create: no HIP device (libfpcodec has no CPU fallback)");
+        return FPC_ERR_NO_DEVICE;
+    }
+    FPC_REQUIRE(w->in_features > 0 && w->in_features <= MAX_IN && w->gru_units1 > 0 &&
+                    w->gru_units1 <= MAX_H1 && w->gru_units2 > 0 && w->gru_units2 <= MAX_H2 &&
+                    w->fc_units > 0 && w->fc_units <= MAX_FC && w->fc_units <= w->in_features,
+                "fpc_predictor_create: unsupported sizes in=%d h1=%d h2=%d fc=%d", w->in_features,
+                w->gru_units1, w->gru_units2, w->fc_units);
+    FPC_REQUIRE(w->rnn1_weight_ih && w->rnn1_weight_hh && w->rnn1_bias_ih && w->rnn1_bias_hh &&
+                    w->rnn2_weight_ih && w->rnn2_weight_hh && w->rnn2_bias_ih && w->rnn2_bias_hh &&
+                    w->fc_weight && w->fc_bias,
+                "fpc_predictor_create: null weight pointer");
+    fpc_predictor* p = new fpc_predictor();
+    const int in = w->in_features, h1 = w->gru_units1, h2 = w->gru_units2, fc = w->fc_units;
+    p->d.in = in;
+    p->d.h1 = h1;
+    p->d.h2 = h2;
+    p->d.fc = fc;
+    auto upv = [&](fpc::DevBuf& b, const std::vector<float>& v, const float** dst) -> hipError_t {
+        hipError_t e = b.upload(v);
+        *dst = b.as<float>();
+        return e;
+    };
+    auto vec = [](const float* s, size_t n) { return std::vector<float>(s, s + n); };
+    FPC_HIP(upv(p->buf[0], transpose_f(w->rnn1_weight_ih, 3 * h1, in), &p->d.w1i));
+    FPC_HIP(upv(p->buf[1], transpose_f(w->rnn1_weight_hh, 3 * h1, h1), &p->d.w1h));
+    FPC_HIP(upv(p->buf[2], vec(w->rnn1_bias_ih, 3 * h1), &p->d.b1i));
+    FPC_HIP(upv(p->buf[3], vec(w->rnn1_bias_hh, 3 * h1), &p->d.b1h));
+    FPC_HIP(upv(p->buf[4], transpose_f(w->rnn2_weight_ih, 3 * h2, h1), &p->d.w2i));
+    FPC_HIP(upv(p->buf[5], transpose_f(w->rnn2_weight_hh, 3 * h2, h2), &p->d.w2h));
+    FPC_HIP(upv(p->buf[6], vec(w->rnn2_bias_ih, 3 * h2), &p->d.b2i));
+    FPC_HIP(upv(p->buf[7], vec(w->rnn2_bias_hh, 3 * h2), &p->d.b2h));
+    FPC_HIP(upv(p->buf[8], transpose_f(w->fc_weight, fc, h2), &p->d.fcw));
+    FPC_HIP(upv(p->buf[9], vec(w->fc_bias, fc), &p->d.fcb));
+    *out = p;
+    return FPC_OK;
+}
+
+extern "C" void fpc_predictor_destroy(fpc_predictor* p) { delete p; }
+
+extern "C" int fpc_predictor_forward(fpc_predictor* p, const float* x_dev, int B, int L,
+                                     float* h1_dev, float* h2_dev, float* y_dev, fpc_stream s) {
+    FPC_REQUIRE(p && x_dev && h1_dev && h2_dev && y_dev, "fpc_predictor_forward: null argument");
+    FPC_REQUIRE(B > 0 && L >= 0, "fpc_predictor_forward: bad shape B=%d L=%d", B, L);
+    hipLaunchKernelGGL(k_forward, dim3(B), dim3(NT), 0, static_cast<hipStream_t>(s), p->d, x_dev, L,
+                       h1_dev, h2_dev, y_dev);
+    FPC_HIP(hipGetLastError());
+    return FPC_OK;
+}
+
+extern "C" int fpc_codebooks_create(const double* vq_hi, int S_hi, const int* N_hi,
+                                    const double* vq_lo, int N_lo, const double* scl_hi, int n_hi,
+                                    const double* scl_lo, int n_lo, fpc_codebooks** out) {
+    FPC_REQUIRE(out && vq_hi && N_hi && scl_hi, "fpc_codebooks_create: null argument");
+    // the reference's quantize_mstage only works for 1 or 2 stages (vq_func.py:111 breaks at 3)
+    FPC_REQUIRE(S_hi == 1 || S_hi == 2, "fpc_codebooks_create: %d stages unsupported (1 or 2)", S_hi);
+    FPC_REQUIRE(N_hi[0] >= SURV && (S_hi == 1 || N_hi[1] >= SURV) && n_hi > 0,
+                "fpc_codebooks_create: codebook smaller than %d survivors", SURV);
+    FPC_REQUIRE((vq_lo == nullptr) == (N_lo == 0) && (scl_lo == nullptr) == (n_lo == 0),
+                "fpc_codebooks_create: below-threshold codebook pointer/size mismatch");
+    FPC_REQUIRE(N_lo == 0 || N_lo >= SURV, "fpc_codebooks_create: vq_lo smaller than %d survivors", SURV);
+    if (!fpc::have_device()) {
+        fpc::set_error("fpc_codebooks_create: no HIP device (libfpcodec has no CPU fallback)");
+        return FPC_ERR_NO_DEVICE;
+    }
+    fpc_codebooks* c = new fpc_codebooks();
+    memset(&c->d, 0, sizeof c->d);
+    c->d.S_hi = S_hi;
+    c->d.N_hi0 = N_hi[0];
+    c->d.N_hi1 = S_hi == 2 ? N_hi[1] : 0;
+    c->d.N_lo = N_lo;
+    c->d.n_hi = n_hi;
+    c->d.n_lo = n_lo;
+    auto up_cb = [&](int slot, const double* src, int N, const double** dT, const double** dR) -> hipError_t {
+        std::vector<double> t((size_t)N * NDIM), r(src, src + (size_t)N * NDIM);
+        for (int e = 0; e < N; ++e)
+            for (int d = 0; d < NDIM; ++d) t[(size_t)d * N + e] = src[(size_t)e * NDIM + d];
+        hipError_t e1 = c->buf[slot].upload(t);
+        if (e1 != hipSuccess) return e1;
+        *dT = c->buf[slot].as<double>();
+        e1 = c->buf[slot + 1].upload(r);
+        *dR = c->buf[slot + 1].as<double>();
+        return e1;
+    };
+    FPC_HIP(up_cb(0, vq_hi, N_hi[0], &c->d.vq_hi0, &c->d.vq_hi0_r));
+    if (S_hi == 2)
+        FPC_HIP(up_cb(2, vq_hi + (size_t)N_hi[0] * NDIM, N_hi[1], &c->d.vq_hi1, &c->d.vq_hi1_r));
+    if (vq_lo) FPC_HIP(up_cb(4, vq_lo, N_lo, &c->d.vq_lo, &c->d.vq_lo_r));
+    {
+        std::vector<double> v(scl_hi, scl_hi + n_hi);
+        FPC_HIP(c->buf[6].upload(v));
+        c->d.scl_hi = c->buf[6].as<double>();
+    }
+    if (scl_lo) {
+        std::vector<double> v(scl_lo, scl_lo + n_lo);
+        FPC_HIP(c->buf[7].upload(v));
+        c->d.scl_lo = c->buf[7].as<double>();
+    }
+    c->hist_size = n_hi + n_lo + c->d.N_hi0 + c->d.N_hi1 + N_lo;
+    *out = c;
+    return FPC_OK;
+}
+
+extern "C" void fpc_codebooks_destroy(fpc_codebooks* c) { delete c; }
+extern "C" int fpc_codebooks_hist_size(const fpc_codebooks* c) { return c ? c->hist_size : 0; }
+
+extern "C" int fpc_encode(fpc_predictor* p, const fpc_codebooks* cb, const float* feat_dev, int B,
+                          int L, float l1, float l2, int qtz, float* c_in_dev, float* r_dev,
+                          float* r_qtz_dev, float* r_under_dev, float* ind1_dev, float* ind2_dev,
+                          int32_t* idx_dev, unsigned long long* hist_dev, fpc_stream s) {
+    FPC_REQUIRE(p && feat_dev && c_in_dev && r_dev && r_qtz_dev && r_under_dev && ind1_dev && ind2_dev,
+                "fpc_encode: null argument");
+    FPC_REQUIRE(B > 0 && L >= 0, "fpc_encode: bad shape B=%d L=%d", B, L);
+    FPC_REQUIRE(!qtz || cb, "fpc_encode: qtz=1 needs codebooks");
+    FPC_REQUIRE(p->d.fc == NDIM + 1, "fpc_encode: fc_units must be 18 (c0 + 17-dim VQ), got %d", p->d.fc);
+    if (L == 0) return FPC_OK;
+    CbDev cd;
+    memset(&cd, 0, sizeof cd);
+    if (cb) cd = cb->d;
+    EncArgs a{feat_dev, L,  l1, l2, qtz ? 1 : 0, c_in_dev, r_dev, r_qtz_dev, r_under_dev, ind1_dev, ind2_dev,
+              idx_dev,  hist_dev};
+    hipLaunchKernelGGL(k_encode, dim3(B), dim3(NT), 0, static_cast<hipStream_t>(s), p->d, cd, a);
+    FPC_HIP(hipGetLastError());
+    return FPC_OK;
+}
+
+extern "C" int fpc_vq_quantize(const fpc_codebooks* cb, int which, const float* r_dev, int n,
+                               double* qr_dev, int32_t* idx_dev, fpc_stream s) {
+    FPC_REQUIRE(cb && r_dev && qr_dev, "fpc_vq_quantize: null argument");
+    FPC_REQUIRE(which == 0 || (which == 1 && cb->d.vq_lo), "fpc_vq_quantize: codebook %d not loaded", which);
+    if (n <= 0) return FPC_OK;
+    hipLaunchKernelGGL(k_vq, dim3(n), dim3(NT), 0, static_cast<hipStream_t>(s), cb->d, which, r_dev, qr_dev,
+                       idx_dev);
+    FPC_HIP(hipGetLastError());
+    return FPC_OK;
+}
+
+extern "C" int fpc_scl_quantize(const fpc_codebooks* cb, int which, const float* x_dev, int n,
+                                double* q_dev, int32_t* idx_dev, fpc_stream s) {
+    FPC_REQUIRE(cb && x_dev && q_dev, "fpc_scl_quantize: null argument");
+    FPC_REQUIRE(which == 0 || (which == 1 && cb->d.scl_lo), "fpc_scl_quantize: codebook %d not loaded", which);
+    if (n <= 0) return FPC_OK;
+    hipLaunchKernelGGL(k_scl, dim3(n), dim3(NT), 0, static_cast<hipStream_t>(s), cb->d, which, x_dev, q_dev,
+                       idx_dev);
+    FPC_HIP(hipGetLastError());
+    return FPC_OK;
+}

@@ -112,6 +112,11 @@ def lpcnet_weights(seed=SEED_VOCODER, density=(0.05, 0.05, 0.2)):
         "md_bias": rng.normal(0, 0.3, (256, 2)).astype(np.float32),
         "md_factor": rng.uniform(0.5, 1.5, (256, 2)).astype(np.float32),
     }
+    # bias the tree towards excitation values near 128 (small residual), as a trained
+    # LPCNet does: nodes under the MSB=1 half prefer bit 0, nodes under MSB=0 prefer bit 1
+    for n in range(2, 256):
+        top = (n >> (n.bit_length() - 2)) & 1
+        w["md_bias"][n] += np.float32(-1.2 if top else 1.2)
     N = 384
     rec = glorot((N, 3 * N), N, N) * np.float32(2.0)
     for g, d in enumerate(density):

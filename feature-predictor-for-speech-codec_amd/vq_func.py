@@ -1,0 +1,152 @@
+"""Quantizers with the reference's signatures (src/quantization/vq_func.py) on the HIP
+search kernels: `vq_quantize(r, cb_path)` (:134-164), `scl_quantize(data, cb_path)`
+(:167-185), plus `cal_entropy` (src/generate_qtz_features.py:94-101).
+
+Codebook files keep the reference formats: VQ `(S, N, 17)` float64 array or an object
+array of S `(N_s, 17)` stages (np.load(..., allow_pickle=True), vq_func.py:141); scalar
+`(n, 1)` float64 (vq_func.py:171).  Unlike the reference, parsed codebooks are cached by
+path (and mtime) and stay resident in HBM instead of being re-read per frame."""
+import ctypes as C
+import os
+
+import numpy as np
+import torch
+
+from . import _lib
+
+SURVIVORS = 5  # vq_func.py:3
+
+
+def read_vq_file(path):
+    cb = np.load(path, allow_pickle=True)
+    if cb.dtype != object and cb.ndim == 2:
+        # the reference crashes on 2-D files (n_entries computed before expand_dims, :143-146)
+        raise ValueError(f"{path}: 2-D VQ codebooks are not a valid reference format; expected (S,N,17)")
+    stages = [np.ascontiguousarray(np.asarray(s, dtype=np.float64)) for s in cb]
+    if not 1 <= len(stages) <= 2:
+        raise ValueError(f"{path}: {len(stages)} stages; the reference search only works for 1 or 2")
+    for s in stages:
+        if s.ndim != 2 or s.shape[1] != 17:
+            raise ValueError(f"{path}: stage shape {s.shape}, expected (N,17)")
+    return stages
+
+
+def read_scl_file(path):
+    c = np.load(path)
+    return np.ascontiguousarray(np.asarray(c, dtype=np.float64).reshape(-1))
+
+
+class Codebooks:
+    """device-resident codebook set (fpc_codebooks)"""
+
+    def __init__(self, vq_hi, scl_hi, vq_lo=None, scl_lo=None):
+        _lib.require_gpu()
+        self.vq_hi = [np.ascontiguousarray(s, np.float64) for s in vq_hi]
+        self.vq_lo = np.ascontiguousarray(vq_lo[-1], np.float64) if vq_lo is not None else None
+        self.scl_hi = np.ascontiguousarray(np.asarray(scl_hi, np.float64).reshape(-1))
+        self.scl_lo = np.ascontiguousarray(np.asarray(scl_lo, np.float64).reshape(-1)) if scl_lo is not None else None
+        flat = np.ascontiguousarray(np.concatenate(self.vq_hi, 0))
+        n_hi = (C.c_int * 2)(self.vq_hi[0].shape[0], self.vq_hi[1].shape[0] if len(self.vq_hi) == 2 else 0)
+        h = C.c_void_p()
+        _lib.check(_lib.lib().fpc_codebooks_create(
+            flat.ctypes.data, len(self.vq_hi), n_hi,
+            self.vq_lo.ctypes.data if self.vq_lo is not None else None,
+            self.vq_lo.shape[0] if self.vq_lo is not None else 0,
+            self.scl_hi.ctypes.data, self.scl_hi.size,
+            self.scl_lo.ctypes.data if self.scl_lo is not None else None,
+            self.scl_lo.size if self.scl_lo is not None else 0, C.byref(h)), "fpc_codebooks_create")
+        self.handle = h
+        self.sizes = [self.scl_hi.size, self.scl_lo.size if self.scl_lo is not None else 0,
+                      self.vq_hi[0].shape[0], self.vq_hi[1].shape[0] if len(self.vq_hi) == 2 else 0,
+                      self.vq_lo.shape[0] if self.vq_lo is not None else 0]
+        self.hist_size = int(sum(self.sizes))
+
+    def __del__(self):
+        try:
+            if self.handle is not None:
+                _lib.lib().fpc_codebooks_destroy(self.handle)
+                self.handle = None
+        except Exception:
+            pass
+
+    def split_hist(self, hist):
+        out, o = [], 0
+        for n in self.sizes:
+            out.append(np.array(hist[o:o + n], dtype=np.float64) if n else 0)
+            o += n
+        return out
+
+
+_cache = {}
+
+
+def _key(p):
+    return (os.path.abspath(p), os.path.getmtime(p)) if p else None
+
+
+def load_codebooks(cb_path, scl_cb_path, bl_cb_path=None, bl_scl_cb_path=None):
+    key = (_key(cb_path), _key(scl_cb_path), _key(bl_cb_path), _key(bl_scl_cb_path))
+    if key not in _cache:
+        _cache[key] = Codebooks(read_vq_file(cb_path), read_scl_file(scl_cb_path),
+                                read_vq_file(bl_cb_path) if bl_cb_path else None,
+                                read_scl_file(bl_scl_cb_path) if bl_scl_cb_path else None)
+    return _cache[key]
+
+
+_single = {}
+
+
+def _single_vq(cb_path):
+    k = _key(cb_path)
+    if k not in _single:
+        st = read_vq_file(cb_path)
+        _single[k] = Codebooks(st, np.zeros(1))
+    return _single[k]
+
+
+def vq_quantize(r, cb_path, return_indices=False):
+    """vq_func.py:134-164: r (n,17) -> (qr (n,17) float64, cb_tot list of per-stage histograms)"""
+    cb = _single_vq(cb_path)
+    r = np.ascontiguousarray(np.asarray(r, dtype=np.float32))
+    n, nd = r.shape
+    assert nd == 17
+    rd = torch.from_numpy(r).cuda()
+    qr = torch.empty(n, 17, device="cuda", dtype=torch.float64)
+    idx = torch.empty(n, 2, device="cuda", dtype=torch.int32)
+    _lib.check(_lib.lib().fpc_vq_quantize(cb.handle, 0, rd.data_ptr(), n, qr.data_ptr(), idx.data_ptr(),
+                                          _lib.stream_ptr()), "fpc_vq_quantize")
+    ih = idx.cpu().numpy()
+    cb_tot = []
+    for s, st in enumerate(cb.vq_hi):
+        cb_tot.append(np.bincount(ih[:, s], minlength=st.shape[0]).astype(np.float64))
+    out = (qr.cpu().numpy(), cb_tot)
+    return out + (ih,) if return_indices else out
+
+
+def _single_scl(cb_path):
+    k = ("scl", _key(cb_path))
+    if k not in _single:
+        _single[k] = Codebooks([np.zeros((SURVIVORS, 17))], read_scl_file(cb_path))
+    return _single[k]
+
+
+def scl_quantize(data, cb_path, return_indices=False):
+    """vq_func.py:167-185: data (n,1) -> (q (n,1) float64, cb_tot (n_codes,))"""
+    cb = _single_scl(cb_path)
+    x = np.ascontiguousarray(np.asarray(data, dtype=np.float32).reshape(-1))
+    n = x.size
+    xd = torch.from_numpy(x).cuda()
+    q = torch.empty(n, device="cuda", dtype=torch.float64)
+    idx = torch.empty(n, device="cuda", dtype=torch.int32)
+    _lib.check(_lib.lib().fpc_scl_quantize(cb.handle, 0, xd.data_ptr(), n, q.data_ptr(), idx.data_ptr(),
+                                           _lib.stream_ptr()), "fpc_scl_quantize")
+    ih = idx.cpu().numpy()
+    out = (q.cpu().numpy()[:, None], np.bincount(ih, minlength=cb.scl_hi.size).astype(np.float64))
+    return out + (ih,) if return_indices else out
+
+
+def cal_entropy(cb):
+    """generate_qtz_features.py:94-101 (bits per symbol); does not mutate its argument"""
+    cb = np.asarray(cb, dtype=np.float64)
+    p = cb / np.sum(cb)
+    return float(np.sum(-p * np.log2(p + 1e-20)))

@@ -1,0 +1,145 @@
+"""`Wavernn` with the reference's call surface (src/models/wavernn.py:22-256) on the
+HIP kernels of libfpcodec.so.
+
+Same constructor arguments, same state_dict keys/shapes (wavernn.py:24-52), same
+`forward(x, h1, h2) -> (y, h1, h2)` (:63-102) and
+`encoder(cfg, feat, mask, l1, l2, vq_quantize, scl_quantize, qtz)` ->
+`(c_in[:,1:], r, r_qtz, r_under, ind1_mask, ind2_mask, cb_tot)` (:165-256).  The whole
+closed loop of `encoder` runs in one persistent kernel per utterance; the quantizer
+callables are accepted for signature compatibility and are NOT called - the codebooks
+named by cfg['scl_cb_path'] / ['cb_path'] / ['bl_scl_cb_path'] / ['bl_cb_path'] are
+searched on the device with the same arithmetic.  Dead/broken reference methods
+(mask_enc, decoder, loop_attention: SURVEY.md App. C) are not reproduced.
+"""
+import ctypes as C
+from collections import OrderedDict
+
+import numpy as np
+import torch
+
+from . import _lib
+from .vq_func import load_codebooks
+
+_KEYS = ["rnn1.weight_ih_l0", "rnn1.weight_hh_l0", "rnn1.bias_ih_l0", "rnn1.bias_hh_l0",
+         "rnn2.weight_ih_l0", "rnn2.weight_hh_l0", "rnn2.bias_ih_l0", "rnn2.bias_hh_l0",
+         "dual_fc.0.weight", "dual_fc.0.bias"]
+
+
+class Wavernn:
+    def __init__(self, in_features=20, gru_units1=384, gru_units2=16, fc_units=20, attn_units=20,
+                 rnn_layers=2, bidirectional=False, packing=False):
+        if bidirectional or packing:
+            raise NotImplementedError("production path is unidirectional, unpacked (train_frame.py:195,203)")
+        self.in_features, self.gru_units1, self.gru_units2, self.fc_units = (
+            in_features, gru_units1, gru_units2, fc_units)
+        self.scale = 1
+        self._sd = None
+        self._h = None
+        self.device = torch.device("cuda")
+
+    # ---- torch.nn.Module-like surface used by synthesis_qtz.py:79-87 ----
+    def shapes(self):
+        i, h1, h2, f = self.in_features, self.gru_units1, self.gru_units2, self.fc_units
+        return OrderedDict(zip(_KEYS, [(3 * h1, i), (3 * h1, h1), (3 * h1,), (3 * h1,), (3 * h2, h1),
+                                       (3 * h2, h2), (3 * h2,), (3 * h2,), (f, h2), (f,)]))
+
+    def load_state_dict(self, sd, strict=True):
+        shp = self.shapes()
+        missing = [k for k in _KEYS if k not in sd]
+        extra = [k for k in sd if k not in shp]
+        if missing or (strict and extra):
+            raise KeyError(f"state_dict mismatch: missing {missing}, unexpected {extra}")
+        arrs = []
+        for k in _KEYS:
+            v = sd[k]
+            v = v.detach().cpu().numpy() if isinstance(v, torch.Tensor) else np.asarray(v)
+            if tuple(v.shape) != shp[k]:
+                raise ValueError(f"{k}: shape {tuple(v.shape)} != {shp[k]}")
+            arrs.append(np.ascontiguousarray(v, dtype=np.float32))
+        self._sd = OrderedDict(zip(_KEYS, arrs))
+        self._release()
+        return self
+
+    def state_dict(self):
+        return OrderedDict((k, torch.from_numpy(v.copy())) for k, v in self._sd.items())
+
+    def to(self, device):
+        return self
+
+    def eval(self):
+        return self
+
+    def _release(self):
+        if self._h is not None:
+            _lib.lib().fpc_predictor_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self._release()
+        except Exception:
+            pass
+
+    def _handle(self):
+        if self._sd is None:
+            raise _lib.FpcError("Wavernn: load_state_dict() first (the reference loads a checkpoint, synthesis_qtz.py:86)")
+        if self._h is None:
+            _lib.require_gpu()
+            a = list(self._sd.values())
+            w = _lib.PredictorWeights(self.in_features, self.gru_units1, self.gru_units2, self.fc_units,
+                                      *[x.ctypes.data for x in a])
+            h = C.c_void_p()
+            _lib.check(_lib.lib().fpc_predictor_create(C.byref(w), C.byref(h)), "fpc_predictor_create")
+            self._h = h
+        return self._h
+
+    # ---- Wavernn.forward (wavernn.py:63-102) ----
+    def forward(self, x, h1=None, h2=None):
+        h = self._handle()
+        x = x.to(self.device, torch.float32).contiguous()
+        B, L, Cc = x.shape
+        assert Cc == self.in_features
+        s1 = torch.zeros(B, self.gru_units1, device=self.device) if h1 is None else \
+            h1.to(self.device, torch.float32).reshape(B, self.gru_units1).clone()
+        s2 = torch.zeros(B, self.gru_units2, device=self.device) if h2 is None else \
+            h2.to(self.device, torch.float32).reshape(B, self.gru_units2).clone()
+        y = torch.empty(B, L, self.fc_units, device=self.device)
+        _lib.check(_lib.lib().fpc_predictor_forward(h, x.data_ptr(), B, L, s1.data_ptr(), s2.data_ptr(),
+                                                    y.data_ptr(), _lib.stream_ptr()), "fpc_predictor_forward")
+        return y, s1.unsqueeze(0), s2.unsqueeze(0)
+
+    __call__ = forward
+
+    # ---- Wavernn.encoder (wavernn.py:165-256) ----
+    def encoder(self, cfg, feat, mask, l1, l2, vq_quantize=None, scl_quantize=None, qtz=True,
+                return_indices=False):
+        if mask is not None:
+            raise NotImplementedError("only the threshold mode (mask=None) is live in the reference")
+        h = self._handle()
+        feat = feat.to(self.device, torch.float32).contiguous()
+        B, L, Cc = feat.shape
+        dev = self.device
+        c_in = torch.empty(B, L, Cc, device=dev)
+        r = torch.empty(B, L, 18, device=dev)
+        r_qtz = torch.empty(B, L, 18, device=dev)
+        r_under = torch.empty(B, L, 18, device=dev)
+        ind1 = torch.empty(B, L, 1, device=dev)
+        ind2 = torch.empty(B, L, 1, device=dev)
+        idx = torch.empty(B, L, 4, device=dev, dtype=torch.int32)
+        cb = None
+        hist = None
+        if qtz:
+            cb = load_codebooks(cfg["cb_path"], cfg["scl_cb_path"], cfg.get("bl_cb_path") or None,
+                                cfg.get("bl_scl_cb_path") or None)
+            hist = torch.zeros(cb.hist_size, device=dev, dtype=torch.int64)
+        _lib.check(_lib.lib().fpc_encode(
+            h, cb.handle if cb else None, feat.data_ptr(), B, L, float(l1), float(l2), int(bool(qtz)),
+            c_in.data_ptr(), r.data_ptr(), r_qtz.data_ptr(), r_under.data_ptr(), ind1.data_ptr(),
+            ind2.data_ptr(), idx.data_ptr(), hist.data_ptr() if hist is not None else None,
+            _lib.stream_ptr()), "fpc_encode")
+        if qtz:
+            cb_tot = cb.split_hist(hist.cpu().numpy().astype(np.float64))
+        else:
+            cb_tot = [0, 0, 0, 0, 0]  # wavernn.py:189
+        out = (c_in, r, r_qtz, r_under, ind1, ind2, cb_tot)
+        return out + (idx,) if return_indices else out

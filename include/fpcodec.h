@@ -26,6 +26,7 @@ extern "C" {
 #endif
 
 #define FPC_ABI_VERSION 1
+#define FPC_API __attribute__((visibility("default")))
 
 typedef enum {
     FPC_OK = 0,
@@ -37,10 +38,10 @@ typedef enum {
 
 typedef void* fpc_stream; /* hipStream_t */
 
-const char* fpc_last_error(void);
-int fpc_abi_version(void);
+FPC_API const char* fpc_last_error(void);
+FPC_API int fpc_abi_version(void);
 /* number of visible HIP devices (0 on a CPU-only host); never fails */
-int fpc_device_count(void);
+FPC_API int fpc_device_count(void);
 
 /* ------------------------------------------------------------------------
  * Feature predictor  (src/models/wavernn.py:24-52 parameters,
@@ -67,13 +68,13 @@ typedef struct {
 
 typedef struct fpc_predictor fpc_predictor;
 
-int fpc_predictor_create(const fpc_predictor_weights* w, fpc_predictor** out);
-void fpc_predictor_destroy(fpc_predictor* p);
+FPC_API int fpc_predictor_create(const fpc_predictor_weights* w, fpc_predictor** out);
+FPC_API void fpc_predictor_destroy(fpc_predictor* p);
 
 /* Wavernn.forward (wavernn.py:63-102): x [B,L,in] -> y [B,L,fc]; h1 [B,H1],
  * h2 [B,H2] are read as initial state and overwritten with the final state.
  * All pointers are device pointers. */
-int fpc_predictor_forward(fpc_predictor* p, const float* x_dev, int B, int L,
+FPC_API int fpc_predictor_forward(fpc_predictor* p, const float* x_dev, int B, int L,
                           float* h1_dev, float* h2_dev, float* y_dev, fpc_stream s);
 
 /* Codebooks (src/quantization/vq_func.py:134-185; file formats written by
@@ -85,16 +86,16 @@ int fpc_predictor_forward(fpc_predictor* p, const float* x_dev, int B, int L,
  *   scl_lo: n_lo scalars (may be NULL/0)              (cfg['bl_scl_cb_path'])
  */
 typedef struct fpc_codebooks fpc_codebooks;
-int fpc_codebooks_create(const double* vq_hi, int S_hi, const int* N_hi,
+FPC_API int fpc_codebooks_create(const double* vq_hi, int S_hi, const int* N_hi,
                          const double* vq_lo, int N_lo,
                          const double* scl_hi, int n_hi,
                          const double* scl_lo, int n_lo, fpc_codebooks** out);
-void fpc_codebooks_destroy(fpc_codebooks* c);
+FPC_API void fpc_codebooks_destroy(fpc_codebooks* c);
 
 /* Histogram block layout of fpc_encode's `hist` (= cb_tot of wavernn.py:189):
  * [n_hi | n_lo | N_hi[0] | N_hi[1] | N_lo] unsigned 64-bit counters, absent
  * codebooks contribute zero-length segments. */
-int fpc_codebooks_hist_size(const fpc_codebooks* c);
+FPC_API int fpc_codebooks_hist_size(const fpc_codebooks* c);
 
 /* Wavernn.encoder (wavernn.py:165-256), mask=None.  Device pointers.
  *   feat   [B,L,20]   normalised features (cepstrum/24.1, pitch/24.1)
@@ -106,7 +107,7 @@ int fpc_codebooks_hist_size(const fpc_codebooks* c);
  *                     came from the below-threshold scalar codebook. May be NULL.
  *   hist   see above; ADDED to (caller zeroes). May be NULL.
  * qtz=0 reproduces the un-quantised branch (wavernn.py:244-252); cb may then be NULL. */
-int fpc_encode(fpc_predictor* p, const fpc_codebooks* cb, const float* feat_dev, int B, int L,
+FPC_API int fpc_encode(fpc_predictor* p, const fpc_codebooks* cb, const float* feat_dev, int B, int L,
                float l1, float l2, int qtz, float* c_in_dev, float* r_dev, float* r_qtz_dev,
                float* r_under_dev, float* ind1_dev, float* ind2_dev, int32_t* idx_dev,
                unsigned long long* hist_dev, fpc_stream s);
@@ -115,15 +116,18 @@ int fpc_encode(fpc_predictor* p, const fpc_codebooks* cb, const float* feat_dev,
  * (vq_quantize vq_func.py:134, scl_quantize vq_func.py:167).  Device pointers.
  *   which = 0: above-threshold codebook, 1: below-threshold codebook
  *   r [n,17] float32 -> qr [n,17] float64, idx [n,2] int32 (stage 2 = -1 if absent) */
-int fpc_vq_quantize(const fpc_codebooks* cb, int which, const float* r_dev, int n,
+FPC_API int fpc_vq_quantize(const fpc_codebooks* cb, int which, const float* r_dev, int n,
                     double* qr_dev, int32_t* idx_dev, fpc_stream s);
 /*   x [n] float32 -> q [n] float64, idx [n] int32 */
-int fpc_scl_quantize(const fpc_codebooks* cb, int which, const float* x_dev, int n,
+FPC_API int fpc_scl_quantize(const fpc_codebooks* cb, int which, const float* x_dev, int n,
                      double* q_dev, int32_t* idx_dev, fpc_stream s);
 
 /* ceps2lpc_v (src/ceps2lpc/ceps2lpc_vct.py:122-162): ceps [N,stride] float32
- * (first 18 columns used, un-normalised i.e. already x24.1) -> lpc [N,16]. */
-int fpc_ceps2lpc(const float* ceps_dev, int N, int stride, float* lpc_dev, fpc_stream s);
+ * (first 18 columns used, un-normalised i.e. already x24.1) -> lpc [N,16].
+ * Optional outputs (may be NULL): e [N] final Levinson error, rc [N,16] reflection
+ * coefficients (the reference returns both for the LAST row only). */
+FPC_API int fpc_ceps2lpc(const float* ceps_dev, int N, int stride, float* lpc_dev, float* e_dev,
+                 float* rc_dev, fpc_stream s);
 
 /* ------------------------------------------------------------------------
  * LPCNet-style vocoder (NOT in /root/reference: xiph/LPCNet training_tf2/
@@ -154,11 +158,11 @@ typedef struct {
 
 typedef struct fpc_lpcnet fpc_lpcnet;
 
-int fpc_lpcnet_create(const fpc_lpcnet_weights* w, fpc_lpcnet** out);
-void fpc_lpcnet_destroy(fpc_lpcnet* m);
+FPC_API int fpc_lpcnet_create(const fpc_lpcnet_weights* w, fpc_lpcnet** out);
+FPC_API void fpc_lpcnet_destroy(fpc_lpcnet* m);
 
 /* bytes of device workspace fpc_lpcnet_synthesize needs for (B,T) */
-long long fpc_lpcnet_workspace_bytes(const fpc_lpcnet* m, int B, int T);
+FPC_API long long fpc_lpcnet_workspace_bytes(const fpc_lpcnet* m, int B, int T);
 
 /* test_lpcnet.py loop.  Device pointers.
  *   features [B,T,36] float32 (un-normalised: cepstrum, pitch, corr, 16 LPC)
@@ -166,17 +170,17 @@ long long fpc_lpcnet_workspace_bytes(const fpc_lpcnet* m, int B, int T);
  *   pcm      [B,T*160] int16  de-emphasised output; the first 17 samples of each
  *                             utterance are 0 (test_lpcnet.py skips order+1)
  *   workspace: at least fpc_lpcnet_workspace_bytes(B,T) bytes */
-int fpc_lpcnet_synthesize(fpc_lpcnet* m, const float* features_dev, int B, int T,
+FPC_API int fpc_lpcnet_synthesize(fpc_lpcnet* m, const float* features_dev, int B, int T,
                           const uint64_t* seeds_dev, int16_t* pcm_dev, void* workspace_dev,
                           fpc_stream s);
 
 /* frame-rate conditioning only (enc of lpcnet.py): cfeat [B,T,128] */
-int fpc_lpcnet_condition(fpc_lpcnet* m, const float* features_dev, int B, int T,
+FPC_API int fpc_lpcnet_condition(fpc_lpcnet* m, const float* features_dev, int B, int T,
                          float* cfeat_dev, void* workspace_dev, fpc_stream s);
 
 /* average duration (ms) of the last decode-kernel launch measured with HIP
  * events on the launch stream; synchronises on those events. <0 if none. */
-float fpc_lpcnet_last_decode_ms(fpc_lpcnet* m);
+FPC_API float fpc_lpcnet_last_decode_ms(fpc_lpcnet* m);
 
 #ifdef __cplusplus
 }

@@ -765,9 +765,9 @@ EXPORT void orc_lpcnet_synthesize(const orc_lpcnet* m, const float* feat, int T,
                     part[l] = sacc;
                 }
                 gb[o] = tree_reduce(part, 64) + cfb[o];
-                float racc = 0.0f;
-                for (int k = 0; k < RNN_B; ++k) racc = fmaf(w->gb_r[(size_t)k * GB + o], s2[k], racc);
-                ub[o] = racc;
+                float prod[RNN_B]; /* recurrent part: balanced tree over the 16 products */
+                for (int k = 0; k < RNN_B; ++k) prod[k] = w->gb_r[(size_t)k * GB + o] * s2[k];
+                ub[o] = tree_reduce(prod, RNN_B);
             }
             for (int j = 0; j < RNN_B; ++j) {
                 const float z = fpc_sigmoidf(gb[j] + ub[j]);
@@ -807,32 +807,34 @@ EXPORT void orc_lpcnet_synthesize(const orc_lpcnet* m, const float* feat, int T,
                 const float d = p[v] - thr;
                 p[v] = d > 0.0f ? d : 0.0f;
             }
-            /* inclusive scan: Kogge-Stone inside each 64-block, block offsets in order */
-            float W4[4], O4[4];
-            for (int blk = 0; blk < 4; ++blk) {
-                float* cb = c + 64 * blk;
-                memcpy(cb, p + 64 * blk, 64 * sizeof(float));
-                for (int d = 1; d < 64; d <<= 1) {
-                    float nx[64];
-                    for (int l = 0; l < 64; ++l) nx[l] = l >= d ? cb[l] + cb[l - d] : cb[l];
-                    memcpy(cb, nx, sizeof nx);
+            /* two-level inclusive scan: sequential prefix inside each aligned group of 4
+             * leaves, Kogge-Stone over the 64 group totals */
+            float I64[64];
+            for (int g4 = 0; g4 < 64; ++g4) {
+                float run = p[4 * g4];
+                c[4 * g4] = run;
+                for (int j = 1; j < 4; ++j) {
+                    run = run + p[4 * g4 + j];
+                    c[4 * g4 + j] = run;
                 }
-                W4[blk] = cb[63];
+                I64[g4] = run;
             }
-            O4[0] = 0.0f;
-            O4[1] = W4[0];
-            O4[2] = W4[0] + W4[1];
-            O4[3] = O4[2] + W4[2];
-            const float S2 = O4[3] + W4[3];
+            for (int d = 1; d < 64; d <<= 1) {
+                float nx[64];
+                for (int l = 0; l < 64; ++l) nx[l] = l >= d ? I64[l] + I64[l - d] : I64[l];
+                memcpy(I64, nx, sizeof nx);
+            }
+            const float S2 = I64[63];
             const float rthr = fpc_philox_uniform(seed, (uint32_t)t) * S2;
-            int wsel = 0;
-            for (int blk = 0; blk < 3; ++blk)
-                if (O4[blk] + W4[blk] <= rthr) ++wsel;
+            int wsel = 0; /* group that holds the draw */
+            for (int g4 = 0; g4 < 63; ++g4)
+                if (I64[g4] <= rthr) ++wsel;
+            const float O = wsel > 0 ? I64[wsel - 1] : 0.0f;
             int cnt = 0;
-            for (int l = 0; l < 64; ++l)
-                if (O4[wsel] + c[64 * wsel + l] <= rthr) ++cnt;
-            if (cnt > 63) cnt = 63;
-            const int exc = 64 * wsel + cnt;
+            for (int j = 0; j < 4; ++j)
+                if (O + c[4 * wsel + j] <= rthr) ++cnt;
+            if (cnt > 3) cnt = 3;
+            const int exc = 4 * wsel + cnt;
             /* synthesis filter + de-emphasis (wavenet.py:188 coefficient) */
             const float pcm = pred + m->ulaw_tab[exc];
             for (int k = FPC_LPC_ORDER - 1; k > 0; --k) hist[k] = hist[k - 1];
