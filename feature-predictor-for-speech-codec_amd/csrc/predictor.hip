@@ -611,9 +611,10 @@ extern "C" int fpc_encode(fpc_predictor* p, const fpc_codebooks* cb, const float
 
 extern "C" int fpc_vq_quantize(const fpc_codebooks* cb, int which, const float* r_dev, int n,
                                double* qr_dev, int32_t* idx_dev, fpc_stream s) {
-    FPC_REQUIRE(cb && r_dev && qr_dev, "fpc_vq_quantize: null argument");
+    FPC_REQUIRE(cb, "fpc_vq_quantize: null codebook handle");
     FPC_REQUIRE(which == 0 || (which == 1 && cb->d.vq_lo), "fpc_vq_quantize: codebook %d not loaded", which);
-    if (n <= 0) return FPC_OK;
+    if (n <= 0) return FPC_OK;  // empty input: nothing to do (pointers may be null)
+    FPC_REQUIRE(r_dev && qr_dev, "fpc_vq_quantize: null argument");
     hipLaunchKernelGGL(k_vq, dim3(n), dim3(NT), 0, static_cast<hipStream_t>(s), cb->d, which, r_dev, qr_dev,
                        idx_dev);
     FPC_HIP(hipGetLastError());
@@ -622,9 +623,10 @@ extern "C" int fpc_vq_quantize(const fpc_codebooks* cb, int which, const float* 
 
 extern "C" int fpc_scl_quantize(const fpc_codebooks* cb, int which, const float* x_dev, int n,
                                 double* q_dev, int32_t* idx_dev, fpc_stream s) {
-    FPC_REQUIRE(cb && x_dev && q_dev, "fpc_scl_quantize: null argument");
+    FPC_REQUIRE(cb, "fpc_scl_quantize: null codebook handle");
     FPC_REQUIRE(which == 0 || (which == 1 && cb->d.scl_lo), "fpc_scl_quantize: codebook %d not loaded", which);
     if (n <= 0) return FPC_OK;
+    FPC_REQUIRE(x_dev && q_dev, "fpc_scl_quantize: null argument");
     hipLaunchKernelGGL(k_scl, dim3(n), dim3(NT), 0, static_cast<hipStream_t>(s), cb->d, which, x_dev, q_dev,
                        idx_dev);
     FPC_HIP(hipGetLastError());
