@@ -116,6 +116,7 @@ struct DecodeParams {
     const float* fc_tab;     // [256][2][FC_STRIDE]
     const float* ulaw_tab;   // [256]
     int wave_maxQ[NWAVES];
+    unsigned long long* stamps;  // diagnostic only
 };
 
 struct __attribute__((aligned(16))) DecodeLds {
@@ -144,8 +145,20 @@ __device__ __forceinline__ float bfly_sum(float v, int width) {
     return v;
 }
 
+// STAMP=true is a diagnostic build (env FPC_DECODE_STAMPS=1): wave 0 / lane 0 of block 0
+// accumulates s_memtime deltas per phase into P.stamps; never used for timing claims.
+#define FPC_STAMP(k)                                              \
+    if (STAMP) {                                                  \
+        const unsigned long long now_ = __builtin_readcyclecounter(); \
+        st_acc[k] += now_ - st_last;                              \
+        st_last = now_;                                           \
+    }
+
+template <bool STAMP>
 __global__ __launch_bounds__(NTHREADS) void k_decode(const DecodeParams P) {
     __shared__ DecodeLds L;
+    unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long st_last = STAMP ? __builtin_readcyclecounter() : 0;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int b = blockIdx.x, T = P.T;
     const unsigned long long seed = P.seeds[b];
@@ -299,7 +312,9 @@ __global__ __launch_bounds__(NTHREADS) void k_decode(const DecodeParams P) {
             const float gz = ((g_t[0] + g_t[1]) + g_t[2]) + g_c[0];
             const float gr = ((g_t[3] + g_t[4]) + g_t[5]) + g_c[1];
             const float gn = ((g_t[6] + g_t[7]) + g_t[8]) + g_c[2];
+            FPC_STAMP(0)
             __syncthreads();  // B0
+            FPC_STAMP(6)
 
             // ================= phase B: GRU_A gates =====================================
             if (tid < RNN_A) {
@@ -309,7 +324,9 @@ __global__ __launch_bounds__(NTHREADS) void k_decode(const DecodeParams P) {
                 const float n = fpc_tanhf(fmaf(r, L.rec[2 * RNN_A + tid] + L.brn_a[tid], gn));
                 L.s1[tid] = fmaf(z, h - n, n);
             }
+            FPC_STAMP(1)
             __syncthreads();  // B1
+            FPC_STAMP(6)
 
             // ================= phase C: GRU_B (half-wave = unit) =========================
             {
@@ -344,7 +361,9 @@ __global__ __launch_bounds__(NTHREADS) void k_decode(const DecodeParams P) {
                     L.s2[unitB] = fmaf(z, so - n, n);
                 }
             }
+            FPC_STAMP(2)
             __syncthreads();  // B2
+            FPC_STAMP(6)
 
             // ================= phase D1: dual FC -> node probabilities ====================
             {
@@ -365,7 +384,9 @@ __global__ __launch_bounds__(NTHREADS) void k_decode(const DecodeParams P) {
                 const float v = fch == 0 ? fmaf(fo, to, ff * tt) : fmaf(ff, tt, fo * to);
                 if (fch == 0) L.q[fnode] = fpc_sigmoidf(v);
             }
+            FPC_STAMP(3)
             __syncthreads();  // B3
+            FPC_STAMP(6)
 
             // ================= phase D2: tree pdf and per-leaf candidates (256 lanes) ======
             if (tid < 256) {
@@ -384,7 +405,9 @@ __global__ __launch_bounds__(NTHREADS) void k_decode(const DecodeParams P) {
                 L.cand_pred[tid] = cpred;
                 L.cand_e[tid] = fpc_lin2ulaw(cpcm) | (fpc_lin2ulaw(cpred) << 8);
             }
+            FPC_STAMP(4)
             __syncthreads();  // B4
+            FPC_STAMP(6)
 
             // ================= phase EF (wave 0): normaliser, tail cut, scan, draw ==========
             if (wave == 0) {
@@ -427,9 +450,13 @@ __global__ __launch_bounds__(NTHREADS) void k_decode(const DecodeParams P) {
                     out[t] = fpc_pcm16(mem);
                 }
             }
+            FPC_STAMP(5)
             __syncthreads();  // B5
+            FPC_STAMP(6)
         }
     }
+    if (STAMP && blockIdx.x == 0 && tid == 0)
+        for (int k = 0; k < 8; ++k) P.stamps[k] = st_acc[k];
 }
 
 }  // namespace
@@ -715,10 +742,28 @@ extern "C" int fpc_lpcnet_synthesize(fpc_lpcnet* m, const float* features_dev, i
     P.fc_tab = m->fc_tab.as<float>();
     P.ulaw_tab = m->ulaw_tab.as<float>();
     for (int i = 0; i < NWAVES; ++i) P.wave_maxQ[i] = m->wave_maxQ[i];
+    const bool stamp = getenv("FPC_DECODE_STAMPS") != nullptr;
+    fpc::DevBuf stamps;
+    P.stamps = nullptr;
+    if (stamp) {
+        FPC_HIP(stamps.alloc(8 * sizeof(unsigned long long)));
+        P.stamps = stamps.as<unsigned long long>();
+    }
     FPC_HIP(hipEventRecord(m->ev0, st));
-    hipLaunchKernelGGL(k_decode, dim3(B), dim3(NTHREADS), 0, st, P);
+    if (stamp)
+        hipLaunchKernelGGL(k_decode<true>, dim3(B), dim3(NTHREADS), 0, st, P);
+    else
+        hipLaunchKernelGGL(k_decode<false>, dim3(B), dim3(NTHREADS), 0, st, P);
     FPC_HIP(hipEventRecord(m->ev1, st));
     FPC_HIP(hipGetLastError());
+    if (stamp) {  // diagnostic path only: synchronises
+        unsigned long long h[8];
+        FPC_HIP(hipStreamSynchronize(st));
+        FPC_HIP(hipMemcpy(h, stamps.p, sizeof h, hipMemcpyDeviceToHost));
+        const double n = (double)T * FPC_FRAME_SIZE - 17;
+        fprintf(stderr, "[fpc stamps] cycles/sample (wave0): A=%.0f B=%.0f C=%.0f D1=%.0f D2=%.0f EF=%.0f barrier-wait=%.0f\n",
+                h[0] / n, h[1] / n, h[2] / n, h[3] / n, h[4] / n, h[5] / n, h[6] / n);
+    }
     m->timed = true;
     return FPC_OK;
 }
