@@ -1,0 +1,214 @@
+"""CPU-only checks of the host side: the C-ABI library loads and exports every symbol of
+include/fpcodec.h, fails loudly without a GPU, config/feature-file helpers, oracle
+known-answer tests for the vocoder pieces (parity unpinned -> self-consistency), and the
+world_size-2 gloo rehearsal of the multi-GPU sharding."""
+import ctypes as C
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def built():
+    import __graft_entry__ as g
+    g.build()
+    from fpcodec_amd import _lib
+    return _lib
+
+
+def test_abi_exports_every_declared_symbol(built):
+    hdr = open(os.path.join(ROOT, "include", "fpcodec.h")).read()
+    declared = set(re.findall(r"FPC_API [^;(]*?\b(fpc_[a-z0-9_]+)\(", hdr))
+    assert declared and declared == set(built.SYMBOLS)
+    L = built.lib()
+    for s in declared:
+        assert hasattr(L, s), s
+    assert L.fpc_abi_version() == 1
+
+
+def test_no_cpu_fallback(built):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    L = built.lib()
+    assert L.fpc_device_count() == 0
+    h = C.c_void_p()
+    w = built.PredictorWeights(20, 384, 128, 18, *([1] * 10))
+    rc = L.fpc_predictor_create(C.byref(w), C.byref(h))
+    assert rc == -3 and b"no HIP device" in L.fpc_last_error()
+    with pytest.raises(built.FpcError):
+        built.require_gpu()
+    import fpcodec_amd
+    m = fpcodec_amd.Wavernn(20, 384, 128, 18)
+    m.load_state_dict(fpcodec_amd.synth.predictor_state_dict())
+    with pytest.raises(built.FpcError):
+        m.forward(torch.zeros(1, 2, 20))
+
+
+def test_state_dict_contract(synth):
+    import fpcodec_amd
+    m = fpcodec_amd.Wavernn(20, 384, 128, 18)
+    sd = synth.predictor_state_dict()
+    assert list(m.shapes().keys()) == list(sd.keys())  # src/models/wavernn.py:24-52 order
+    assert sum(v.size for v in sd.values()) == 667410
+    bad = dict(sd)
+    bad.pop("dual_fc.0.bias")
+    with pytest.raises(KeyError):
+        m.load_state_dict(bad)
+    bad = dict(sd)
+    bad["rnn1.weight_ih_l0"] = np.zeros((3, 3), np.float32)
+    with pytest.raises(ValueError):
+        m.load_state_dict(bad)
+
+
+def test_cfg_overrides():
+    from fpcodec_amd.config import parse_overrides
+    cfg = parse_overrides("with cfg.l1=0.09 cfg.l2=0.28 cfg.qtz=True cfg.note=abc cfg.total_secs=3".split())
+    assert cfg["l1"] == 0.09 and cfg["qtz"] is True and cfg["note"] == "abc"
+    assert cfg["total_secs"] * cfg["sr"] // cfg["n_sample_seg"] == 20  # synthesis_qtz.py:97-98
+
+
+def test_codebook_file_formats(tmp_path, synth):
+    from fpcodec_amd.vq_func import read_vq_file, read_scl_file, cal_entropy
+    c = synth.codebooks()
+    p = tmp_path / "cb.npy"
+    np.save(p, c["vq_hi"])
+    st = read_vq_file(str(p))
+    assert len(st) == 2 and st[0].shape == (1024, 17) and st[0].dtype == np.float64
+    rag = np.empty(2, dtype=object)
+    rag[0], rag[1] = c["vq_hi"][0], c["vq_hi"][1][:512]
+    np.save(p, rag, allow_pickle=True)
+    st = read_vq_file(str(p))
+    assert st[1].shape == (512, 17)
+    np.save(p, c["vq_hi"][0])  # 2-D files crash the reference (vq_func.py:143-146)
+    with pytest.raises(ValueError):
+        read_vq_file(str(p))
+    np.save(p, c["scl_hi"])
+    assert read_scl_file(str(p)).shape == (256,)
+    h = np.array([1.0, 1.0, 2.0, 0.0])
+    assert abs(cal_entropy(h) - 1.5) < 1e-12 and h[2] == 2.0  # does not mutate (the reference does)
+
+
+def test_feature_file_readers(tmp_path):
+    from fpcodec_amd.lpcnet import read_features
+    a = np.arange(5 * 36, dtype=np.float32).reshape(5, 36)
+    a.tofile(tmp_path / "f.f32")
+    np.save(tmp_path / "f.npy", a[None])
+    assert np.array_equal(read_features(str(tmp_path / "f.f32")), a)
+    assert np.array_equal(read_features(str(tmp_path / "f.npy")), a)
+
+
+# ---------------- vocoder oracle known-answer tests (parity unpinned) ----------------
+def test_philox_known_answer(oracle):
+    # Random123 Philox4x32-10 KAT: counter 0, key 0 -> first word 0x6627e8d5
+    u = oracle.lib().orc_philox_uniform(0, 0)
+    assert u == np.float32((0x6627e8d5 >> 8) * 2.0 ** -24)
+
+
+def test_tree_pdf_properties(oracle):
+    L = oracle.lib()
+    rng = np.random.default_rng(0)
+    q = rng.uniform(0.05, 0.95, 256).astype(np.float32)
+    p = np.zeros(256, np.float32)
+    L.orc_tree_pdf(q.ctypes.data_as(C.c_void_p), p.ctypes.data_as(C.c_void_p))
+    assert abs(p.sum() - 1.0) < 1e-5
+    v = 0b10110010
+    node, ref = 1, 1.0
+    for l in range(8):
+        bit = (v >> (7 - l)) & 1
+        ref *= q[node] if bit else 1 - q[node]
+        node = 2 * node + bit
+    assert abs(p[v] - ref) < 1e-7
+    q[:] = 0.5  # all-zero dual-FC weights -> sigmoid(0) -> uniform pdf
+    L.orc_tree_pdf(q.ctypes.data_as(C.c_void_p), p.ctypes.data_as(C.c_void_p))
+    assert np.all(p == np.float32(1 / 256))
+
+
+def test_ulaw_roundtrip_and_activations(oracle):
+    L = oracle.lib()
+    assert all(L.orc_lin2ulaw(L.orc_ulaw2lin(u)) == u for u in range(256))
+    assert L.orc_lin2ulaw(0.0) == 128 and L.orc_lin2ulaw(-0.0) == 128
+    assert L.orc_lin2ulaw(1e9) == 255 and L.orc_lin2ulaw(-1e9) == 0
+    xs = np.linspace(-12, 12, 4001)
+    t = np.array([L.orc_tanh(float(x)) for x in xs])
+    assert np.abs(t - np.tanh(xs)).max() < 5e-7
+    s = np.array([L.orc_sigmoid(float(x)) for x in xs])
+    assert np.abs(s - 1 / (1 + np.exp(-xs))).max() < 5e-7
+
+
+def test_lpc_only_impulse_response(oracle, synth):
+    """zero network weights => excitation index fixed by the uniform pdf; the synthesis filter
+    then must equal scipy.signal.lfilter([1],[1,a...]) on u2l(exc) (src/utils.py:91-114 sign)."""
+    from scipy.signal import lfilter
+    w = {k: np.zeros(s, np.float32) for k, s in __import__("fpcodec_amd")._lib.LPCNET_SHAPES.items()}
+    orc = oracle.LPCNet(w)
+    T = 3
+    feat = np.zeros((T, 36), np.float32)
+    a = np.array([-0.9, 0.2] + [0.0] * 14, np.float32)
+    feat[:, 20:] = a
+    pcm, exc, pf = orc.synthesize(feat, 7, trace=True)
+    e = np.array([oracle.lib().orc_ulaw2lin(int(v)) for v in exc[17:]], np.float64)
+    ref = lfilter([1.0], np.concatenate([[1.0], a.astype(np.float64)]), e)
+    assert np.abs(pf[17:] - ref).max() < 1e-2 * max(1.0, np.abs(ref).max())
+    # uniform pdf: inverse-CDF of the Philox uniform
+    u = np.array([oracle.lib().orc_philox_uniform(7, t) for t in range(17, T * 160)])
+    assert np.abs(exc[17:].astype(int) - np.floor(u * 256)).max() <= 1
+
+
+def test_vocoder_oracle_determinism_and_seed(oracle, synth):
+    w = synth.lpcnet_weights()
+    orc = oracle.LPCNet(w)
+    assert orc.nblocks == 1382  # 4608 blocks x (.05,.05,.2)
+    f = synth.vocoder_features_raw(1, 5)[0]
+    f[:, 20:] = oracle.ceps2lpc(f[:, :20])[0]
+    a = orc.synthesize(f, 1004)
+    assert np.array_equal(a, orc.synthesize(f, 1004))
+    assert not np.array_equal(a, orc.synthesize(f, 1005))
+    assert (a[:17] == 0).all() and np.abs(a[17:].astype(int)).max() > 0
+
+
+# ---------------- multi-GPU sharding rehearsal on CPU (gloo, world_size 2) ----------------
+_WORKER = r'''
+import os, sys, numpy as np, torch, torch.distributed as dist
+sys.path.insert(0, os.environ["FPC_ROOT"])
+import fpcodec_amd
+from fpcodec_amd.parallel import shard_range, gather_report
+from oracle import oracle as O
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+B, T = 6, 3
+lo, hi = shard_range(B, rank, world)
+synth = fpcodec_amd.synth
+w = synth.lpcnet_weights(); orc = O.LPCNet(w)
+feats = synth.vocoder_features_raw(B, T)
+feats[:, :, 20:] = O.ceps2lpc(feats.reshape(-1, 36)[:, :20])[0].reshape(B, T, 16)
+seeds = synth.seeds(B)
+# stand-in decode for the CPU rehearsal: the oracle plays the role of the per-rank GPU decode
+local = np.stack([orc.synthesize(feats[b], int(seeds[b])) for b in range(lo, hi)])
+rep = gather_report(elapsed_s=0.5 + rank, samples=local.size, hist=np.full(4, rank + 1, np.int64))
+if rank == 0:
+    assert rep["samples"] == B * T * 160 and rep["elapsed_s"] == 0.5 + world - 1
+    assert np.array_equal(rep["hist"], np.full(4, sum(range(1, world + 1))))
+# shard invariance: same PCM as an unsharded decode
+full = np.stack([orc.synthesize(feats[b], int(seeds[b])) for b in range(B)])
+assert np.array_equal(local, full[lo:hi])
+print("rank", rank, "ok", lo, hi)
+dist.destroy_process_group()
+'''
+
+
+def test_gloo_world2_sharding(tmp_path, oracle):
+    script = tmp_path / "w.py"
+    script.write_text(_WORKER)
+    env = dict(os.environ, FPC_ROOT=ROOT, MASTER_ADDR="127.0.0.1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                        "--master-addr", "127.0.0.1", "--master-port", "29611", str(script)],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "rank 0 ok 0 3" in r.stdout and "rank 1 ok 3 6" in r.stdout
