@@ -24,7 +24,6 @@ namespace {
 constexpr int RNN_A = 384, RNN_B = 16, COND = 128, EMB = 128;
 constexpr int GA = 3 * RNN_A;  // 1152
 constexpr int GB = 3 * RNN_B;  // 48
-constexpr int NTHREADS = 512, NWAVES = 8;
 constexpr int NROWGRP = GA / 8;  // 144 groups of 8 gate rows
 constexpr int FC_STRIDE = 20;    // floats per (node,channel): 16 weights, bias, factor, pad
 
@@ -41,7 +40,8 @@ __global__ void k_embed_tables(const float* __restrict__ embed, const float* __r
             const double t = (double)embed[e * EMB + k] * (double)ga_k[(size_t)(s * EMB + k) * GA + row];
             acc = acc + t;
         }
-        tab[((size_t)s * 256 + e) * GA + row] = (float)acc;
+        // stored gate-interleaved [table][entry][unit][z,r,h]: a gate lane fetches 12 contiguous bytes
+        tab[((size_t)s * 256 + e) * GA + (row % RNN_A) * 3 + row / RNN_A] = (float)acc;
     }
 }
 
@@ -90,374 +90,7 @@ __global__ void k_frame_dense(const float* __restrict__ x, int ldx, int C, int K
     }
 }
 
-// ---------------------------------------------------------------------------------
-// decode kernel: one 512-thread workgroup (8 wave64, 2 per SIMD, 256 VGPRs each) per
-// utterance.  Per output sample, six workgroup barriers separate the phases
-//   A  issue embedding-row gather | sparse GRU_A mat-vec (weights in VGPRs) | side chains
-//   B  GRU_A gates (384 lanes)                      C  GRU_B (half-wave = unit)
-//   D1 dual-FC node probabilities (510 lanes)       D2 tree pdf + per-leaf candidates
-//   EF (wave 0) normaliser, tail cut, scan, draw, publish next-step control block
-// ---------------------------------------------------------------------------------
-struct DecodeParams {
-    const float* tab;       // [3][256][1152]
-    const float* cfa;       // [B][T][1152]  GRU_A conditioning product (+biases)
-    const float* cfb;       // [B][T][48]    GRU_B conditioning product (+biases)
-    const float* features;  // [B][T][36]
-    const unsigned long long* seeds;
-    int16_t* pcm;  // [B][T*160]
-    int T;
-    const float* lane_w;     // [128][512] sparse GRU_A weights: 2 leaves x 2 blocks x 8x4
-    const int* lane_meta;    // [6][512]   4 column blocks, row group, lane-in-group | lanes<<8
-    const float* lane_wb;    // [36][512]  GRU_B input weights [gate][12 inputs]
-    const float* ub;         // [16][48]
-    const float* diag;       // [1152]
-    const float* brn_a;      // [384]
-    const float* brn_b;      // [16]
-    const float* fc_tab;     // [256][2][FC_STRIDE]
-    const float* ulaw_tab;   // [256]
-    int wave_maxQ[NWAVES];
-    unsigned long long* stamps;  // diagnostic only
-};
-
-struct __attribute__((aligned(16))) DecodeLds {
-    float s1[RNN_A];
-    float rec[GA];
-    float diag[GA];
-    float brn_a[RNN_A];
-    float ub[RNN_B * GB];
-    float fc[256 * 2 * FC_STRIDE];
-    float uframe[FPC_FRAME_SIZE];
-    float q[256];
-    float p[256];
-    float cand_pcm[256];
-    float cand_pred[256];
-    int cand_e[256];  // e_sig | e_pred << 8
-    float s2[RNN_B];
-    float brn_b[RNN_B];
-    float hist[16];
-    // control block written by the winning lane / the LPC chain lane
-    int e_sig, e_pred, e_exc, pad0;
-    float pred, partial, a1n, mem;
-};
-
-__device__ __forceinline__ float bfly_sum(float v, int width) {
-    for (int s = 1; s < width; s <<= 1) v = v + __shfl_xor(v, s);
-    return v;
-}
-
-// STAMP=true is a diagnostic build (env FPC_DECODE_STAMPS=1): wave 0 / lane 0 of block 0
-// accumulates s_memtime deltas per phase into P.stamps; never used for timing claims.
-#define FPC_STAMP(k)                                              \
-    if (STAMP) {                                                  \
-        const unsigned long long now_ = __builtin_readcyclecounter(); \
-        st_acc[k] += now_ - st_last;                              \
-        st_last = now_;                                           \
-    }
-
-template <bool STAMP>
-__global__ __launch_bounds__(NTHREADS) void k_decode(const DecodeParams P) {
-    __shared__ DecodeLds L;
-    unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    unsigned long long st_last = STAMP ? __builtin_readcyclecounter() : 0;
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const int b = blockIdx.x, T = P.T;
-    const unsigned long long seed = P.seeds[b];
-
-    // ---- weights that stay in registers for the whole utterance ----
-    float w[128];
-#pragma unroll
-    for (int j = 0; j < 128; ++j) w[j] = P.lane_w[j * NTHREADS + tid];
-    int colb[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) colb[j] = P.lane_meta[j * NTHREADS + tid];
-    const int grp = P.lane_meta[4 * NTHREADS + tid];
-    const int lanem = P.lane_meta[5 * NTHREADS + tid];
-    const int lq = lanem & 0xff, lQ = lanem >> 8;
-    float wb[36];
-#pragma unroll
-    for (int j = 0; j < 36; ++j) wb[j] = P.lane_wb[j * NTHREADS + tid];
-    int maxQ = 1;
-#pragma unroll
-    for (int i = 0; i < NWAVES; ++i)
-        if (i == __builtin_amdgcn_readfirstlane(wave)) maxQ = P.wave_maxQ[i];
-    const float my_ulaw = P.ulaw_tab[tid & 255];
-
-    // ---- LDS init ----
-    for (int i = tid; i < RNN_A; i += NTHREADS) {
-        L.s1[i] = 0.0f;
-        L.brn_a[i] = P.brn_a[i];
-    }
-    for (int i = tid; i < GA; i += NTHREADS) {
-        L.rec[i] = 0.0f;
-        L.diag[i] = P.diag[i];
-    }
-    for (int i = tid; i < RNN_B * GB; i += NTHREADS) L.ub[i] = P.ub[i];
-    for (int i = tid; i < 256 * 2 * FC_STRIDE; i += NTHREADS) L.fc[i] = P.fc_tab[i];
-    if (tid < RNN_B) {
-        L.s2[tid] = 0.0f;
-        L.brn_b[tid] = P.brn_b[tid];
-        L.hist[tid] = 0.0f;
-    }
-    if (tid == 0) {
-        L.e_sig = 128;
-        L.e_pred = 128;
-        L.e_exc = 128;
-        L.pred = -0.0f;
-        L.partial = 0.0f;
-        L.a1n = 0.0f;
-        L.mem = 0.0f;
-    }
-    int16_t* out = P.pcm + (size_t)b * T * FPC_FRAME_SIZE;
-    if (tid < FPC_LPC_ORDER + 1) out[tid] = 0;  // test_lpcnet.py skips order+1 samples
-    __syncthreads();
-
-    const int fnode = tid >> 1, fch = tid & 1;  // dual-FC role: (tree node, channel)
-    const float* fcw = &L.fc[(fnode * 2 + fch) * FC_STRIDE];
-    const int half = lane >> 5, hl = lane & 31;  // GRU_B role: unit 2*wave+half, leaves 2hl,2hl+1
-    const int unitB = 2 * wave + half;
-
-    for (int fr = 0; fr < T; ++fr) {
-        const float* feat = P.features + ((size_t)b * T + fr) * FPC_NB_FEATURES;
-        const float shape_e = fpc_shape_exponent(feat[19]);
-        const float* cfa = P.cfa + ((size_t)b * T + fr) * GA;
-        const float* cfb = P.cfb + ((size_t)b * T + fr) * GB;
-        if (tid < FPC_FRAME_SIZE)
-            L.uframe[tid] = fpc_philox_uniform(seed, (uint32_t)(fr * FPC_FRAME_SIZE + tid));
-        // uframe is first read in phase EF, behind several barriers
-
-        for (int i = (fr == 0 ? FPC_LPC_ORDER + 1 : 0); i < FPC_FRAME_SIZE; ++i) {
-            const int t = fr * FPC_FRAME_SIZE + i;
-
-            // ================= phase A: gather issue | sparse mat-vec | side chains =========
-            float g_t[9], g_c[3];
-            if (tid < RNN_A) {
-                const unsigned o0 = (unsigned)L.e_sig * GA + tid;
-                const unsigned o1 = (256u + (unsigned)L.e_pred) * GA + tid;
-                const unsigned o2 = (512u + (unsigned)L.e_exc) * GA + tid;
-#pragma unroll
-                for (int g = 0; g < 3; ++g) {
-                    g_t[g * 3 + 0] = P.tab[o0 + g * RNN_A];
-                    g_t[g * 3 + 1] = P.tab[o1 + g * RNN_A];
-                    g_t[g * 3 + 2] = P.tab[o2 + g * RNN_A];
-                    g_c[g] = cfa[(unsigned)(g * RNN_A + tid)];
-                }
-            } else {
-#pragma unroll
-                for (int g = 0; g < 9; ++g) g_t[g] = 0.0f;
-                g_c[0] = g_c[1] = g_c[2] = 0.0f;
-            }
-            {
-                float acc[8];
-#pragma unroll
-                for (int lf = 0; lf < 2; ++lf) {  // two canonical leaves of two blocks each
-                    const float4 ha = *reinterpret_cast<const float4*>(&L.s1[colb[2 * lf] * 4]);
-                    const float4 hb = *reinterpret_cast<const float4*>(&L.s1[colb[2 * lf + 1] * 4]);
-                    const float* wl = &w[lf * 64];
-#pragma unroll
-                    for (int r = 0; r < 8; ++r) {
-                        float a = 0.0f;
-                        a = fmaf(wl[r * 4 + 0], ha.x, a);
-                        a = fmaf(wl[r * 4 + 1], ha.y, a);
-                        a = fmaf(wl[r * 4 + 2], ha.z, a);
-                        a = fmaf(wl[r * 4 + 3], ha.w, a);
-                        a = fmaf(wl[32 + r * 4 + 0], hb.x, a);
-                        a = fmaf(wl[32 + r * 4 + 1], hb.y, a);
-                        a = fmaf(wl[32 + r * 4 + 2], hb.z, a);
-                        a = fmaf(wl[32 + r * 4 + 3], hb.w, a);
-                        acc[r] = lf == 0 ? a : acc[r] + a;  // first tree level is in-lane
-                    }
-                }
-                for (int s = 1; s < maxQ; s <<= 1) {
-#pragma unroll
-                    for (int r = 0; r < 8; ++r) {
-                        const float o = __shfl_down(acc[r], s);
-                        if (lq + s < lQ) acc[r] = acc[r] + o;
-                    }
-                }
-                if (grp >= 0 && lq == 0) {
-                    const int gate = grp / (RNN_A / 8), rb = grp - gate * (RNN_A / 8);
-                    const int row0 = gate * RNN_A + rb * 8;
-#pragma unroll
-                    for (int r = 0; r < 8; ++r)
-                        L.rec[row0 + r] = fmaf(L.diag[row0 + r], L.s1[rb * 8 + r], acc[r]);
-                }
-            }
-            // GRU_B recurrent part of this wave's two units: balanced tree over 16 products
-            float ub_z, ub_r, ub_n;
-            {
-                const int g = (lane >> 4) < 3 ? (lane >> 4) : 0, k = lane & 15;
-                const float s2k = L.s2[k];
-                const float pa = bfly_sum(L.ub[k * GB + g * RNN_B + 2 * wave] * s2k, 16);
-                const float pb = bfly_sum(L.ub[k * GB + g * RNN_B + 2 * wave + 1] * s2k, 16);
-                const float za = __shfl(pa, 0), ra = __shfl(pa, 16), na = __shfl(pa, 32);
-                const float zb = __shfl(pb, 0), rb2 = __shfl(pb, 16), nb = __shfl(pb, 32);
-                ub_z = half ? zb : za;
-                ub_r = half ? rb2 : ra;
-                ub_n = half ? nb : na;
-            }
-            // LPC history chain for the NEXT sample (all taps except the newest)
-            if (tid == NTHREADS - 1) {
-                int frn = (t + 1) / FPC_FRAME_SIZE;
-                frn = frn < T ? frn : T - 1;
-                const float* a = P.features + ((size_t)b * T + frn) * FPC_NB_FEATURES +
-                                 (FPC_NB_FEATURES - FPC_LPC_ORDER);
-                float acc = 0.0f;
-#pragma unroll
-                for (int k = FPC_LPC_ORDER; k >= 2; --k)
-                    acc = fmaf(a[k - 1], L.hist[(t + 1 - k) & 15], acc);
-                L.partial = acc;
-                L.a1n = a[0];
-            }
-            // input-side gate sums (the gather has landed behind the mat-vec by now)
-            const float gz = ((g_t[0] + g_t[1]) + g_t[2]) + g_c[0];
-            const float gr = ((g_t[3] + g_t[4]) + g_t[5]) + g_c[1];
-            const float gn = ((g_t[6] + g_t[7]) + g_t[8]) + g_c[2];
-            FPC_STAMP(0)
-            __syncthreads();  // B0
-            FPC_STAMP(6)
-
-            // ================= phase B: GRU_A gates =====================================
-            if (tid < RNN_A) {
-                const float h = L.s1[tid];
-                const float z = fpc_sigmoidf(gz + L.rec[tid]);
-                const float r = fpc_sigmoidf(gr + L.rec[RNN_A + tid]);
-                const float n = fpc_tanhf(fmaf(r, L.rec[2 * RNN_A + tid] + L.brn_a[tid], gn));
-                L.s1[tid] = fmaf(z, h - n, n);
-            }
-            FPC_STAMP(1)
-            __syncthreads();  // B1
-            FPC_STAMP(6)
-
-            // ================= phase C: GRU_B (half-wave = unit) =========================
-            {
-                const float4 h0 = *reinterpret_cast<const float4*>(&L.s1[12 * hl]);
-                const float4 h1 = *reinterpret_cast<const float4*>(&L.s1[12 * hl + 4]);
-                const float4 h2 = *reinterpret_cast<const float4*>(&L.s1[12 * hl + 8]);
-                float a3[3];
-#pragma unroll
-                for (int g = 0; g < 3; ++g) {
-                    const float* wg = &wb[g * 12];
-                    float a = 0.0f, c = 0.0f;  // leaves 2hl and 2hl+1 (6 inputs each)
-                    a = fmaf(wg[0], h0.x, a);
-                    a = fmaf(wg[1], h0.y, a);
-                    a = fmaf(wg[2], h0.z, a);
-                    a = fmaf(wg[3], h0.w, a);
-                    a = fmaf(wg[4], h1.x, a);
-                    a = fmaf(wg[5], h1.y, a);
-                    c = fmaf(wg[6], h1.z, c);
-                    c = fmaf(wg[7], h1.w, c);
-                    c = fmaf(wg[8], h2.x, c);
-                    c = fmaf(wg[9], h2.y, c);
-                    c = fmaf(wg[10], h2.z, c);
-                    c = fmaf(wg[11], h2.w, c);
-                    a3[g] = bfly_sum(a + c, 32);
-                }
-                if (hl == 0) {
-                    const float cfb_z = cfb[unitB], cfb_r = cfb[RNN_B + unitB], cfb_n = cfb[2 * RNN_B + unitB];
-                    const float so = L.s2[unitB];
-                    const float z = fpc_sigmoidf((a3[0] + cfb_z) + ub_z);
-                    const float r = fpc_sigmoidf((a3[1] + cfb_r) + ub_r);
-                    const float n = fpc_tanhf(fmaf(r, ub_n + L.brn_b[unitB], a3[2] + cfb_n));
-                    L.s2[unitB] = fmaf(z, so - n, n);
-                }
-            }
-            FPC_STAMP(2)
-            __syncthreads();  // B2
-            FPC_STAMP(6)
-
-            // ================= phase D1: dual FC -> node probabilities ====================
-            {
-                float acc = fcw[16];
-#pragma unroll
-                for (int k4 = 0; k4 < 4; ++k4) {
-                    const float4 wv = *reinterpret_cast<const float4*>(&fcw[4 * k4]);
-                    const float4 sv = *reinterpret_cast<const float4*>(&L.s2[4 * k4]);
-                    acc = fmaf(wv.x, sv.x, acc);
-                    acc = fmaf(wv.y, sv.y, acc);
-                    acc = fmaf(wv.z, sv.z, acc);
-                    acc = fmaf(wv.w, sv.w, acc);
-                }
-                const float tt = fpc_tanhf(acc);
-                const float ff = fcw[17];
-                const float to = __shfl_xor(tt, 1), fo = __shfl_xor(ff, 1);
-                // v = fma(f1, t1, f0*t0) evaluated identically on both lanes of the pair
-                const float v = fch == 0 ? fmaf(fo, to, ff * tt) : fmaf(ff, tt, fo * to);
-                if (fch == 0) L.q[fnode] = fpc_sigmoidf(v);
-            }
-            FPC_STAMP(3)
-            __syncthreads();  // B3
-            FPC_STAMP(6)
-
-            // ================= phase D2: tree pdf and per-leaf candidates (256 lanes) ======
-            if (tid < 256) {
-                float p = 1.0f;
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const float qq = L.q[(1 << j) + (tid >> (8 - j))];
-                    p = p * (((tid >> (7 - j)) & 1) ? qq : 1.0f - qq);
-                }
-                if (shape_e > 0.0f) p = fpc_shape_pow(p, shape_e);
-                L.p[tid] = p;
-                // what the control block becomes if this leaf wins the draw
-                const float cpcm = L.pred + my_ulaw;
-                const float cpred = -fmaf(L.a1n, cpcm, L.partial);
-                L.cand_pcm[tid] = cpcm;
-                L.cand_pred[tid] = cpred;
-                L.cand_e[tid] = fpc_lin2ulaw(cpcm) | (fpc_lin2ulaw(cpred) << 8);
-            }
-            FPC_STAMP(4)
-            __syncthreads();  // B4
-            FPC_STAMP(6)
-
-            // ================= phase EF (wave 0): normaliser, tail cut, scan, draw ==========
-            if (wave == 0) {
-                const float4 p4 = *reinterpret_cast<const float4*>(&L.p[4 * lane]);
-                const float S1 = bfly_sum((p4.x + p4.y) + (p4.z + p4.w), 64);
-                const float thr = 0.002f * S1;
-                float c0 = p4.x - thr, c1 = p4.y - thr, c2 = p4.z - thr, c3 = p4.w - thr;
-                c0 = c0 > 0.0f ? c0 : 0.0f;
-                c1 = c1 > 0.0f ? c1 : 0.0f;
-                c2 = c2 > 0.0f ? c2 : 0.0f;
-                c3 = c3 > 0.0f ? c3 : 0.0f;
-                c1 = c0 + c1;  // sequential prefix inside the lane's 4 leaves
-                c2 = c1 + c2;
-                c3 = c2 + c3;
-                float I = c3;  // Kogge-Stone over the 64 lane totals
-#pragma unroll
-                for (int s = 1; s < 64; s <<= 1) {
-                    const float o = __shfl_up(I, s);
-                    if (lane >= s) I = I + o;
-                }
-                const float S2 = __shfl(I, 63);
-                const float rthr = L.uframe[i] * S2;
-                const int lw = __popcll(__ballot(lane < 63 && I <= rthr));  // winning lane
-                const float Iprev = __shfl_up(I, 1);
-                if (lane == lw) {
-                    const float O = lane > 0 ? Iprev : 0.0f;
-                    int cnt = ((O + c0) <= rthr) + ((O + c1) <= rthr) + ((O + c2) <= rthr) +
-                              ((O + c3) <= rthr);
-                    cnt = cnt > 3 ? 3 : cnt;
-                    const int exc = 4 * lane + cnt;
-                    const int ce = L.cand_e[exc];
-                    const float cpcm = L.cand_pcm[exc];
-                    L.e_sig = ce & 0xff;
-                    L.e_pred = ce >> 8;
-                    L.e_exc = exc;
-                    L.pred = L.cand_pred[exc];
-                    L.hist[t & 15] = cpcm;
-                    const float mem = fmaf(FPC_PREEMPH, L.mem, cpcm);
-                    L.mem = mem;
-                    out[t] = fpc_pcm16(mem);
-                }
-            }
-            FPC_STAMP(5)
-            __syncthreads();  // B5
-            FPC_STAMP(6)
-        }
-    }
-    if (STAMP && blockIdx.x == 0 && tid == 0)
-        for (int k = 0; k < 8; ++k) P.stamps[k] = st_acc[k];
-}
+#include "lpcnet_decode.h"
 
 }  // namespace
 
@@ -468,8 +101,8 @@ struct fpc_lpcnet {
     int device = 0;
     fpc::DevBuf embed_pitch, conv1_k, conv1_b, conv2_k, conv2_b, d1_k, d1_b, d2_k, d2_b;
     fpc::DevBuf ga_k, gb_k, bias_a, bias_b, tab;
-    fpc::DevBuf lane_w, lane_meta, lane_wb, ub, diag, brn_a, brn_b, fc_tab, ulaw_tab;
-    int wave_maxQ[NWAVES];
+    fpc::DevBuf lane_w, lane_meta, lane_wb, lane_ub, lane_fc, diag, brn_a, brn_b, ulaw_tab;
+    int wave_maxQ[NMW];
     int nblocks = 0, nleaves = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool timed = false;
@@ -552,8 +185,9 @@ extern "C" int fpc_lpcnet_create(const fpc_lpcnet_weights* w, fpc_lpcnet** out) 
         }
         m->nblocks += (int)grps[g].cols.size();
     }
-    // canonical leaf = 2 consecutive blocks; a lane owns 2 consecutive leaves (4 blocks);
-    // the lanes of one row group are consecutive lanes of one wave
+    // canonical leaf = 2 consecutive blocks; a mat-vec lane owns 2 consecutive leaves (4 blocks);
+    // the lanes of one row group are consecutive lanes of ONE 16-lane DPP row
+    constexpr int NROWS16 = NMAT / 16;
     std::vector<int> order(NROWGRP);
     for (int g = 0; g < NROWGRP; ++g) order[g] = g;
     auto lanes_of = [&](int g) {  // an empty row group still owns one (all-zero) lane
@@ -564,73 +198,70 @@ extern "C" int fpc_lpcnet_create(const fpc_lpcnet_weights* w, fpc_lpcnet** out) 
         const int la = lanes_of(a), lb = lanes_of(b);
         return la != lb ? la > lb : a < b;
     });
-    int wave_fill[NWAVES] = {0};
-    for (int i = 0; i < NWAVES; ++i) m->wave_maxQ[i] = 1;
-    std::vector<float> lane_w((size_t)128 * NTHREADS, 0.0f);
-    std::vector<int> lane_meta(6 * NTHREADS, 0);
-    for (int l = 0; l < NTHREADS; ++l) {
-        lane_meta[4 * NTHREADS + l] = -1;
-        lane_meta[5 * NTHREADS + l] = (1 << 8);
-    }
+    int row_fill[NROWS16] = {0};
+    for (int i = 0; i < NMW; ++i) m->wave_maxQ[i] = 1;
+    std::vector<float> lane_w((size_t)128 * NMAT, 0.0f);
+    std::vector<int> lane_meta(2 * NMAT, 0);
+    for (int l = 0; l < NMAT; ++l) lane_meta[NMAT + l] = (1 << 8);  // no group, 1 lane, lane 0
     for (int oi = 0; oi < NROWGRP; ++oi) {
         const int g = order[oi], Q = lanes_of(g);
         int best = -1;
-        for (int wv = 0; wv < NWAVES; ++wv)  // least-filled wave that still has room
-            if (wave_fill[wv] + Q <= 64 && (best < 0 || wave_fill[wv] < wave_fill[best])) best = wv;
-        if (best < 0) {
+        for (int rw = 0; rw < NROWS16; ++rw)  // least-filled 16-lane row that still has room
+            if (row_fill[rw] + Q <= 16 && (best < 0 || row_fill[rw] < row_fill[best])) best = rw;
+        if (Q > 16 || best < 0) {
             fpc::set_error(
-                "fpc_lpcnet_create: recurrent matrix too dense for the register-resident "
-                "layout (%d blocks of 8x4; capacity %d)", m->nblocks, 4 * NTHREADS);
+                "fpc_lpcnet_create: recurrent matrix too dense for the register-resident layout "
+                "(%d blocks of 8x4, row group %d needs %d lanes; capacity %d blocks, 64 per row group)",
+                m->nblocks, g, Q, 4 * NMAT);
             delete m;
             return FPC_ERR_CAPACITY;
         }
         const int gate = g / (RNN_A / 8), rb = g % (RNN_A / 8);
         for (int q = 0; q < Q; ++q) {
-            const int l = best * 64 + wave_fill[best] + q;
-            lane_meta[4 * NTHREADS + l] = g;
-            lane_meta[5 * NTHREADS + l] = q | (Q << 8);
+            const int l = best * 16 + row_fill[best] + q;
+            lane_meta[NMAT + l] = q | (Q << 8) | ((g + 1) << 16);
+            unsigned colp = 0;
             for (int bb = 0; bb < 4; ++bb) {
                 const int bi = 4 * q + bb;
-                if (bi >= (int)grps[g].cols.size()) continue;  // weights stay 0, column 0
+                if (bi >= (int)grps[g].cols.size()) continue;  // weights stay 0, column block 0
                 const int cb = grps[g].cols[bi];
-                lane_meta[bb * NTHREADS + l] = cb;
+                colp |= (unsigned)cb << (8 * bb);
                 for (int r = 0; r < 8; ++r)
                     for (int c = 0; c < 4; ++c) {
                         const int in = cb * 4 + c, o = rb * 8 + r;
-                        lane_w[(size_t)(bb * 32 + r * 4 + c) * NTHREADS + l] =
+                        lane_w[(size_t)(bb * 32 + r * 4 + c) * NMAT + l] =
                             in == o ? 0.0f : w->gru_a_recurrent[(size_t)in * GA + gate * RNN_A + o];
                     }
             }
+            lane_meta[l] = (int)colp;
         }
-        wave_fill[best] += Q;
-        if (Q > m->wave_maxQ[best]) m->wave_maxQ[best] = Q;
+        row_fill[best] += Q;
+        const int wv = best / 4;
+        if (Q > m->wave_maxQ[wv]) m->wave_maxQ[wv] = Q;
         m->nleaves += Q;
     }
     FPC_HIP(m->lane_w.upload(lane_w));
     FPC_HIP(m->lane_meta.upload(lane_meta));
 
-    // GRU_B input weights: half-wave = unit, lane = 12 consecutive inputs (2 leaves of 6)
-    std::vector<float> lane_wb(36 * NTHREADS);
-    for (int wv = 0; wv < NWAVES; ++wv)
-        for (int l = 0; l < 64; ++l) {
-            const int unit = 2 * wv + (l >> 5), hl = l & 31;
-            for (int g = 0; g < 3; ++g)
-                for (int k = 0; k < 12; ++k)
-                    lane_wb[(g * 12 + k) * NTHREADS + wv * 64 + l] =
-                        w->gru_b_kernel[(size_t)(12 * hl + k) * GB + g * RNN_B + unit];
+    // sampler-lane weights: lane = (unit u, slice kl) for GRU_B, lane = tree node for the dual FC
+    std::vector<float> lane_wb(72 * NSAMP), lane_ub(3 * NSAMP), lane_fc(36 * NSAMP);
+    for (int sl = 0; sl < NSAMP; ++sl) {
+        const int u = sl >> 4, kl = sl & 15;
+        for (int g = 0; g < 3; ++g) {
+            for (int k = 0; k < 24; ++k)
+                lane_wb[(g * 24 + k) * NSAMP + sl] = w->gru_b_kernel[(size_t)(24 * kl + k) * GB + g * RNN_B + u];
+            lane_ub[g * NSAMP + sl] = w->gru_b_recurrent[kl * GB + g * RNN_B + u];
         }
-    FPC_HIP(m->lane_wb.upload(lane_wb));
-    FPC_HIP(up(m->ub, w->gru_b_recurrent, RNN_B * GB));
-
-    std::vector<float> fc(256 * 2 * FC_STRIDE, 0.0f);
-    for (int j = 0; j < 256; ++j)
         for (int ch = 0; ch < 2; ++ch) {
-            float* d = &fc[(j * 2 + ch) * FC_STRIDE];
-            for (int k = 0; k < RNN_B; ++k) d[k] = w->md_kernel[((size_t)j * RNN_B + k) * 2 + ch];
-            d[16] = w->md_bias[j * 2 + ch];
-            d[17] = w->md_factor[j * 2 + ch];
+            for (int k = 0; k < RNN_B; ++k)
+                lane_fc[(ch * 16 + k) * NSAMP + sl] = w->md_kernel[((size_t)sl * RNN_B + k) * 2 + ch];
+            lane_fc[(32 + ch) * NSAMP + sl] = w->md_bias[sl * 2 + ch];
+            lane_fc[(34 + ch) * NSAMP + sl] = w->md_factor[sl * 2 + ch];
         }
-    FPC_HIP(m->fc_tab.upload(fc));
+    }
+    FPC_HIP(m->lane_wb.upload(lane_wb));
+    FPC_HIP(m->lane_ub.upload(lane_ub));
+    FPC_HIP(m->lane_fc.upload(lane_fc));
     std::vector<float> ulaw(256);
     for (int u = 0; u < 256; ++u) ulaw[u] = fpc_ulaw2lin(u);
     FPC_HIP(m->ulaw_tab.upload(ulaw));
@@ -735,18 +366,20 @@ extern "C" int fpc_lpcnet_synthesize(fpc_lpcnet* m, const float* features_dev, i
     P.lane_w = m->lane_w.as<float>();
     P.lane_meta = m->lane_meta.as<int>();
     P.lane_wb = m->lane_wb.as<float>();
-    P.ub = m->ub.as<float>();
+    P.lane_ub = m->lane_ub.as<float>();
+    P.lane_fc = m->lane_fc.as<float>();
     P.diag = m->diag.as<float>();
     P.brn_a = m->brn_a.as<float>();
     P.brn_b = m->brn_b.as<float>();
-    P.fc_tab = m->fc_tab.as<float>();
     P.ulaw_tab = m->ulaw_tab.as<float>();
-    for (int i = 0; i < NWAVES; ++i) P.wave_maxQ[i] = m->wave_maxQ[i];
+    P.dbg_const_rows = getenv("FPC_DBG_CONST_ROWS") != nullptr;
+    for (int i = 0; i < NMW; ++i) P.wave_maxQ[i] = m->wave_maxQ[i];
     const bool stamp = getenv("FPC_DECODE_STAMPS") != nullptr;
     fpc::DevBuf stamps;
     P.stamps = nullptr;
     if (stamp) {
-        FPC_HIP(stamps.alloc(8 * sizeof(unsigned long long)));
+        FPC_HIP(stamps.alloc(16 * sizeof(unsigned long long)));
+        FPC_HIP(hipMemsetAsync(stamps.p, 0, 16 * sizeof(unsigned long long), st));
         P.stamps = stamps.as<unsigned long long>();
     }
     FPC_HIP(hipEventRecord(m->ev0, st));
@@ -757,12 +390,15 @@ extern "C" int fpc_lpcnet_synthesize(fpc_lpcnet* m, const float* features_dev, i
     FPC_HIP(hipEventRecord(m->ev1, st));
     FPC_HIP(hipGetLastError());
     if (stamp) {  // diagnostic path only: synchronises
-        unsigned long long h[8];
+        unsigned long long h[16];
         FPC_HIP(hipStreamSynchronize(st));
         FPC_HIP(hipMemcpy(h, stamps.p, sizeof h, hipMemcpyDeviceToHost));
         const double n = (double)T * FPC_FRAME_SIZE - 17;
-        fprintf(stderr, "[fpc stamps] cycles/sample (wave0): A=%.0f B=%.0f C=%.0f D1=%.0f D2=%.0f EF=%.0f barrier-wait=%.0f\n",
-                h[0] / n, h[1] / n, h[2] / n, h[3] / n, h[4] / n, h[5] / n, h[6] / n);
+        fprintf(stderr,
+                "[fpc stamps] cycles/sample  sampler wave0: window=%.0f GRU_B=%.0f (dot %.0f) FC=%.0f leaves=%.0f draw=%.0f wait=%.0f"
+                " | mat-vec wave4: gather=%.0f gates=%.0f leaf0=%.0f leaf1=%.0f tree=%.0f wait=%.0f\n",
+                h[0] / n, (h[1] + h[5]) / n, h[5] / n, h[2] / n, h[3] / n, h[4] / n, h[6] / n, h[13] / n, h[15] / n,
+                h[9] / n, h[10] / n, h[11] / n, h[14] / n);
     }
     m->timed = true;
     return FPC_OK;

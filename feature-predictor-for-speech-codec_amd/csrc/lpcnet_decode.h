@@ -1,0 +1,472 @@
+// lpcnet_decode.h -- the persistent per-utterance sample loop of the LPCNet-style vocoder
+// (included by lpcnet.hip only; gfx950).
+//
+// One 768-thread workgroup (12 wave64, 3 per SIMD, 168 VGPRs each) per utterance:
+//   waves 0-3  "sampler":  GRU_B, dual-FC, tree pdf, draw   (GRU_B weights in VGPRs)
+//   waves 4-11 "mat-vec":  embedding-row gather + GRU_A gates, and the block-sparse
+//                          recurrent product for the NEXT sample (weights in VGPRs)
+// Five workgroup barriers per output sample (X, Y, Z1, Z2, Z3):
+//   X  control block (mu-law indices of the drawn sample) published
+//        M: gather 3 table rows, gates -> s1'
+//        S: GRU_B recurrent part, LPC history chain, per-leaf candidates of this sample
+//   Y  s1' ready
+//        S: GRU_B -> s2'                           M: sparse product, leaf 0
+//   Z1 s2' ready
+//        S: dual FC -> 255 node probabilities      M: sparse product, leaf 1
+//   Z2 q ready
+//        S: leaf probabilities                     M: DPP tree, diagonal, rec -> LDS
+//   Z3 pdf ready
+//        S wave 0: normaliser, tail cut, scan, draw, control block
+// The sparse product (61 % of the algorithmic FLOPs) never sits on the sample-to-sample
+// critical path; HBM is touched only for the gathered table rows (L2-resident), the
+// per-frame conditioning rows and 2 bytes of PCM per sample.
+//
+// Canonical evaluation orders (DESIGN.md "Vocoder numerics") are those of
+// oracle/fpc_oracle.c::orc_lpcnet_synthesize; results are bit-identical.
+#pragma once
+
+constexpr int NTHREADS = 768;
+constexpr int NSAMP = 256;  // sampler lanes (waves 0-3)
+constexpr int NMAT = 512;   // mat-vec lanes (waves 4-11)
+constexpr int NMW = NMAT / 64;
+
+struct DecodeParams {
+    const float* tab;       // [3][256][384][3]  embedding x input-kernel tables, gate-interleaved
+    const float* cfa;       // [B][T][1152]  GRU_A conditioning product (+biases)
+    const float* cfb;       // [B][T][48]    GRU_B conditioning product (+biases)
+    const float* features;  // [B][T][36]
+    const unsigned long long* seeds;
+    int16_t* pcm;  // [B][T*160]
+    int T;
+    const float* lane_w;     // [128][512] sparse GRU_A weights: 2 leaves x 2 blocks x 8x4
+    const int* lane_meta;    // [2][512]   packed column blocks; (group+1)<<16 | lanes<<8 | lane
+    const float* lane_wb;    // [72][256]  GRU_B input weights [gate][24 inputs] of (unit, slice)
+    const float* lane_ub;    // [3][256]   GRU_B recurrent weights ub[k][gate*16+unit]
+    const float* lane_fc;    // [36][256]  dual-FC of node = lane: 2x16 weights, 2 bias, 2 factor
+    const float* diag;       // [1152]
+    const float* brn_a;      // [384]
+    const float* brn_b;      // [16]
+    const float* ulaw_tab;   // [256]
+    int wave_maxQ[NMW];
+    unsigned long long* stamps;  // diagnostic only
+    int dbg_const_rows;          // diagnostic only (STAMP build): gather fixed table rows
+};
+
+struct __attribute__((aligned(16))) DecodeLds {
+    float s1[RNN_A];
+    float rec[GA];
+    float diag[GA];
+    float cfa[GA];            // this frame's GRU_A conditioning rows [z|r|h][unit]
+    float fc[9 * NSAMP * 4];  // dual-FC weights of node = lane, [chunk][lane][4]
+    float brn_a[RNN_A];
+    float uframe[FPC_FRAME_SIZE];
+    float q[256];
+    float p[256];
+    float cand_pcm[256];
+    float cand_pred[256];
+    int cand_e[256];  // e_sig | e_pred << 8
+    float s2[RNN_B];
+    float hist[16];
+    // control block written by the winning lane / the LPC chain lane
+    int e_sig, e_pred, e_exc, pad0;
+    float pred, partial, a1n, mem;
+};
+
+// ---- DPP helpers (gfx9 DPP controls; invalid source lanes read 0) ----
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
+}
+constexpr int DPP_XOR1 = 0xB1, DPP_XOR2 = 0x4E, DPP_HALF_MIRROR = 0x141, DPP_MIRROR = 0x140;
+constexpr int DPP_ROW_SHL = 0x100, DPP_ROW_SHR = 0x110, DPP_WAVE_SHR1 = 0x138;
+
+// balanced (adjacent-pair) sum over each aligned row of 16 lanes; result in every lane
+__device__ __forceinline__ float row_bfly16(float v) {
+    v = v + dpp_f<DPP_XOR1>(v);
+    v = v + dpp_f<DPP_XOR2>(v);
+    v = v + dpp_f<DPP_HALF_MIRROR>(v);
+    v = v + dpp_f<DPP_MIRROR>(v);
+    return v;
+}
+__device__ __forceinline__ float lane_val(float v, int l) {
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l));
+}
+// opaque copy: the compiler recomputes what derives from it instead of hoisting + spilling
+__device__ __forceinline__ unsigned opaque(unsigned v) {
+    asm volatile("" : "+v"(v));
+    return v;
+}
+
+// STAMP=true is a diagnostic build (env FPC_DECODE_STAMPS=1): lane 0 of wave 0 (slots 0-7) and
+// of wave 4 (slots 8-15) of block 0 accumulate s_memtime deltas per phase; never timed.
+#define FPC_STAMP(k)                                                  \
+    if (STAMP) {                                                      \
+        const unsigned long long now_ = __builtin_readcyclecounter(); \
+        st_acc[k] += now_ - st_last;                                  \
+        st_last = now_;                                               \
+    }
+#define FPC_BARRIER()   \
+    FPC_STAMP(st_phase) \
+    __syncthreads();    \
+    FPC_STAMP(6)
+
+template <bool STAMP>
+__global__ __launch_bounds__(NTHREADS) void k_decode(const DecodeParams P) {
+    __shared__ DecodeLds L;
+    unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long st_last = STAMP ? __builtin_readcyclecounter() : 0;
+    int st_phase = 0;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int b = blockIdx.x, T = P.T;
+
+    // ---- LDS init ----
+    for (int i = tid; i < RNN_A; i += NTHREADS) {
+        L.s1[i] = 0.0f;
+        L.brn_a[i] = P.brn_a[i];
+    }
+    for (int i = tid; i < GA; i += NTHREADS) {
+        L.rec[i] = 0.0f;
+        L.diag[i] = P.diag[i];
+    }
+    if (tid < NSAMP) {
+#pragma unroll
+        for (int j = 0; j < 36; ++j) L.fc[((j >> 2) * NSAMP + tid) * 4 + (j & 3)] = P.lane_fc[j * NSAMP + tid];
+    }
+    if (tid < RNN_B) {
+        L.s2[tid] = 0.0f;
+        L.hist[tid] = 0.0f;
+    }
+    if (tid == 0) {
+        L.e_sig = 128;
+        L.e_pred = 128;
+        L.e_exc = 128;
+        L.pred = -0.0f;
+        L.partial = 0.0f;
+        L.a1n = 0.0f;
+        L.mem = 0.0f;
+    }
+    int16_t* out = P.pcm + (size_t)b * T * FPC_FRAME_SIZE;
+    if (tid < FPC_LPC_ORDER + 1) out[tid] = 0;  // test_lpcnet.py skips order+1 samples
+    __syncthreads();
+
+    if (wave >= 4) {
+        // =========================== mat-vec role ===========================
+        const int ml_ = tid - NSAMP;
+        float w[128];
+#pragma unroll
+        for (int j = 0; j < 128; ++j) w[j] = P.lane_w[j * NMAT + ml_];
+        const unsigned colp_ = (unsigned)P.lane_meta[ml_];
+        const unsigned metap_ = (unsigned)P.lane_meta[NMAT + ml_];
+        int maxQ = 1;
+#pragma unroll
+        for (int i = 0; i < NMW; ++i)
+            if (i == __builtin_amdgcn_readfirstlane(wave - 4)) maxQ = P.wave_maxQ[i];
+        const bool gate_lane = ml_ < RNN_A;
+
+        for (int fr = 0; fr < T; ++fr) {
+            {  // this frame's conditioning rows -> LDS (read by the gate lanes right below)
+                const float* cfa = P.cfa + ((size_t)b * T + fr) * GA;
+                for (int k = ml_; k < GA; k += NMAT) L.cfa[k] = cfa[k];
+            }
+            for (int i = (fr == 0 ? FPC_LPC_ORDER + 1 : 0); i < FPC_FRAME_SIZE; ++i) {
+                // ---- X..Y: gather the three embedding-table rows, GRU_A gates ----
+                st_phase = 0;
+                if (gate_lane) {
+                    const unsigned ml = opaque((unsigned)ml_);
+                    struct F3 {
+                        float x, y, z;
+                    };
+                    unsigned ea = (unsigned)L.e_sig, eb = (unsigned)L.e_pred, ec = (unsigned)L.e_exc;
+                    if (STAMP && P.dbg_const_rows) ea = eb = ec = 128u;  // timing experiment (wrong output)
+                    const F3 ta = *reinterpret_cast<const F3*>(P.tab + (ea * GA + 3u * ml));
+                    const F3 tb = *reinterpret_cast<const F3*>(P.tab + ((256u + eb) * GA + 3u * ml));
+                    const F3 tc = *reinterpret_cast<const F3*>(P.tab + ((512u + ec) * GA + 3u * ml));
+                    const float uz = L.rec[ml], ur = L.rec[RNN_A + ml], un = L.rec[2 * RNN_A + ml];
+                    const float cz = L.cfa[ml], cr = L.cfa[RNN_A + ml], cn = L.cfa[2 * RNN_A + ml];
+                    const float brn = L.brn_a[ml];
+                    const float h_own = L.s1[ml];
+                    const float gz = ((ta.x + tb.x) + tc.x) + cz;
+                    const float gr = ((ta.y + tb.y) + tc.y) + cr;
+                    const float gn = ((ta.z + tb.z) + tc.z) + cn;
+                    if (STAMP) {
+                        asm volatile("" ::"v"(gz), "v"(gr), "v"(gn));
+                        FPC_STAMP(5)
+                    }
+                    const float z = fpc_sigmoidf(gz + uz);
+                    const float r = fpc_sigmoidf(gr + ur);
+                    const float n = fpc_tanhf(fmaf(r, un + brn, gn));
+                    const float h_new = fmaf(z, h_own - n, n);
+                    L.s1[ml] = h_new;
+                    if (STAMP) {
+                        asm volatile("" ::"v"(h_new));
+                        FPC_STAMP(7)
+                    }
+                }
+                FPC_BARRIER()  // Y
+                // ---- Y..Z1: leaf 0 ----
+                st_phase = 1;
+                float acc[8];
+                {
+                    const unsigned colp = opaque(colp_);
+                    const float4 ha = *reinterpret_cast<const float4*>(&L.s1[(colp & 0xff) * 4]);
+                    const float4 hb = *reinterpret_cast<const float4*>(&L.s1[((colp >> 8) & 0xff) * 4]);
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) {
+                        float a = 0.0f;
+                        a = fmaf(w[r * 4 + 0], ha.x, a);
+                        a = fmaf(w[r * 4 + 1], ha.y, a);
+                        a = fmaf(w[r * 4 + 2], ha.z, a);
+                        a = fmaf(w[r * 4 + 3], ha.w, a);
+                        a = fmaf(w[32 + r * 4 + 0], hb.x, a);
+                        a = fmaf(w[32 + r * 4 + 1], hb.y, a);
+                        a = fmaf(w[32 + r * 4 + 2], hb.z, a);
+                        a = fmaf(w[32 + r * 4 + 3], hb.w, a);
+                        acc[r] = a;
+                    }
+                }
+                FPC_BARRIER()  // Z1
+                // ---- Z1..Z2: leaf 1, first (in-lane) tree level ----
+                st_phase = 2;
+                {
+                    const unsigned colp = opaque(colp_);
+                    const float4 hc = *reinterpret_cast<const float4*>(&L.s1[((colp >> 16) & 0xff) * 4]);
+                    const float4 hd = *reinterpret_cast<const float4*>(&L.s1[(colp >> 24) * 4]);
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) {
+                        float a = 0.0f;
+                        a = fmaf(w[64 + r * 4 + 0], hc.x, a);
+                        a = fmaf(w[64 + r * 4 + 1], hc.y, a);
+                        a = fmaf(w[64 + r * 4 + 2], hc.z, a);
+                        a = fmaf(w[64 + r * 4 + 3], hc.w, a);
+                        a = fmaf(w[96 + r * 4 + 0], hd.x, a);
+                        a = fmaf(w[96 + r * 4 + 1], hd.y, a);
+                        a = fmaf(w[96 + r * 4 + 2], hd.z, a);
+                        a = fmaf(w[96 + r * 4 + 3], hd.w, a);
+                        acc[r] = acc[r] + a;
+                    }
+                }
+                FPC_BARRIER()  // Z2
+                // ---- Z2..Z3: cross-lane tree (row-local DPP), diagonal, publish rec ----
+                st_phase = 3;
+                {
+                    const unsigned metap = opaque(metap_);
+                    const int lq = (int)(metap & 0xff), lQ = (int)((metap >> 8) & 0xff);
+#define FPC_TREE_LEVEL(S)                                   \
+    if (maxQ > S) {                                         \
+        _Pragma("unroll") for (int r = 0; r < 8; ++r) {     \
+            const float o = dpp_f<DPP_ROW_SHL + S>(acc[r]); \
+            if (lq + S < lQ) acc[r] = acc[r] + o;           \
+        }                                                   \
+    }
+                    FPC_TREE_LEVEL(1)
+                    FPC_TREE_LEVEL(2)
+                    FPC_TREE_LEVEL(4)
+                    FPC_TREE_LEVEL(8)
+#undef FPC_TREE_LEVEL
+                    if ((metap >> 16) != 0 && lq == 0) {
+                        const int grp = (int)(metap >> 16) - 1;
+                        const int gate = grp / (RNN_A / 8), rb = grp - gate * (RNN_A / 8);
+                        const int row0 = gate * RNN_A + rb * 8;
+                        const float4 d0 = *reinterpret_cast<const float4*>(&L.diag[row0]);
+                        const float4 d1 = *reinterpret_cast<const float4*>(&L.diag[row0 + 4]);
+                        const float4 s0 = *reinterpret_cast<const float4*>(&L.s1[rb * 8]);
+                        const float4 s4 = *reinterpret_cast<const float4*>(&L.s1[rb * 8 + 4]);
+                        float4 o0, o1;
+                        o0.x = fmaf(d0.x, s0.x, acc[0]);
+                        o0.y = fmaf(d0.y, s0.y, acc[1]);
+                        o0.z = fmaf(d0.z, s0.z, acc[2]);
+                        o0.w = fmaf(d0.w, s0.w, acc[3]);
+                        o1.x = fmaf(d1.x, s4.x, acc[4]);
+                        o1.y = fmaf(d1.y, s4.y, acc[5]);
+                        o1.z = fmaf(d1.z, s4.z, acc[6]);
+                        o1.w = fmaf(d1.w, s4.w, acc[7]);
+                        *reinterpret_cast<float4*>(&L.rec[row0]) = o0;
+                        *reinterpret_cast<float4*>(&L.rec[row0 + 4]) = o1;
+                    }
+                }
+                FPC_BARRIER()  // Z3
+                st_phase = 4;
+                FPC_BARRIER()  // X
+            }
+        }
+        if (STAMP && blockIdx.x == 0 && tid == NSAMP)
+            for (int k = 0; k < 8; ++k) P.stamps[8 + k] = st_acc[k];
+    } else {
+        // =========================== sampler role ===========================
+        __builtin_amdgcn_s_setprio(3);  // the sample-to-sample critical path lives in these waves
+        const int sl = tid;                    // 0..255
+        const int u = sl >> 4, kl = sl & 15;   // GRU_B: unit, 24-input slice
+        const unsigned long long seed = P.seeds[b];
+        float wb[72];
+#pragma unroll
+        for (int j = 0; j < 72; ++j) wb[j] = P.lane_wb[j * NSAMP + sl];
+        const float ub0 = P.lane_ub[sl], ub1 = P.lane_ub[NSAMP + sl], ub2 = P.lane_ub[2 * NSAMP + sl];
+        const float brnb = P.brn_b[u];
+        const float my_ulaw = P.ulaw_tab[sl];
+        float s2_own = 0.0f;  // state of unit u, replicated over the 16 lanes of its row
+
+        for (int fr = 0; fr < T; ++fr) {
+            const float* feat = P.features + ((size_t)b * T + fr) * FPC_NB_FEATURES;
+            const float shape_e = fpc_shape_exponent(feat[19]);
+            const float* cfb = P.cfb + ((size_t)b * T + fr) * GB;
+            const float cfb_z = cfb[u], cfb_r = cfb[RNN_B + u], cfb_n = cfb[2 * RNN_B + u];
+            if (sl < FPC_FRAME_SIZE)  // first read behind barrier Z3 of this frame's first sample
+                L.uframe[sl] = fpc_philox_uniform(seed, (uint32_t)(fr * FPC_FRAME_SIZE + sl));
+
+            for (int i = (fr == 0 ? FPC_LPC_ORDER + 1 : 0); i < FPC_FRAME_SIZE; ++i) {
+                const int t = fr * FPC_FRAME_SIZE + i;
+                // ---- X..Y (the mat-vec waves gather + gate): everything that only needs the
+                //      previous draw: GRU_B recurrent part, LPC history chain, leaf candidates ----
+                st_phase = 0;
+                const float s2k = L.s2[kl];
+                const float ub_z = row_bfly16(ub0 * s2k);
+                const float ub_r = row_bfly16(ub1 * s2k);
+                const float ub_n = row_bfly16(ub2 * s2k);
+                {
+                    // prediction taps 16..2 of the NEXT sample, evaluated by every lane (broadcast LDS
+                    // reads, uniform coefficient loads) so that no extra hand-off is needed
+                    int frn = (t + 1) / FPC_FRAME_SIZE;
+                    frn = frn < T ? frn : T - 1;
+                    const float* a = P.features + ((size_t)b * T + frn) * FPC_NB_FEATURES +
+                                     (FPC_NB_FEATURES - FPC_LPC_ORDER);
+                    float part = 0.0f;
+#pragma unroll
+                    for (int k = FPC_LPC_ORDER; k >= 2; --k) part = fmaf(a[k - 1], L.hist[(t + 1 - k) & 15], part);
+                    // what the control block becomes if leaf `sl` wins this sample's draw
+                    const float cpcm = L.pred + my_ulaw;
+                    const float cpred = -fmaf(a[0], cpcm, part);
+                    L.cand_pcm[sl] = cpcm;
+                    L.cand_pred[sl] = cpred;
+                    L.cand_e[sl] = fpc_lin2ulaw(cpcm) | (fpc_lin2ulaw(cpred) << 8);
+                }
+                FPC_BARRIER()  // Y
+                // ---- Y..Z1: GRU_B (row of 16 lanes = unit, lane = 4 leaves of 6 inputs) ----
+                st_phase = 1;
+                {
+                    const unsigned klv = opaque((unsigned)kl);
+                    float lf[3][4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {  // canonical leaf j of this lane: 6 inputs
+                        const float2 h0 = *reinterpret_cast<const float2*>(&L.s1[24 * klv + 6 * j]);
+                        const float2 h1 = *reinterpret_cast<const float2*>(&L.s1[24 * klv + 6 * j + 2]);
+                        const float2 h2 = *reinterpret_cast<const float2*>(&L.s1[24 * klv + 6 * j + 4]);
+#pragma unroll
+                        for (int g = 0; g < 3; ++g) {
+                            const float* wg = &wb[g * 24 + j * 6];
+                            float a = 0.0f;
+                            a = fmaf(wg[0], h0.x, a);
+                            a = fmaf(wg[1], h0.y, a);
+                            a = fmaf(wg[2], h1.x, a);
+                            a = fmaf(wg[3], h1.y, a);
+                            a = fmaf(wg[4], h2.x, a);
+                            a = fmaf(wg[5], h2.y, a);
+                            lf[g][j] = a;
+                        }
+                    }
+                    float a3[3];
+#pragma unroll
+                    for (int g = 0; g < 3; ++g) a3[g] = row_bfly16((lf[g][0] + lf[g][1]) + (lf[g][2] + lf[g][3]));
+                    if (STAMP) {
+                        asm volatile("" ::"v"(a3[0]), "v"(a3[1]), "v"(a3[2]));
+                        FPC_STAMP(5)
+                    }
+                    const float z = fpc_sigmoidf((a3[0] + cfb_z) + ub_z);
+                    const float r = fpc_sigmoidf((a3[1] + cfb_r) + ub_r);
+                    const float n = fpc_tanhf(fmaf(r, ub_n + brnb, a3[2] + cfb_n));
+                    s2_own = fmaf(z, s2_own - n, n);
+                    if (kl == 0) L.s2[u] = s2_own;
+                }
+                FPC_BARRIER()  // Z1
+                // ---- Z1..Z2: dual FC of tree node `sl` ----
+                st_phase = 2;
+                {
+                    const unsigned slv = opaque((unsigned)sl);
+                    float4 fw[9];
+#pragma unroll
+                    for (int c = 0; c < 9; ++c) fw[c] = *reinterpret_cast<const float4*>(&L.fc[(c * NSAMP + slv) * 4]);
+                    float a0 = fw[8].x, a1 = fw[8].y;
+#pragma unroll
+                    for (int k4 = 0; k4 < 4; ++k4) {
+                        const float4 sv = *reinterpret_cast<const float4*>(&L.s2[4 * k4]);
+                        a0 = fmaf(fw[k4].x, sv.x, a0);
+                        a1 = fmaf(fw[4 + k4].x, sv.x, a1);
+                        a0 = fmaf(fw[k4].y, sv.y, a0);
+                        a1 = fmaf(fw[4 + k4].y, sv.y, a1);
+                        a0 = fmaf(fw[k4].z, sv.z, a0);
+                        a1 = fmaf(fw[4 + k4].z, sv.z, a1);
+                        a0 = fmaf(fw[k4].w, sv.w, a0);
+                        a1 = fmaf(fw[4 + k4].w, sv.w, a1);
+                    }
+                    const float t0 = fpc_tanhf(a0), t1 = fpc_tanhf(a1);
+                    const float v = fmaf(fw[8].w, t1, fw[8].z * t0);
+                    L.q[slv] = fpc_sigmoidf(v);
+                }
+                FPC_BARRIER()  // Z2
+                // ---- Z2..Z3: leaf probability, MSB first ----
+                st_phase = 3;
+                {
+                    const unsigned slv = opaque((unsigned)sl);
+                    float p = 1.0f;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const float qq = L.q[(1u << j) + (slv >> (8 - j))];
+                        p = p * (((slv >> (7 - j)) & 1u) ? qq : 1.0f - qq);
+                    }
+                    if (shape_e > 0.0f) p = fpc_shape_pow(p, shape_e);
+                    L.p[slv] = p;
+                }
+                FPC_BARRIER()  // Z3
+                // ---- Z3..X (wave 0): normaliser, tail cut, scan, draw, publish ----
+                st_phase = 4;
+                if (wave == 0) {
+                    const float4 p4 = *reinterpret_cast<const float4*>(&L.p[4 * lane]);
+                    const float rs = row_bfly16((p4.x + p4.y) + (p4.z + p4.w));
+                    const float S1 = (lane_val(rs, 0) + lane_val(rs, 16)) + (lane_val(rs, 32) + lane_val(rs, 48));
+                    const float thr = 0.002f * S1;
+                    float c0 = p4.x - thr, c1 = p4.y - thr, c2 = p4.z - thr, c3 = p4.w - thr;
+                    c0 = c0 > 0.0f ? c0 : 0.0f;
+                    c1 = c1 > 0.0f ? c1 : 0.0f;
+                    c2 = c2 > 0.0f ? c2 : 0.0f;
+                    c3 = c3 > 0.0f ? c3 : 0.0f;
+                    c1 = c0 + c1;  // sequential prefix inside the lane's 4 leaves
+                    c2 = c1 + c2;
+                    c3 = c2 + c3;
+                    float I = c3;  // Kogge-Stone inside each row of 16 lanes
+                    I = I + dpp_f<DPP_ROW_SHR + 1>(I);
+                    I = I + dpp_f<DPP_ROW_SHR + 2>(I);
+                    I = I + dpp_f<DPP_ROW_SHR + 4>(I);
+                    I = I + dpp_f<DPP_ROW_SHR + 8>(I);
+                    const float R0 = lane_val(I, 15), R1 = lane_val(I, 31), R2 = lane_val(I, 47);
+                    const float O2 = R0 + R1, O3 = O2 + R2;
+                    if (lane >= 16) I = (lane < 32 ? R0 : (lane < 48 ? O2 : O3)) + I;
+                    const float S2 = lane_val(I, 63);
+                    const float rthr = L.uframe[i] * S2;
+                    const int lw = __popcll(__ballot(lane < 63 && I <= rthr));  // winning lane
+                    const float Iprev = dpp_f<DPP_WAVE_SHR1>(I);
+                    if (lane == lw) {
+                        const float O = lane > 0 ? Iprev : 0.0f;
+                        int cnt = ((O + c0) <= rthr) + ((O + c1) <= rthr) + ((O + c2) <= rthr) +
+                                  ((O + c3) <= rthr);
+                        cnt = cnt > 3 ? 3 : cnt;
+                        const int exc = 4 * lane + cnt;
+                        const int ce = L.cand_e[exc];
+                        const float cpcm = L.cand_pcm[exc];
+                        L.e_sig = ce & 0xff;
+                        L.e_pred = ce >> 8;
+                        L.e_exc = exc;
+                        L.pred = L.cand_pred[exc];
+                        L.hist[t & 15] = cpcm;
+                        const float mem = fmaf(FPC_PREEMPH, L.mem, cpcm);
+                        L.mem = mem;
+                        out[t] = fpc_pcm16(mem);
+                    }
+                }
+                FPC_BARRIER()  // X
+            }
+        }
+        if (STAMP && blockIdx.x == 0 && tid == 0)
+            for (int k = 0; k < 8; ++k) P.stamps[k] = st_acc[k];
+    }
+}
+#undef FPC_BARRIER
+#undef FPC_STAMP

@@ -807,8 +807,9 @@ EXPORT void orc_lpcnet_synthesize(const orc_lpcnet* m, const float* feat, int T,
                 const float d = p[v] - thr;
                 p[v] = d > 0.0f ? d : 0.0f;
             }
-            /* two-level inclusive scan: sequential prefix inside each aligned group of 4
-             * leaves, Kogge-Stone over the 64 group totals */
+            /* three-level inclusive scan: sequential prefix inside each aligned group of 4
+             * leaves; Kogge-Stone over the 16 group totals of each aligned block of 64 leaves;
+             * sequential offsets over the 4 block totals */
             float I64[64];
             for (int g4 = 0; g4 < 64; ++g4) {
                 float run = p[4 * g4];
@@ -819,11 +820,22 @@ EXPORT void orc_lpcnet_synthesize(const orc_lpcnet* m, const float* feat, int T,
                 }
                 I64[g4] = run;
             }
-            for (int d = 1; d < 64; d <<= 1) {
-                float nx[64];
-                for (int l = 0; l < 64; ++l) nx[l] = l >= d ? I64[l] + I64[l - d] : I64[l];
-                memcpy(I64, nx, sizeof nx);
+            float R4[4], O4[4];
+            for (int row = 0; row < 4; ++row) {
+                float* x = I64 + 16 * row;
+                for (int d = 1; d < 16; d <<= 1) {
+                    float nx[16];
+                    for (int l = 0; l < 16; ++l) nx[l] = l >= d ? x[l] + x[l - d] : x[l];
+                    memcpy(x, nx, sizeof nx);
+                }
+                R4[row] = x[15];
             }
+            O4[0] = 0.0f;
+            O4[1] = R4[0];
+            O4[2] = R4[0] + R4[1];
+            O4[3] = O4[2] + R4[2];
+            for (int row = 1; row < 4; ++row)
+                for (int l = 0; l < 16; ++l) I64[16 * row + l] = O4[row] + I64[16 * row + l];
             const float S2 = I64[63];
             const float rthr = fpc_philox_uniform(seed, (uint32_t)t) * S2;
             int wsel = 0; /* group that holds the draw */

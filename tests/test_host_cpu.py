@@ -146,7 +146,8 @@ def test_lpc_only_impulse_response(oracle, synth):
     """zero network weights => excitation index fixed by the uniform pdf; the synthesis filter
     then must equal scipy.signal.lfilter([1],[1,a...]) on u2l(exc) (src/utils.py:91-114 sign)."""
     from scipy.signal import lfilter
-    w = {k: np.zeros(s, np.float32) for k, s in __import__("fpcodec_amd")._lib.LPCNET_SHAPES.items()}
+    from fpcodec_amd import _lib
+    w = {k: np.zeros(s, np.float32) for k, s in _lib.LPCNET_SHAPES.items()}
     orc = oracle.LPCNet(w)
     T = 3
     feat = np.zeros((T, 36), np.float32)
