@@ -164,9 +164,11 @@ __global__ __launch_bounds__(NTHREADS) void k_decode(const DecodeParams P) {
         const bool gate_lane = ml_ < RNN_A;
 
         for (int fr = 0; fr < T; ++fr) {
-            {  // this frame's conditioning rows -> LDS (read by the gate lanes right below)
+            if (gate_lane) {  // this frame's conditioning values of unit ml: written and read by the same lane
                 const float* cfa = P.cfa + ((size_t)b * T + fr) * GA;
-                for (int k = ml_; k < GA; k += NMAT) L.cfa[k] = cfa[k];
+                L.cfa[ml_] = cfa[ml_];
+                L.cfa[RNN_A + ml_] = cfa[RNN_A + ml_];
+                L.cfa[2 * RNN_A + ml_] = cfa[2 * RNN_A + ml_];
             }
             for (int i = (fr == 0 ? FPC_LPC_ORDER + 1 : 0); i < FPC_FRAME_SIZE; ++i) {
                 // ---- X..Y: gather the three embedding-table rows, GRU_A gates ----
