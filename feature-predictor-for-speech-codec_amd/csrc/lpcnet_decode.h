@@ -91,6 +91,16 @@ __device__ __forceinline__ float row_bfly16(float v) {
 __device__ __forceinline__ float lane_val(float v, int l) {
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l));
 }
+typedef float f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f2 mk2(float x, float y) {
+    f2 r;
+    r.x = x;
+    r.y = y;
+    return r;
+}
+__device__ __forceinline__ f2 splat2(float v) { return mk2(v, v); }
+__device__ __forceinline__ f2 fma2(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }  // v_pk_fma_f32
+
 // opaque copy: the compiler recomputes what derives from it instead of hoisting + spilling
 __device__ __forceinline__ unsigned opaque(unsigned v) {
     asm volatile("" : "+v"(v));
@@ -152,9 +162,16 @@ __global__ __launch_bounds__(NTHREADS) void k_decode(const DecodeParams P) {
     if (wave >= 4) {
         // =========================== mat-vec role ===========================
         const int ml_ = tid - NSAMP;
-        float w[128];
+        // w2[(block*4 + col)*4 + rp] = weights of rows (2rp, 2rp+1) at column `col` of block `block`:
+        // one v_pk_fma_f32 advances two row chains by one column with the h value broadcast
+        f2 w2[64];
 #pragma unroll
-        for (int j = 0; j < 128; ++j) w[j] = P.lane_w[j * NMAT + ml_];
+        for (int j = 0; j < 64; ++j) {
+            const int bc = j >> 2, rp = j & 3;  // bc = block*4 + col
+            const int bb = bc >> 2, c = bc & 3;
+            w2[j] = mk2(P.lane_w[(bb * 32 + (2 * rp) * 4 + c) * NMAT + ml_],
+                         P.lane_w[(bb * 32 + (2 * rp + 1) * 4 + c) * NMAT + ml_]);
+        }
         const unsigned colp_ = (unsigned)P.lane_meta[ml_];
         const unsigned metap_ = (unsigned)P.lane_meta[NMAT + ml_];
         int maxQ = 1;
@@ -207,24 +224,18 @@ __global__ __launch_bounds__(NTHREADS) void k_decode(const DecodeParams P) {
                 FPC_BARRIER()  // Y
                 // ---- Y..Z1: leaf 0 ----
                 st_phase = 1;
-                float acc[8];
+                f2 acc[4];
                 {
                     const unsigned colp = opaque(colp_);
                     const float4 ha = *reinterpret_cast<const float4*>(&L.s1[(colp & 0xff) * 4]);
                     const float4 hb = *reinterpret_cast<const float4*>(&L.s1[((colp >> 8) & 0xff) * 4]);
+                    const float hv[8] = {ha.x, ha.y, ha.z, ha.w, hb.x, hb.y, hb.z, hb.w};
 #pragma unroll
-                    for (int r = 0; r < 8; ++r) {
-                        float a = 0.0f;
-                        a = fmaf(w[r * 4 + 0], ha.x, a);
-                        a = fmaf(w[r * 4 + 1], ha.y, a);
-                        a = fmaf(w[r * 4 + 2], ha.z, a);
-                        a = fmaf(w[r * 4 + 3], ha.w, a);
-                        a = fmaf(w[32 + r * 4 + 0], hb.x, a);
-                        a = fmaf(w[32 + r * 4 + 1], hb.y, a);
-                        a = fmaf(w[32 + r * 4 + 2], hb.z, a);
-                        a = fmaf(w[32 + r * 4 + 3], hb.w, a);
-                        acc[r] = a;
-                    }
+                    for (int rp = 0; rp < 4; ++rp) acc[rp] = splat2(0.0f);
+#pragma unroll
+                    for (int bc = 0; bc < 8; ++bc)
+#pragma unroll
+                        for (int rp = 0; rp < 4; ++rp) acc[rp] = fma2(w2[bc * 4 + rp], splat2(hv[bc]), acc[rp]);
                 }
                 FPC_BARRIER()  // Z1
                 // ---- Z1..Z2: leaf 1, first (in-lane) tree level ----
@@ -233,19 +244,16 @@ __global__ __launch_bounds__(NTHREADS) void k_decode(const DecodeParams P) {
                     const unsigned colp = opaque(colp_);
                     const float4 hc = *reinterpret_cast<const float4*>(&L.s1[((colp >> 16) & 0xff) * 4]);
                     const float4 hd = *reinterpret_cast<const float4*>(&L.s1[(colp >> 24) * 4]);
+                    const float hv[8] = {hc.x, hc.y, hc.z, hc.w, hd.x, hd.y, hd.z, hd.w};
+                    f2 a[4];
 #pragma unroll
-                    for (int r = 0; r < 8; ++r) {
-                        float a = 0.0f;
-                        a = fmaf(w[64 + r * 4 + 0], hc.x, a);
-                        a = fmaf(w[64 + r * 4 + 1], hc.y, a);
-                        a = fmaf(w[64 + r * 4 + 2], hc.z, a);
-                        a = fmaf(w[64 + r * 4 + 3], hc.w, a);
-                        a = fmaf(w[96 + r * 4 + 0], hd.x, a);
-                        a = fmaf(w[96 + r * 4 + 1], hd.y, a);
-                        a = fmaf(w[96 + r * 4 + 2], hd.z, a);
-                        a = fmaf(w[96 + r * 4 + 3], hd.w, a);
-                        acc[r] = acc[r] + a;
-                    }
+                    for (int rp = 0; rp < 4; ++rp) a[rp] = splat2(0.0f);
+#pragma unroll
+                    for (int bc = 0; bc < 8; ++bc)
+#pragma unroll
+                        for (int rp = 0; rp < 4; ++rp) a[rp] = fma2(w2[32 + bc * 4 + rp], splat2(hv[bc]), a[rp]);
+#pragma unroll
+                    for (int rp = 0; rp < 4; ++rp) acc[rp] = acc[rp] + a[rp];
                 }
                 FPC_BARRIER()  // Z2
                 // ---- Z2..Z3: cross-lane tree (row-local DPP), diagonal, publish rec ----
@@ -255,9 +263,10 @@ __global__ __launch_bounds__(NTHREADS) void k_decode(const DecodeParams P) {
                     const int lq = (int)(metap & 0xff), lQ = (int)((metap >> 8) & 0xff);
 #define FPC_TREE_LEVEL(S)                                   \
     if (maxQ > S) {                                         \
-        _Pragma("unroll") for (int r = 0; r < 8; ++r) {     \
-            const float o = dpp_f<DPP_ROW_SHL + S>(acc[r]); \
-            if (lq + S < lQ) acc[r] = acc[r] + o;           \
+        _Pragma("unroll") for (int rp = 0; rp < 4; ++rp) {  \
+            const float ox = dpp_f<DPP_ROW_SHL + S>(acc[rp].x); \
+            const float oy = dpp_f<DPP_ROW_SHL + S>(acc[rp].y); \
+            if (lq + S < lQ) acc[rp] = acc[rp] + mk2(ox, oy);  \
         }                                                   \
     }
                     FPC_TREE_LEVEL(1)
@@ -274,14 +283,14 @@ __global__ __launch_bounds__(NTHREADS) void k_decode(const DecodeParams P) {
                         const float4 s0 = *reinterpret_cast<const float4*>(&L.s1[rb * 8]);
                         const float4 s4 = *reinterpret_cast<const float4*>(&L.s1[rb * 8 + 4]);
                         float4 o0, o1;
-                        o0.x = fmaf(d0.x, s0.x, acc[0]);
-                        o0.y = fmaf(d0.y, s0.y, acc[1]);
-                        o0.z = fmaf(d0.z, s0.z, acc[2]);
-                        o0.w = fmaf(d0.w, s0.w, acc[3]);
-                        o1.x = fmaf(d1.x, s4.x, acc[4]);
-                        o1.y = fmaf(d1.y, s4.y, acc[5]);
-                        o1.z = fmaf(d1.z, s4.z, acc[6]);
-                        o1.w = fmaf(d1.w, s4.w, acc[7]);
+                        o0.x = fmaf(d0.x, s0.x, acc[0].x);
+                        o0.y = fmaf(d0.y, s0.y, acc[0].y);
+                        o0.z = fmaf(d0.z, s0.z, acc[1].x);
+                        o0.w = fmaf(d0.w, s0.w, acc[1].y);
+                        o1.x = fmaf(d1.x, s4.x, acc[2].x);
+                        o1.y = fmaf(d1.y, s4.y, acc[2].y);
+                        o1.z = fmaf(d1.z, s4.z, acc[3].x);
+                        o1.w = fmaf(d1.w, s4.w, acc[3].y);
                         *reinterpret_cast<float4*>(&L.rec[row0]) = o0;
                         *reinterpret_cast<float4*>(&L.rec[row0 + 4]) = o1;
                     }
@@ -386,19 +395,16 @@ __global__ __launch_bounds__(NTHREADS) void k_decode(const DecodeParams P) {
                     float4 fw[9];
 #pragma unroll
                     for (int c = 0; c < 9; ++c) fw[c] = *reinterpret_cast<const float4*>(&L.fc[(c * NSAMP + slv) * 4]);
-                    float a0 = fw[8].x, a1 = fw[8].y;
+                    f2 a01 = mk2(fw[8].x, fw[8].y);  // both channels advance together
 #pragma unroll
                     for (int k4 = 0; k4 < 4; ++k4) {
                         const float4 sv = *reinterpret_cast<const float4*>(&L.s2[4 * k4]);
-                        a0 = fmaf(fw[k4].x, sv.x, a0);
-                        a1 = fmaf(fw[4 + k4].x, sv.x, a1);
-                        a0 = fmaf(fw[k4].y, sv.y, a0);
-                        a1 = fmaf(fw[4 + k4].y, sv.y, a1);
-                        a0 = fmaf(fw[k4].z, sv.z, a0);
-                        a1 = fmaf(fw[4 + k4].z, sv.z, a1);
-                        a0 = fmaf(fw[k4].w, sv.w, a0);
-                        a1 = fmaf(fw[4 + k4].w, sv.w, a1);
+                        a01 = fma2(mk2(fw[k4].x, fw[4 + k4].x), splat2(sv.x), a01);
+                        a01 = fma2(mk2(fw[k4].y, fw[4 + k4].y), splat2(sv.y), a01);
+                        a01 = fma2(mk2(fw[k4].z, fw[4 + k4].z), splat2(sv.z), a01);
+                        a01 = fma2(mk2(fw[k4].w, fw[4 + k4].w), splat2(sv.w), a01);
                     }
+                    const float a0 = a01.x, a1 = a01.y;
                     const float t0 = fpc_tanhf(a0), t1 = fpc_tanhf(a1);
                     const float v = fmaf(fw[8].w, t1, fw[8].z * t0);
                     L.q[slv] = fpc_sigmoidf(v);
@@ -445,13 +451,13 @@ __global__ __launch_bounds__(NTHREADS) void k_decode(const DecodeParams P) {
                     const float rthr = L.uframe[i] * S2;
                     const int lw = __popcll(__ballot(lane < 63 && I <= rthr));  // winning lane
                     const float Iprev = dpp_f<DPP_WAVE_SHR1>(I);
+                    const float O = lane > 0 ? Iprev : 0.0f;
+                    int cnt = ((O + c0) <= rthr) + ((O + c1) <= rthr) + ((O + c2) <= rthr) + ((O + c3) <= rthr);
+                    cnt = cnt > 3 ? 3 : cnt;
+                    // the winning lane's result, made wave-uniform
+                    const int exc = __builtin_amdgcn_readlane(4 * lane + cnt, lw);
+                    const int ce = L.cand_e[exc];
                     if (lane == lw) {
-                        const float O = lane > 0 ? Iprev : 0.0f;
-                        int cnt = ((O + c0) <= rthr) + ((O + c1) <= rthr) + ((O + c2) <= rthr) +
-                                  ((O + c3) <= rthr);
-                        cnt = cnt > 3 ? 3 : cnt;
-                        const int exc = 4 * lane + cnt;
-                        const int ce = L.cand_e[exc];
                         const float cpcm = L.cand_pcm[exc];
                         L.e_sig = ce & 0xff;
                         L.e_pred = ce >> 8;
