@@ -68,7 +68,7 @@ struct __attribute__((aligned(16))) DecodeLds {
     float s2[RNN_B];
     float hist[16];
     // control block written by the winning lane / the LPC chain lane
-    int e_sig, e_pred, e_exc, pad0;
+    unsigned o_sig, o_pred, o_exc, pad0;  // float offsets of the three table rows to gather next
     float pred, partial, a1n, mem;
 };
 
@@ -147,9 +147,9 @@ __global__ __launch_bounds__(NTHREADS) void k_decode(const DecodeParams P) {
         L.hist[tid] = 0.0f;
     }
     if (tid == 0) {
-        L.e_sig = 128;
-        L.e_pred = 128;
-        L.e_exc = 128;
+        L.o_sig = 128u * GA;
+        L.o_pred = (256u + 128u) * GA;
+        L.o_exc = (512u + 128u) * GA;
         L.pred = -0.0f;
         L.partial = 0.0f;
         L.a1n = 0.0f;
@@ -195,11 +195,15 @@ __global__ __launch_bounds__(NTHREADS) void k_decode(const DecodeParams P) {
                     struct F3 {
                         float x, y, z;
                     };
-                    unsigned ea = (unsigned)L.e_sig, eb = (unsigned)L.e_pred, ec = (unsigned)L.e_exc;
-                    if (STAMP && P.dbg_const_rows) ea = eb = ec = 128u;  // timing experiment (wrong output)
-                    const F3 ta = *reinterpret_cast<const F3*>(P.tab + (ea * GA + 3u * ml));
-                    const F3 tb = *reinterpret_cast<const F3*>(P.tab + ((256u + eb) * GA + 3u * ml));
-                    const F3 tc = *reinterpret_cast<const F3*>(P.tab + ((512u + ec) * GA + 3u * ml));
+                    unsigned oa = L.o_sig, ob = L.o_pred, oc = L.o_exc;
+                    if (STAMP && P.dbg_const_rows) {  // timing experiment (wrong output)
+                        oa = 128u * GA;
+                        ob = 384u * GA;
+                        oc = 640u * GA;
+                    }
+                    const F3 ta = *reinterpret_cast<const F3*>(P.tab + (oa + 3u * ml));
+                    const F3 tb = *reinterpret_cast<const F3*>(P.tab + (ob + 3u * ml));
+                    const F3 tc = *reinterpret_cast<const F3*>(P.tab + (oc + 3u * ml));
                     const float uz = L.rec[ml], ur = L.rec[RNN_A + ml], un = L.rec[2 * RNN_A + ml];
                     const float cz = L.cfa[ml], cr = L.cfa[RNN_A + ml], cn = L.cfa[2 * RNN_A + ml];
                     const float brn = L.brn_a[ml];
@@ -459,9 +463,10 @@ __global__ __launch_bounds__(NTHREADS) void k_decode(const DecodeParams P) {
                     const int ce = L.cand_e[exc];
                     if (lane == lw) {
                         const float cpcm = L.cand_pcm[exc];
-                        L.e_sig = ce & 0xff;
-                        L.e_pred = ce >> 8;
-                        L.e_exc = exc;
+                        const unsigned es = (unsigned)(ce & 0xff), ep = 256u + (unsigned)(ce >> 8), ee = 512u + (unsigned)exc;
+                        L.o_sig = (es << 10) + (es << 7);  // x GA (1152 = 1024 + 128)
+                        L.o_pred = (ep << 10) + (ep << 7);
+                        L.o_exc = (ee << 10) + (ee << 7);
                         L.pred = L.cand_pred[exc];
                         L.hist[t & 15] = cpcm;
                         const float mem = fmaf(FPC_PREEMPH, L.mem, cpcm);
