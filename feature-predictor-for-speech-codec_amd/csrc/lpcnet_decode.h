@@ -10,11 +10,11 @@
 //        M: gather 3 table rows, gates -> s1'
 //        S: GRU_B recurrent part, LPC history chain, per-leaf candidates of this sample
 //   Y  s1' ready
-//        S: GRU_B -> s2'                           M: sparse product, leaf 0
+//        S: GRU_B -> s2'                           M: sparse product (both leaves), DPP tree
 //   Z1 s2' ready
-//        S: dual FC -> 255 node probabilities      M: sparse product, leaf 1
+//        S: dual FC -> 255 node probabilities      M: diagonal term, rec -> LDS
 //   Z2 q ready
-//        S: leaf probabilities                     M: DPP tree, diagonal, rec -> LDS
+//        S: leaf probabilities                     M: -
 //   Z3 pdf ready
 //        S wave 0: normaliser, tail cut, scan, draw, control block
 // The sparse product (61 % of the algorithmic FLOPs) never sits on the sample-to-sample
@@ -241,9 +241,7 @@ __global__ __launch_bounds__(NTHREADS) void k_decode(const DecodeParams P) {
 #pragma unroll
                         for (int rp = 0; rp < 4; ++rp) acc[rp] = fma2(w2[bc * 4 + rp], splat2(hv[bc]), acc[rp]);
                 }
-                FPC_BARRIER()  // Z1
-                // ---- Z1..Z2: leaf 1, first (in-lane) tree level ----
-                st_phase = 2;
+                // leaf 1, first (in-lane) tree level
                 {
                     const unsigned colp = opaque(colp_);
                     const float4 hc = *reinterpret_cast<const float4*>(&L.s1[((colp >> 16) & 0xff) * 4]);
@@ -259,11 +257,9 @@ __global__ __launch_bounds__(NTHREADS) void k_decode(const DecodeParams P) {
 #pragma unroll
                     for (int rp = 0; rp < 4; ++rp) acc[rp] = acc[rp] + a[rp];
                 }
-                FPC_BARRIER()  // Z2
-                // ---- Z2..Z3: cross-lane tree (row-local DPP), diagonal, publish rec ----
-                st_phase = 3;
+                // cross-lane tree (row-local DPP)
+                const unsigned metap = opaque(metap_);
                 {
-                    const unsigned metap = opaque(metap_);
                     const int lq = (int)(metap & 0xff), lQ = (int)((metap >> 8) & 0xff);
 #define FPC_TREE_LEVEL(S)                                   \
     if (maxQ > S) {                                         \
@@ -278,6 +274,12 @@ __global__ __launch_bounds__(NTHREADS) void k_decode(const DecodeParams P) {
                     FPC_TREE_LEVEL(4)
                     FPC_TREE_LEVEL(8)
 #undef FPC_TREE_LEVEL
+                }
+                FPC_BARRIER()  // Z1
+                // ---- Z1..Z2: diagonal term, publish rec ----
+                st_phase = 2;
+                {
+                    const int lq = (int)(metap & 0xff);
                     if ((metap >> 16) != 0 && lq == 0) {
                         const int grp = (int)(metap >> 16) - 1;
                         const int gate = grp / (RNN_A / 8), rb = grp - gate * (RNN_A / 8);
@@ -299,6 +301,8 @@ __global__ __launch_bounds__(NTHREADS) void k_decode(const DecodeParams P) {
                         *reinterpret_cast<float4*>(&L.rec[row0 + 4]) = o1;
                     }
                 }
+                FPC_BARRIER()  // Z2
+                st_phase = 3;
                 FPC_BARRIER()  // Z3
                 st_phase = 4;
                 FPC_BARRIER()  // X
