@@ -118,6 +118,13 @@ def main():
     dec_s = float(np.mean(dec_ms)) / 1e3
     dec_rate = samples_step / dec_s  # per GPU, decode kernel only
 
+    traffic = None  # HBM bytes per k_decode launch from the committed PMC passes (same workload only)
+    try:
+        tj = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
+        if B == 256 and T == 300:
+            traffic = tj["hbm_bytes_per_launch"]
+    except Exception:
+        pass
     out = {
         "metric": "LPCNet synthesis samples/sec (16 kHz RTF) per GPU; 1/2/4/8-GPU throughput",
         "value": value, "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -132,7 +139,8 @@ def main():
             "bound": "mfma", "note": "f32 VALU sparse mat-vec; f32 vector peak == f32 MFMA dense peak (157.3 TF)",
             "kernel": "k_decode", "achieved": dec_rate * FLOP_PER_SAMPLE / 1e12, "peak": PEAK_F32_TFLOPS,
             "unit": "TFLOP/s", "frac": dec_rate * FLOP_PER_SAMPLE / 1e12 / PEAK_F32_TFLOPS,
-            "traffic": None, "launch_ms": dec_s * 1e3,
+            "traffic": traffic, "traffic_unit": "bytes/launch (rocprofv3 PMC FETCH_SIZE+WRITE_SIZE, profiles/r01_traffic.json)",
+            "launch_ms": dec_s * 1e3,
             "hbm": {"achieved": dec_rate * HBM_BYTES_PER_SAMPLE / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                     "frac": dec_rate * HBM_BYTES_PER_SAMPLE / 1e9 / PEAK_HBM_GBS},
         },
