@@ -181,6 +181,8 @@ __global__ __launch_bounds__(NTHREADS) void k_decode(const DecodeParams P) {
         const bool gate_lane = ml_ < RNN_A;
 
         for (int fr = 0; fr < T; ++fr) {
+            // voiced frames (pdf sharpening on) keep a separate parallel leaf phase: one more barrier
+            const bool voiced = fpc_shape_exponent(P.features[((size_t)b * T + fr) * FPC_NB_FEATURES + 19]) > 0.0f;
             if (gate_lane) {  // this frame's conditioning values of unit ml: written and read by the same lane
                 const float* cfa = P.cfa + ((size_t)b * T + fr) * GA;
                 L.cfa[ml_] = cfa[ml_];
@@ -303,7 +305,9 @@ __global__ __launch_bounds__(NTHREADS) void k_decode(const DecodeParams P) {
                 }
                 FPC_BARRIER()  // Z2
                 st_phase = 3;
-                FPC_BARRIER()  // Z3
+                if (voiced) {
+                    FPC_BARRIER()  // Z3 (voiced frames only)
+                }
                 st_phase = 4;
                 FPC_BARRIER()  // X
             }
@@ -418,24 +422,44 @@ __global__ __launch_bounds__(NTHREADS) void k_decode(const DecodeParams P) {
                     L.q[slv] = fpc_sigmoidf(v);
                 }
                 FPC_BARRIER()  // Z2
-                // ---- Z2..Z3: leaf probability, MSB first ----
-                st_phase = 3;
-                {
-                    const unsigned slv = opaque((unsigned)sl);
-                    float p = 1.0f;
+                float4 p4;  // wave 0: probabilities of leaves 4*lane .. 4*lane+3
+                if (shape_e > 0.0f) {
+                    // ---- voiced frame, Z2..Z3: leaf probability (MSB first) + sharpening, 256 lanes ----
+                    st_phase = 3;
+                    {
+                        const unsigned slv = opaque((unsigned)sl);
+                        float p = 1.0f;
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        const float qq = L.q[(1u << j) + (slv >> (8 - j))];
-                        p = p * (((slv >> (7 - j)) & 1u) ? qq : 1.0f - qq);
+                        for (int j = 0; j < 8; ++j) {
+                            const float qq = L.q[(1u << j) + (slv >> (8 - j))];
+                            p = p * (((slv >> (7 - j)) & 1u) ? qq : 1.0f - qq);
+                        }
+                        L.p[slv] = fpc_shape_pow(p, shape_e);
                     }
-                    if (shape_e > 0.0f) p = fpc_shape_pow(p, shape_e);
-                    L.p[slv] = p;
+                    FPC_BARRIER()  // Z3
+                    st_phase = 4;
+                    if (wave == 0) p4 = *reinterpret_cast<const float4*>(&L.p[4 * lane]);
+                } else if (wave == 0) {
+                    // ---- unvoiced frame: the drawing wave builds its 4 leaves per lane straight from
+                    //      q (same MSB-first product per leaf); no separate leaf phase, no barrier ----
+                    st_phase = 4;
+                    const unsigned lv = opaque((unsigned)lane);
+                    float pre = 1.0f;
+#pragma unroll
+                    for (int j = 0; j < 6; ++j) {
+                        const float qq = L.q[(1u << j) + (lv >> (6 - j))];
+                        pre = pre * (((lv >> (5 - j)) & 1u) ? qq : 1.0f - qq);
+                    }
+                    const float q6 = L.q[64u + lv];
+                    const float2 q7 = *reinterpret_cast<const float2*>(&L.q[128u + 2u * lv]);
+                    const float lo = pre * (1.0f - q6), hi = pre * q6;
+                    p4.x = lo * (1.0f - q7.x);
+                    p4.y = lo * q7.x;
+                    p4.z = hi * (1.0f - q7.y);
+                    p4.w = hi * q7.y;
                 }
-                FPC_BARRIER()  // Z3
-                // ---- Z3..X (wave 0): normaliser, tail cut, scan, draw, publish ----
-                st_phase = 4;
+                // ---- (wave 0): normaliser, tail cut, scan, draw, publish ----
                 if (wave == 0) {
-                    const float4 p4 = *reinterpret_cast<const float4*>(&L.p[4 * lane]);
                     const float rs = row_bfly16((p4.x + p4.y) + (p4.z + p4.w));
                     const float S1 = (lane_val(rs, 0) + lane_val(rs, 16)) + (lane_val(rs, 32) + lane_val(rs, 48));
                     const float thr = 0.002f * S1;
