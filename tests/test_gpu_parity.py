@@ -206,3 +206,83 @@ def test_lpcnet_batch_invariance(torch_cuda, vocoder, synth, oracle):
     perm = np.array([4, 2, 0, 1, 3])
     p2 = voc.synthesize(f[perm], sd[perm]).cpu().numpy()
     assert np.array_equal(p2, full[perm])
+
+
+def test_synthesis_qtz_harness_vs_reference_golden(torch_cuda, synth, golden, cb_paths, tmp_path, monkeypatch):
+    """rows a9/a10: the synthesis_qtz.py driver (checkpoint file -> encoder -> x24.1 -> ceps2lpc ->
+    36-float frames, src/synthesis_qtz.py:67-166) against the reference's own output (G2+G4)."""
+    torch = torch_cuda
+    from fpcodec_amd.config import default_cfg
+    from fpcodec_amd.synthesis_qtz import synthesis
+    label, epoch = "0722_001326", 4000  # README.md:44
+    src = tmp_path / "src"
+    (tmp_path / "saved_models" / label).mkdir(parents=True)
+    src.mkdir()
+    sd = {k: torch.from_numpy(v) for k, v in synth.predictor_state_dict().items()}
+    torch.save(sd, tmp_path / "saved_models" / label / f"{label}_{epoch}.pth")  # src/utils.py:134,146
+    monkeypatch.chdir(src)  # the reference runs with src/ as cwd (relative ../saved_models, ../samples)
+    cfg = default_cfg()
+    cfg.update(model_label_f=label, epoch_f=epoch, gru_units1=384, gru_units2=128, fc_units=18, l1=0.09, l2=0.28,
+               qtz=True, note="t", total_secs=3, scl_cb_path=cb_paths["scl_hi"], cb_path=cb_paths["vq_hi"],
+               bl_scl_cb_path=cb_paths["scl_lo"], bl_cb_path=cb_paths["vq_lo"])
+    nm = np.zeros((1, 300, 36), np.float32)
+    nm[:, :, :20] = synth.predictor_features(1, 300)
+    out = synthesis(cfg, utterances=[("1272-128104-0001", torch.from_numpy(nm))])
+    name, feats, r = out[0]
+    g4, g2 = golden("g4_ceps2lpc"), golden("g2_encoder")
+    assert feats.shape == (1, 300, 36)
+    assert np.abs(feats.cpu().numpy()[..., :20] - g4["feats36"][..., :20]).max() < 1e-4  # 24.1 x 1e-5
+    assert np.abs(feats.cpu().numpy()[..., 20:] - g4["feats36"][..., 20:]).max() < 2e-4
+    assert np.abs(r.cpu().numpy() - g2["full_1x300_r"]).max() < 1e-5
+    saved = np.load(tmp_path / "samples" / label / "1272-128104-0001_r_t.npy")  # synthesis_qtz.py:166 naming
+    assert saved.shape == (1, 300, 18)
+
+
+def test_end_to_end_config5_pipeline_and_bitrate(torch_cuda, model, vocoder, synth, oracle, cb_paths):
+    """BASELINE config 5 in miniature: encode + VQ -> ceps2lpc -> LPCNet decode, GPU vs the oracle
+    pipeline bit for bit, and the bitrate figure from the codebook-usage entropies."""
+    torch = torch_cuda
+    from fpcodec_amd.synthesis_qtz import encode_features
+    from fpcodec_amd.vq_func import cal_entropy
+    voc, w = vocoder
+    B, L = 3, 40
+    nm = np.zeros((B, L, 36), np.float32)
+    nm[:, :, :20] = synth.predictor_features(B, L, utt0=300)
+    cfg = dict(scl_cb_path=cb_paths["scl_hi"], cb_path=cb_paths["vq_hi"], bl_scl_cb_path=cb_paths["scl_lo"],
+               bl_cb_path=cb_paths["vq_lo"], l1=0.09, l2=0.28, qtz=True)
+    feats, r, ind1, ind2, cb_tot = encode_features(model, cfg, torch.from_numpy(nm))
+    sd = synth.seeds(B, utt0=300)
+    pcm = voc.synthesize(feats, sd).cpu().numpy()
+    # oracle pipeline
+    c = synth.codebooks()
+    CB = oracle.Codebooks(c["vq_hi"], c["scl_hi"], c["vq_lo"], c["scl_lo"])
+    o = oracle.Predictor(synth.predictor_state_dict()).encode(nm[:, :, :20], CB, 0.09, 0.28, True)
+    cin = o["c_in"] * np.float32(synth.MAXI)
+    lpc = oracle.ceps2lpc(cin.reshape(-1, 20))[0].reshape(B, L, 16)
+    f36 = np.concatenate([cin, lpc], -1)
+    assert np.array_equal(feats.cpu().numpy(), f36)
+    orc = oracle.LPCNet(w)
+    for b in range(B):
+        assert np.array_equal(pcm[b], orc.synthesize(f36[b], int(sd[b])))
+    # bits per frame = flag bits + sum over used codebooks of usage-weighted entropy (generate_qtz_features.py:94-101,202)
+    hs = CB.split_hist(o["hist"])
+    for i in range(5):
+        assert np.array_equal(np.atleast_1d(cb_tot[i]), hs[i])
+    ent = [cal_entropy(h) if np.sum(h) > 0 else 0.0 for h in cb_tot]
+    n = B * L
+    bits = sum(e * np.sum(h) for e, h in zip(ent, cb_tot)) / n
+    assert 5.0 < bits < 30.0  # scalar (<=8) + 2-stage VQ (<=20) weighted by keep-rates, + below-threshold books
+
+
+def test_lpcnet_cli_three_args(torch_cuda, vocoder, synth, oracle, tmp_path):
+    """`test_lpcnet.py [model] [features] [out]` surface (README.md:47): raw f32 in, raw int16 out"""
+    from fpcodec_amd import lpcnet as L
+    voc, w = vocoder
+    voc.save(str(tmp_path / "model.npz"))
+    f = _voc_features(synth, oracle, 1, 4)[0]
+    f.astype("<f4").tofile(tmp_path / "feat.f32")
+    assert L.main([str(tmp_path / "model.npz"), str(tmp_path / "feat.f32"), str(tmp_path / "out.pcm")]) == 0
+    pcm = np.fromfile(tmp_path / "out.pcm", dtype="<i2")
+    ref = oracle.LPCNet(w).synthesize(f, 0)
+    assert pcm.size == 4 * 160 - 17 and np.array_equal(pcm, ref[17:])
+    assert L.main(["only", "two"]) == 2
