@@ -52,6 +52,8 @@ struct DecodeParams {
     int dbg_const_rows;          // diagnostic only (STAMP build): gather fixed table rows
 };
 
+__device__ const float k_ulaw_thr[64] = FPC_ULAW_TABLE_INIT;
+
 struct __attribute__((aligned(16))) DecodeLds {
     float s1[RNN_A];
     float rec[GA];
@@ -65,6 +67,7 @@ struct __attribute__((aligned(16))) DecodeLds {
     float cand_pcm[256];
     float cand_pred[256];
     int cand_e[256];  // e_sig | e_pred << 8
+    float ulaw_thr[64];  // fpc_lin2ulaw_tab table
     float s2[RNN_B];
     float hist[16];
     // control block written by the winning lane / the LPC chain lane
@@ -142,6 +145,7 @@ __global__ __launch_bounds__(NTHREADS) void k_decode(const DecodeParams P) {
 #pragma unroll
         for (int j = 0; j < 36; ++j) L.fc[((j >> 2) * NSAMP + tid) * 4 + (j & 3)] = P.lane_fc[j * NSAMP + tid];
     }
+    if (tid < 64) L.ulaw_thr[tid] = k_ulaw_thr[tid];
     if (tid < RNN_B) {
         L.s2[tid] = 0.0f;
         L.hist[tid] = 0.0f;
@@ -263,13 +267,14 @@ __global__ __launch_bounds__(NTHREADS) void k_decode(const DecodeParams P) {
                 const unsigned metap = opaque(metap_);
                 {
                     const int lq = (int)(metap & 0xff), lQ = (int)((metap >> 8) & 0xff);
-#define FPC_TREE_LEVEL(S)                                   \
-    if (maxQ > S) {                                         \
-        _Pragma("unroll") for (int rp = 0; rp < 4; ++rp) {  \
-            const float ox = dpp_f<DPP_ROW_SHL + S>(acc[rp].x); \
-            const float oy = dpp_f<DPP_ROW_SHL + S>(acc[rp].y); \
-            if (lq + S < lQ) acc[rp] = acc[rp] + mk2(ox, oy);  \
-        }                                                   \
+    // acc += take ? neighbour : 0, as fma(neighbour, 1.0|0.0, acc): exact, one v_fmac_f32_dpp per row
+#define FPC_TREE_LEVEL(S)                                                  \
+    if (maxQ > S) {                                                        \
+        const float take = (lq + S < lQ) ? 1.0f : 0.0f;                    \
+        _Pragma("unroll") for (int rp = 0; rp < 4; ++rp) {                 \
+            acc[rp].x = fmaf(dpp_f<DPP_ROW_SHL + S>(acc[rp].x), take, acc[rp].x); \
+            acc[rp].y = fmaf(dpp_f<DPP_ROW_SHL + S>(acc[rp].y), take, acc[rp].y); \
+        }                                                                  \
     }
                     FPC_TREE_LEVEL(1)
                     FPC_TREE_LEVEL(2)
@@ -360,7 +365,7 @@ __global__ __launch_bounds__(NTHREADS) void k_decode(const DecodeParams P) {
                     const float cpred = -fmaf(a[0], cpcm, part);
                     L.cand_pcm[sl] = cpcm;
                     L.cand_pred[sl] = cpred;
-                    L.cand_e[sl] = fpc_lin2ulaw(cpcm) | (fpc_lin2ulaw(cpred) << 8);
+                    L.cand_e[sl] = fpc_lin2ulaw_tab(cpcm, L.ulaw_thr) | (fpc_lin2ulaw_tab(cpred, L.ulaw_thr) << 8);
                 }
                 FPC_BARRIER()  // Y
                 // ---- Y..Z1: GRU_B (row of 16 lanes = unit, lane = 4 leaves of 6 inputs) ----

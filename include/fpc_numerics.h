@@ -48,6 +48,15 @@ FPC_HD uint32_t fpc_f2u(float f) {
     return u;
 }
 
+/* clamp to [lo,hi] (one v_med3_f32 on gfx950; identical result for non-NaN x) */
+FPC_HD float fpc_clampf(float x, float lo, float hi) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_fmed3f(x, lo, hi);
+#else
+    return fminf(fmaxf(x, lo), hi);
+#endif
+}
+
 /* reciprocal of a positive normal float by integer-seeded Newton iteration: only IEEE
  * mul/fma, so it is bit-reproducible on CPU and GPU, and its dependency chain (7 ops) runs
  * beside the numerator polynomial of the caller.  |rel err| < 1.5e-7 for q in [1e-3, 1e3]. */
@@ -63,9 +72,7 @@ FPC_HD float fpc_recipf(float q) {
  * float32 tanh, with the final quotient taken as p * fpc_recipf(q);
  * |err| < 5e-7 absolute over the whole range. */
 FPC_HD float fpc_tanhf(float x) {
-    const float lim = 7.90531110763549805f;
-    x = x > lim ? lim : x;
-    x = x < -lim ? -lim : x;
+    x = fpc_clampf(x, -7.90531110763549805f, 7.90531110763549805f);
     const float x2 = x * x;
     float q = fmaf(x2, 1.19825839466702e-06f, 1.18534705686654e-04f);
     q = fmaf(x2, q, 2.26843463243900e-03f);
@@ -89,8 +96,7 @@ FPC_HD float fpc_sigmoidf(float x) {
 /* exp: Cephes-style range reduction + degree-5 polynomial, result scaled by
  * integer exponent insertion.  Relative error < 2e-7 on [-87, 88]. */
 FPC_HD float fpc_expf(float x) {
-    x = x > 88.0f ? 88.0f : x;
-    x = x < -87.0f ? -87.0f : x;
+    x = fpc_clampf(x, -87.0f, 88.0f);
     const float n = rintf(x * 1.44269504088896341f);
     float r = fmaf(n, -0.693359375f, x);
     r = fmaf(n, 2.12194440e-4f, r);
@@ -142,18 +148,34 @@ FPC_HD float fpc_exp10f(float x) {
     return fpc_expf(x * 2.30258509299404568f);
 }
 
-/* mu-law companding, LPCNet ulaw.py semantics: formula of src/utils.py:19-24
- * followed by round-half-even and clip to [0,255]. */
-FPC_HD int fpc_lin2ulaw(float x) {
-    const float a = fabsf(x);
-    const float l = fpc_logf(fmaf(255.0f / 32768.0f, a, 1.0f));
-    float u = rintf(l * 23.0831206542234f); /* 128/ln(256) */
-    u = x < 0.0f ? -u : u;
-    u = 128.0f + u;
-    u = u < 0.0f ? 0.0f : u;
-    u = u > 255.0f ? 255.0f : u;
-    return (int)u;
+/* mu-law companding, LPCNet ulaw.py semantics: u = 128 + sign(x)*round(128*ln(1+255|x|/32768)/ln256)
+ * (formula of src/utils.py:19-24 + round, clip to [0,255]) evaluated WITHOUT a logarithm: with
+ * v = fl(1 + 255|x|/32768) the rounded value is K = #{k in 1..128 : v >= 2^((k-.5)/16)}, i.e.
+ * 16*exponent(v) plus the number of the 16 per-octave thresholds c_i = 2^((i-.5)/16) that the
+ * mantissa reaches.  The 32-bin table (top 5 mantissa bits) holds, per bin, the one threshold that
+ * can fall inside it (4.0 = none) and the count of thresholds below the bin. */
+#define FPC_ULAW_TABLE_INIT                                                                             \
+    {1.0218972f, 0.f, 4.0f, 1.f, 1.0671405f, 1.f, 1.1143868f, 2.f, 4.0f, 3.f, 1.1637249f, 3.f,          \
+     1.2152474f, 4.f, 4.0f, 5.f, 1.269051f, 5.f,  4.0f, 6.f, 1.3252367f, 6.f, 4.0f, 7.f,                \
+     1.38391f, 7.f,   4.0f, 8.f, 1.4451808f, 8.f, 4.0f, 9.f, 1.5091645f, 9.f, 4.0f, 10.f,               \
+     1.5759809f, 10.f, 4.0f, 11.f, 1.6457555f, 11.f, 4.0f, 12.f, 1.7186193f, 12.f, 4.0f, 13.f,          \
+     4.0f, 13.f, 1.7947091f, 13.f, 4.0f, 14.f, 1.8741677f, 14.f, 4.0f, 15.f, 4.0f, 15.f,                \
+     1.9571441f, 15.f, 4.0f, 16.f}
+FPC_HD int fpc_lin2ulaw_tab(float x, const float* tab /* [32][2]: threshold, count below */) {
+    const float v = fmaf(255.0f / 32768.0f, fabsf(x), 1.0f);
+    const uint32_t iv = fpc_f2u(v);
+    const int e = (int)(iv >> 23) - 127;
+    const uint32_t bin = (iv >> 18) & 31u;
+    const float m = fpc_u2f((iv & 0x007fffffu) | 0x3f800000u); /* [1,2) */
+    int K = 16 * e + (int)tab[2 * bin + 1] + (m >= tab[2 * bin] ? 1 : 0);
+    K = K > 128 ? 128 : K;
+    const int u = x < 0.0f ? 128 - K : 128 + K;
+    return u > 255 ? 255 : u;
 }
+#if !defined(__HIP_DEVICE_COMPILE__)
+static const float fpc_ulaw_table_host[64] = FPC_ULAW_TABLE_INIT;
+static inline int fpc_lin2ulaw(float x) { return fpc_lin2ulaw_tab(x, fpc_ulaw_table_host); }
+#endif
 
 /* inverse mu-law (src/utils.py:26-31); the vocoder uses the 256-entry table
  * produced by this function, never the function itself in the sample loop. */
