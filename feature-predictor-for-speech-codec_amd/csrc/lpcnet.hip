@@ -10,7 +10,7 @@
 //
 // Kernels
 //   k_embed_tables   one-off: embed_sig x GRU_A input kernel -> three [256][1152] tables
-//   k_frame_dense    frame-rate layers (conv k=3 / dense) as k-ordered fmaf chains
+//   k_frame_mfma     frame-rate layers (conv k=3 / dense) on f32 MFMA (k-ordered fmaf chains)
 //   k_decode         persistent per-utterance sample loop: one 1024-thread workgroup
 //                    (16 wave64) per utterance; sparse GRU_A / GRU_B weights live in
 //                    VGPRs for the whole utterance, recurrent state and the dual-FC
@@ -21,11 +21,10 @@
 
 namespace {
 
-constexpr int RNN_A = 384, RNN_B = 16, COND = 128, EMB = 128;
+constexpr int RNN_A = 384, RNN_B = 16, EMB = 128;
 constexpr int GA = 3 * RNN_A;  // 1152
 constexpr int GB = 3 * RNN_B;  // 48
 constexpr int NROWGRP = GA / 8;  // 144 groups of 8 gate rows
-constexpr int FC_STRIDE = 20;    // floats per (node,channel): 16 weights, bias, factor, pad
 
 // ---------------------------------------------------------------------------------
 // one-off table build: tab[s][e][row] = sum_k embed_sig[e][k] * ga_k[s*128+k][row]
@@ -46,47 +45,77 @@ __global__ void k_embed_tables(const float* __restrict__ embed, const float* __r
 }
 
 // ---------------------------------------------------------------------------------
-// frame-rate layers.  y[f][o] = act(bias[o] + sum_k x_f[k] W[k][o]) as a k-ordered
-// fmaf chain (the order a gfx950 f32 MFMA accumulates in, so an MFMA version stays
-// bit-identical).  MODE 0: x_f = x[f][0..K)   MODE 1: 'same' conv, K = 3*C,
-// x_f[tap*C+c] = x[f+tap-1][c] with zero rows outside the utterance.
-// MODE 2: first layer input built on the fly from the 36-float feature frame:
-//         20 features | 64-dim pitch embedding (conv, C = 84).
+// frame-rate layers on the matrix cores.  y[f][o] = act(bias[o] + sum_k x_f[k] W[k][o]);
+// v_mfma_f32_16x16x4_f32 accumulates D = A.B + C as a k-ordered fmaf chain starting from C, so
+// with C = bias and k ascending the result is bit-identical to the canonical chain of the CPU
+// oracle (dense_chain in oracle/fpc_oracle.c).  A = 16 frames x 4 k (from an LDS-staged tile of
+// one utterance), B = 4 k x 16 outputs (weights straight from L2), 2 output tiles per wave.
+//   MODE 0: x_f = x[f][0..K)                     (dense, K == C)
+//   MODE 1: 'same' k=3 conv, K = 3*C, x_f[tap*C+c] = x[f+tap-1][c], zero rows outside the utterance
+//   MODE 2: like 1 with the input row built on the fly from the 36-float feature frame:
+//           20 features | 64-dim pitch embedding (C = 84)
+// block = 256 threads = 4 waves = 16 frames x 128 outputs; grid = (B * ceil(T/16), ceil(N/128)).
 // ---------------------------------------------------------------------------------
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
 template <int MODE>
-__global__ void k_frame_dense(const float* __restrict__ x, int ldx, int C, int K,
-                              const float* __restrict__ W, const float* __restrict__ bias, int N,
-                              float* __restrict__ y, int T, int do_tanh,
-                              const float* __restrict__ embed_pitch) {
-    extern __shared__ __attribute__((aligned(16))) float xs[];
-    const int f = blockIdx.x;  // frame index over B*T
-    const int t = f % T;
-    for (int k = threadIdx.x; k < K; k += blockDim.x) {
-        float v;
-        if (MODE == 0) {
-            v = x[(size_t)f * ldx + k];
-        } else {
-            const int tap = k / C, c = k - tap * C;
-            const int tt = t + tap - 1;
-            if (tt < 0 || tt >= T) {
-                v = 0.0f;
-            } else if (MODE == 1) {
-                v = x[(size_t)(f + tap - 1) * ldx + c];
-            } else {
-                const float* fr = x + (size_t)(f + tap - 1) * FPC_NB_FEATURES;
+__global__ __launch_bounds__(256) void k_frame_mfma(const float* __restrict__ x, int ldx, int C, int K,
+                                                    const float* __restrict__ W,
+                                                    const float* __restrict__ bias, int N,
+                                                    float* __restrict__ y, int T, int do_tanh,
+                                                    const float* __restrict__ embed_pitch) {
+    extern __shared__ __attribute__((aligned(16))) float xs[];  // [18][Cs]
+    const int Cs = ((C + 29) / 32) * 32 + 2;                    // row stride = 2 mod 32: conflict-free A reads
+    const int tiles = (T + 15) / 16;
+    const int b = blockIdx.x / tiles, t0 = (blockIdx.x % tiles) * 16;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    // ---- stage rows t0-1 .. t0+16 of this utterance (zeros outside [0,T)) ----
+    const int nrows = MODE == 0 ? 16 : 18, roff = MODE == 0 ? 0 : -1;
+    for (int e = tid; e < nrows * C; e += 256) {
+        const int rr = e / C, c = e - rr * C;
+        const int tt = t0 + rr + roff;
+        float v = 0.0f;
+        if (tt >= 0 && tt < T) {
+            const size_t f = (size_t)b * T + tt;
+            if (MODE == 2) {
+                const float* fr = x + f * FPC_NB_FEATURES;
                 v = c < FPC_NB_USED_FEATURES
                         ? fr[c]
                         : embed_pitch[fpc_period_index(fr[18]) * 64 + (c - FPC_NB_USED_FEATURES)];
+            } else {
+                v = x[f * ldx + c];
             }
         }
-        xs[k] = v;
+        xs[rr * Cs + c] = v;
     }
     __syncthreads();
-    for (int o = blockIdx.y * blockDim.x + threadIdx.x; o < N; o += gridDim.y * blockDim.x) {
-        float acc = bias[o];
-#pragma unroll 4
-        for (int k = 0; k < K; ++k) acc = fmaf(xs[k], W[(size_t)k * N + o], acc);
-        y[(size_t)f * N + o] = do_tanh ? fpc_tanhf(acc) : acc;
+    // ---- two 16x16 output tiles per wave ----
+    const int n0 = blockIdx.y * 128 + wave * 32;
+    if (n0 >= N) return;  // (wave-uniform) nothing to do for this wave
+    const int fi = lane & 15, kq = lane >> 4;
+    const int col0 = n0 + fi, col1 = n0 + 16 + fi;
+    const bool has1 = n0 + 16 < N;
+    const float b0 = bias[col0], b1 = has1 ? bias[col1] : 0.0f;
+    f32x4 acc0 = {b0, b0, b0, b0}, acc1 = {b1, b1, b1, b1};
+    const int c1 = has1 ? col1 : col0;
+    for (int k0 = 0; k0 < K; k0 += 4) {
+        const int tap = MODE == 0 ? 0 : k0 / C;  // C % 4 == 0: the 4 k's of a step share a tap
+        const int cc = k0 - tap * C;
+        const float a = xs[(fi + tap) * Cs + cc + kq];
+        const float w0 = W[(size_t)(k0 + kq) * N + col0];
+        const float w1 = W[(size_t)(k0 + kq) * N + c1];
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, w0, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, w1, acc1, 0, 0, 0);
+    }
+    // C/D layout: col = lane & 15, row = (lane >> 4) * 4 + reg
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int tt = t0 + kq * 4 + r;
+        if (tt < T) {
+            const size_t f = (size_t)b * T + tt;
+            y[f * N + col0] = do_tanh ? fpc_tanhf(acc0[r]) : acc0[r];
+            if (has1) y[f * N + col1] = do_tanh ? fpc_tanhf(acc1[r]) : acc1[r];
+        }
     }
 }
 
@@ -303,24 +332,25 @@ CondBufs carve(void* ws, int B, int T) {
     return c;
 }
 
+template <int MODE>
+void launch_frame(const float* x, int ldx, int C, int K, const float* W, const float* bias, int N, float* y,
+                  int B, int T, int do_tanh, const float* embed_pitch, hipStream_t st) {
+    const int Cs = ((C + 29) / 32) * 32 + 2;
+    const dim3 grid(B * ((T + 15) / 16), (N + 127) / 128);
+    hipLaunchKernelGGL(k_frame_mfma<MODE>, grid, dim3(256), (size_t)18 * Cs * sizeof(float), st, x, ldx, C, K, W,
+                       bias, N, y, T, do_tanh, embed_pitch);
+}
+
 int run_condition(fpc_lpcnet* m, const float* feat, int B, int T, const CondBufs& c, float* cfeat,
                   hipStream_t st) {
-    const int F = B * T;
-    // conv1 (84 ch, built on the fly from the feature frame) -> x1
-    hipLaunchKernelGGL(k_frame_dense<2>, dim3(F, 1), dim3(128), 3 * 84 * 4, st, feat, 0, 84, 3 * 84,
-                       m->conv1_k.as<float>(), m->conv1_b.as<float>(), 128, c.x1, T, 1,
-                       m->embed_pitch.as<float>());
-    // conv2 -> x2
-    hipLaunchKernelGGL(k_frame_dense<1>, dim3(F, 1), dim3(128), 3 * 128 * 4, st, c.x1, 128, 128,
-                       3 * 128, m->conv2_k.as<float>(), m->conv2_b.as<float>(), 128, c.x2, T, 1,
-                       (const float*)nullptr);
-    // dense1 -> x3, dense2 -> cfeat
-    hipLaunchKernelGGL(k_frame_dense<0>, dim3(F, 1), dim3(128), 128 * 4, st, c.x2, 128, 128, 128,
-                       m->d1_k.as<float>(), m->d1_b.as<float>(), 128, c.x3, T, 1,
-                       (const float*)nullptr);
-    hipLaunchKernelGGL(k_frame_dense<0>, dim3(F, 1), dim3(128), 128 * 4, st, c.x3, 128, 128, 128,
-                       m->d2_k.as<float>(), m->d2_b.as<float>(), 128, cfeat, T, 1,
-                       (const float*)nullptr);
+    const float* none = nullptr;
+    // conv1 (84 ch, built on the fly from the feature frame) -> x1, conv2 -> x2, dense1 -> x3, dense2 -> cfeat
+    launch_frame<2>(feat, 0, 84, 3 * 84, m->conv1_k.as<float>(), m->conv1_b.as<float>(), 128, c.x1, B, T, 1,
+                    m->embed_pitch.as<float>(), st);
+    launch_frame<1>(c.x1, 128, 128, 3 * 128, m->conv2_k.as<float>(), m->conv2_b.as<float>(), 128, c.x2, B, T, 1,
+                    none, st);
+    launch_frame<0>(c.x2, 128, 128, 128, m->d1_k.as<float>(), m->d1_b.as<float>(), 128, c.x3, B, T, 1, none, st);
+    launch_frame<0>(c.x3, 128, 128, 128, m->d2_k.as<float>(), m->d2_b.as<float>(), 128, cfeat, B, T, 1, none, st);
     FPC_HIP(hipGetLastError());
     return FPC_OK;
 }
@@ -347,14 +377,11 @@ extern "C" int fpc_lpcnet_synthesize(fpc_lpcnet* m, const float* features_dev, i
     // cfeat cannot alias a live buffer: run conv1->x1, conv2->x2, d1->x3, d2->x1
     int rc = run_condition(m, features_dev, B, T, c, cfeat, st);
     if (rc != FPC_OK) return rc;
-    const int F = B * T;
     // conditioning products with the cfeat rows of both GRU input kernels
-    hipLaunchKernelGGL(k_frame_dense<0>, dim3(F, 3), dim3(384), 128 * 4, st, cfeat, 128, 128, 128,
-                       m->ga_k.as<float>() + (size_t)3 * EMB * GA, m->bias_a.as<float>(), GA, c.cfa,
-                       T, 0, (const float*)nullptr);
-    hipLaunchKernelGGL(k_frame_dense<0>, dim3(F, 1), dim3(64), 128 * 4, st, cfeat, 128, 128, 128,
-                       m->gb_k.as<float>() + (size_t)RNN_A * GB, m->bias_b.as<float>(), GB, c.cfb, T,
-                       0, (const float*)nullptr);
+    launch_frame<0>(cfeat, 128, 128, 128, m->ga_k.as<float>() + (size_t)3 * EMB * GA, m->bias_a.as<float>(), GA,
+                    c.cfa, B, T, 0, nullptr, st);
+    launch_frame<0>(cfeat, 128, 128, 128, m->gb_k.as<float>() + (size_t)RNN_A * GB, m->bias_b.as<float>(), GB,
+                    c.cfb, B, T, 0, nullptr, st);
     DecodeParams P;
     P.tab = m->tab.as<float>();
     P.cfa = c.cfa;
