@@ -49,6 +49,52 @@ def cpu_baseline(frames=64):
                       f"(orc_lpcnet_synthesize), single thread"}
 
 
+def e2e_config5(voc, torch, synth, B=128, L=300):
+    """BASELINE config 5, one GPU's share: encode (GRU predictor + thresholds + scalar/2-stage VQ) ->
+    x24.1 -> ceps2lpc -> LPCNet decode for B utterances; bitrate from codebook-usage entropies
+    (src/generate_qtz_features.py:94-101,202)."""
+    import tempfile
+    from fpcodec_amd.synthesis_qtz import encode_features
+    from fpcodec_amd.vq_func import cal_entropy
+    from fpcodec_amd.wavernn import Wavernn
+    d = tempfile.mkdtemp()
+    paths = {}
+    for k, v in synth.codebooks().items():
+        paths[k] = os.path.join(d, k + ".npy")
+        np.save(paths[k], v)
+    cfg = dict(scl_cb_path=paths["scl_hi"], cb_path=paths["vq_hi"], bl_scl_cb_path=paths["scl_lo"],
+               bl_cb_path=paths["vq_lo"], l1=0.09, l2=0.28, qtz=True)
+    model = Wavernn(in_features=20, gru_units1=384, gru_units2=128, fc_units=18)
+    model.load_state_dict(synth.predictor_state_dict())
+    nu = 8
+    nm = np.zeros((B, L, 36), np.float32)
+    nm[:, :, :20] = np.tile(synth.predictor_features(nu, L, utt0=5000), (B // nu + 1, 1, 1))[:B]
+    nm_d = torch.from_numpy(nm).cuda()
+    seeds = torch.from_numpy(synth.seeds(B, utt0=5000).astype(np.int64)).cuda()
+    pcm = torch.empty(B, L * 160, dtype=torch.int16, device="cuda")
+
+    def run():
+        feats, r, i1, i2, cb_tot = encode_features(model, cfg, nm_d)
+        voc.synthesize(feats, seeds, out=pcm)
+        return i1, i2, cb_tot
+
+    run()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    feats, r, i1, i2, cb_tot = encode_features(model, cfg, nm_d)
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    voc.synthesize(feats, seeds, out=pcm)
+    torch.cuda.synchronize()
+    t2 = time.perf_counter()
+    n = B * L
+    ent = [cal_entropy(h) if np.sum(h) > 0 else 0.0 for h in cb_tot]
+    bits_frame = sum(e * float(np.sum(h)) for e, h in zip(ent, cb_tot)) / n + 2.0  # + the two threshold flags
+    return {"utterances": B, "encode_ms": (t1 - t0) * 1e3, "decode_ms": (t2 - t1) * 1e3,
+            "rtf_aggregate": B * 3.0 / (t2 - t0), "keep_rates": [float(i1.mean()), float(i2.mean())],
+            "entropy_bits_per_symbol": ent, "bits_per_frame": bits_frame, "bitrate_bps": bits_frame * 100.0}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -57,6 +103,9 @@ def main():
     ap.add_argument("--streams", type=int, default=256, help="utterances per GPU per step")
     ap.add_argument("--secs", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--e2e", action="store_true",
+                    help="also time BASELINE config 5 per GPU (predictor + residual VQ encode -> ceps2lpc -> decode, "
+                         "128 utterances) and report bitrate; extra key 'e2e', outside the timed region")
     args = ap.parse_args()
 
     import torch
@@ -154,6 +203,8 @@ def main():
         ms1 = voc.last_decode_ms()
         out["single_stream"] = {"decode_ms": ms1, "samples_per_s": (T * 160 - 17) / (ms1 / 1e3),
                                 "rtf": (T * 160 - 17) / (ms1 / 1e3) / 16000.0}
+        if args.e2e:
+            out["e2e"] = e2e_config5(voc, torch, synth)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)
