@@ -117,12 +117,18 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    torch.cuda.set_device(local)
+    ndev = max(1, torch.cuda.device_count())
+    dev = local % ndev  # one process per GPU; the modulo only matters for single-GPU rehearsals
+    torch.cuda.set_device(dev)
     _lib.require_gpu()
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        backend = os.environ.get("FPC_BENCH_BACKEND", "nccl")  # "nccl" == RCCL on ROCm; "gloo" for rehearsals
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev))
+        else:
+            dist.init_process_group(backend)
 
     synth = fpcodec_amd.synth
     B, T = args.streams, args.secs * 100
@@ -157,7 +163,7 @@ def main():
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     if dist:
-        tt = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        tt = torch.tensor([dt], device="cuda" if dist.get_backend() == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 
