@@ -263,7 +263,9 @@ __global__ __launch_bounds__(NTHREADS) void k_decode(const DecodeParams P) {
 #pragma unroll
                     for (int rp = 0; rp < 4; ++rp) acc[rp] = acc[rp] + a[rp];
                 }
-                // cross-lane tree (row-local DPP)
+                FPC_BARRIER()  // Z1
+                // ---- Z1..Z2: cross-lane tree (row-local DPP) ----
+                st_phase = 2;
                 const unsigned metap = opaque(metap_);
                 {
                     const int lq = (int)(metap & 0xff), lQ = (int)((metap >> 8) & 0xff);
@@ -282,9 +284,9 @@ __global__ __launch_bounds__(NTHREADS) void k_decode(const DecodeParams P) {
                     FPC_TREE_LEVEL(8)
 #undef FPC_TREE_LEVEL
                 }
-                FPC_BARRIER()  // Z1
-                // ---- Z1..Z2: diagonal term, publish rec ----
-                st_phase = 2;
+                FPC_BARRIER()  // Z2
+                // ---- Z2..X: diagonal term, publish rec ----
+                st_phase = 3;
                 {
                     const int lq = (int)(metap & 0xff);
                     if ((metap >> 16) != 0 && lq == 0) {
@@ -308,8 +310,6 @@ __global__ __launch_bounds__(NTHREADS) void k_decode(const DecodeParams P) {
                         *reinterpret_cast<float4*>(&L.rec[row0 + 4]) = o1;
                     }
                 }
-                FPC_BARRIER()  // Z2
-                st_phase = 3;
                 if (voiced) {
                     FPC_BARRIER()  // Z3 (voiced frames only)
                 }
