@@ -68,6 +68,7 @@ struct __attribute__((aligned(16))) DecodeLds {
     float cand_pred[256];
     int cand_e[256];  // e_sig | e_pred << 8
     float ulaw_thr[64];  // fpc_lin2ulaw_tab table
+    float tt[FPC_TANH_TABLE_SIZE + 3];  // fpc_tanh_lut table (tanh(k/512)), built at kernel start
     float s2[RNN_B];
     float hist[16];
     // control block written by the winning lane / the LPC chain lane
@@ -146,6 +147,7 @@ __global__ __launch_bounds__(NTHREADS) void k_decode(const DecodeParams P) {
         for (int j = 0; j < 36; ++j) L.fc[((j >> 2) * NSAMP + tid) * 4 + (j & 3)] = P.lane_fc[j * NSAMP + tid];
     }
     if (tid < 64) L.ulaw_thr[tid] = k_ulaw_thr[tid];
+    for (int k = tid; k < FPC_TANH_TABLE_SIZE; k += NTHREADS) L.tt[k] = fpc_tanh_table_entry(k);
     if (tid < RNN_B) {
         L.s2[tid] = 0.0f;
         L.hist[tid] = 0.0f;
@@ -221,9 +223,9 @@ __global__ __launch_bounds__(NTHREADS) void k_decode(const DecodeParams P) {
                         asm volatile("" ::"v"(gz), "v"(gr), "v"(gn));
                         FPC_STAMP(5)
                     }
-                    const float z = fpc_sigmoidf(gz + uz);
-                    const float r = fpc_sigmoidf(gr + ur);
-                    const float n = fpc_tanhf(fmaf(r, un + brn, gn));
+                    const float z = fpc_sigmoid_lut(L.tt, gz + uz);
+                    const float r = fpc_sigmoid_lut(L.tt, gr + ur);
+                    const float n = fpc_tanh_lut(L.tt, fmaf(r, un + brn, gn));
                     const float h_new = fmaf(z, h_own - n, n);
                     L.s1[ml] = h_new;
                     if (STAMP) {
@@ -398,9 +400,9 @@ __global__ __launch_bounds__(NTHREADS) void k_decode(const DecodeParams P) {
                         asm volatile("" ::"v"(a3[0]), "v"(a3[1]), "v"(a3[2]));
                         FPC_STAMP(5)
                     }
-                    const float z = fpc_sigmoidf((a3[0] + cfb_z) + ub_z);
-                    const float r = fpc_sigmoidf((a3[1] + cfb_r) + ub_r);
-                    const float n = fpc_tanhf(fmaf(r, ub_n + brnb, a3[2] + cfb_n));
+                    const float z = fpc_sigmoid_lut(L.tt, (a3[0] + cfb_z) + ub_z);
+                    const float r = fpc_sigmoid_lut(L.tt, (a3[1] + cfb_r) + ub_r);
+                    const float n = fpc_tanh_lut(L.tt, fmaf(r, ub_n + brnb, a3[2] + cfb_n));
                     s2_own = fmaf(z, s2_own - n, n);
                     if (kl == 0) L.s2[u] = s2_own;
                 }
@@ -422,9 +424,9 @@ __global__ __launch_bounds__(NTHREADS) void k_decode(const DecodeParams P) {
                         a01 = fma2(mk2(fw[k4].w, fw[4 + k4].w), splat2(sv.w), a01);
                     }
                     const float a0 = a01.x, a1 = a01.y;
-                    const float t0 = fpc_tanhf(a0), t1 = fpc_tanhf(a1);
+                    const float t0 = fpc_tanh_lut(L.tt, a0), t1 = fpc_tanh_lut(L.tt, a1);
                     const float v = fmaf(fw[8].w, t1, fw[8].z * t0);
-                    L.q[slv] = fpc_sigmoidf(v);
+                    L.q[slv] = fpc_sigmoid_lut(L.tt, v);
                 }
                 FPC_BARRIER()  // Z2
                 float4 p4;  // wave 0: probabilities of leaves 4*lane .. 4*lane+3

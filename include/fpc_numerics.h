@@ -93,6 +93,23 @@ FPC_HD float fpc_sigmoidf(float x) {
     return fmaf(0.5f, fpc_tanhf(0.5f * x), 0.5f);
 }
 
+/* Table forms used by the per-sample vocoder loop (one LDS read instead of ~20 VALU ops):
+ * T[k] = fpc_tanhf(k/512), k = 0..4096, linear interpolation; |err| < 7e-7 absolute.
+ * The table is filled by fpc_tanh_table_entry on both sides, so results are bit-identical. */
+#define FPC_TANH_TABLE_SIZE 4097
+FPC_HD float fpc_tanh_table_entry(int k) { return fpc_tanhf((float)k * (1.0f / 512.0f)); }
+FPC_HD float fpc_tanh_lut_scaled(const float* T, float x, float scale) {
+    const float u = fminf(fabsf(x) * scale, 4095.99976f);
+    const uint32_t i = (uint32_t)u; /* truncation */
+    const float f = u - (float)i;
+    const float t0 = T[i], t1 = T[i + 1];
+    return copysignf(fmaf(f, t1 - t0, t0), x);
+}
+FPC_HD float fpc_tanh_lut(const float* T, float x) { return fpc_tanh_lut_scaled(T, x, 512.0f); }
+FPC_HD float fpc_sigmoid_lut(const float* T, float x) { /* 1/2 + 1/2 tanh(x/2) */
+    return fmaf(0.5f, fpc_tanh_lut_scaled(T, x, 256.0f), 0.5f);
+}
+
 /* exp: Cephes-style range reduction + degree-5 polynomial, result scaled by
  * integer exponent insertion.  Relative error < 2e-7 on [-87, 88]. */
 FPC_HD float fpc_expf(float x) {

@@ -675,11 +675,22 @@ static float tree_reduce(float* a, int P) {
     return a[0];
 }
 
+static float g_tanh_tab[FPC_TANH_TABLE_SIZE + 3];
+static int g_tanh_ready = 0;
+static const float* tanh_tab(void) {
+    if (!g_tanh_ready) {
+        for (int k = 0; k < FPC_TANH_TABLE_SIZE; ++k) g_tanh_tab[k] = fpc_tanh_table_entry(k);
+        g_tanh_ready = 1;
+    }
+    return g_tanh_tab;
+}
+
 /* sample loop of test_lpcnet.py for one utterance.  Optional traces:
  *   exc_out [T*160] uint8 (0 for skipped samples), pcm_f [T*160] float */
 EXPORT void orc_lpcnet_synthesize(const orc_lpcnet* m, const float* feat, int T, uint64_t seed,
                                   int16_t* pcm_out, uint8_t* exc_out, float* pcm_f_out) {
     const orc_lpcnet_weights* w = &m->w;
+    const float* TT = tanh_tab();
     float* cfeat = (float*)malloc(sizeof(float) * (size_t)T * COND);
     orc_lpcnet_condition(m, feat, T, cfeat);
     float s1[RNN_A], s2[RNN_B], cfa[GA], cfb[GB], q[256], p[256], c[256], tmp[256];
@@ -748,9 +759,9 @@ EXPORT void orc_lpcnet_synthesize(const orc_lpcnet* m, const float* feat, int T,
                     gi[g] = ((m->tab[0][(size_t)e_sig * GA + row] + m->tab[1][(size_t)e_pred * GA + row]) +
                              m->tab[2][(size_t)e_exc * GA + row]) + cfa[row];
                 }
-                const float z = fpc_sigmoidf(gi[0] + u[j]);
-                const float r = fpc_sigmoidf(gi[1] + u[RNN_A + j]);
-                const float n = fpc_tanhf(fmaf(r, u[2 * RNN_A + j] + m->brn_a[j], gi[2]));
+                const float z = fpc_sigmoid_lut(TT, gi[0] + u[j]);
+                const float r = fpc_sigmoid_lut(TT, gi[1] + u[RNN_A + j]);
+                const float n = fpc_tanh_lut(TT, fmaf(r, u[2 * RNN_A + j] + m->brn_a[j], gi[2]));
                 s1n[j] = fmaf(z, s1[j] - n, n);
             }
             memcpy(s1, s1n, sizeof s1);
@@ -770,9 +781,9 @@ EXPORT void orc_lpcnet_synthesize(const orc_lpcnet* m, const float* feat, int T,
                 ub[o] = tree_reduce(prod, RNN_B);
             }
             for (int j = 0; j < RNN_B; ++j) {
-                const float z = fpc_sigmoidf(gb[j] + ub[j]);
-                const float r = fpc_sigmoidf(gb[RNN_B + j] + ub[RNN_B + j]);
-                const float n = fpc_tanhf(fmaf(r, ub[2 * RNN_B + j] + m->brn_b[j], gb[2 * RNN_B + j]));
+                const float z = fpc_sigmoid_lut(TT, gb[j] + ub[j]);
+                const float r = fpc_sigmoid_lut(TT, gb[RNN_B + j] + ub[RNN_B + j]);
+                const float n = fpc_tanh_lut(TT, fmaf(r, ub[2 * RNN_B + j] + m->brn_b[j], gb[2 * RNN_B + j]));
                 s2n[j] = fmaf(z, s2[j] - n, n);
             }
             memcpy(s2, s2n, sizeof s2);
@@ -783,10 +794,10 @@ EXPORT void orc_lpcnet_synthesize(const orc_lpcnet* m, const float* feat, int T,
                 for (int ch = 0; ch < 2; ++ch) {
                     float dacc = w->md_b[j * 2 + ch];
                     for (int k = 0; k < RNN_B; ++k) dacc = fmaf(w->md_k[((size_t)j * RNN_B + k) * 2 + ch], s2[k], dacc);
-                    tc[ch] = fpc_tanhf(dacc);
+                    tc[ch] = fpc_tanh_lut(TT, dacc);
                 }
                 const float v = fmaf(w->md_f[j * 2 + 1], tc[1], w->md_f[j * 2] * tc[0]);
-                q[j] = fpc_sigmoidf(v);
+                q[j] = fpc_sigmoid_lut(TT, v);
             }
             /* 8-level binary tree -> pdf over 256 mu-law levels, MSB first */
             for (int v = 0; v < 256; ++v) {
