@@ -340,6 +340,9 @@ __global__ __launch_bounds__(NTHREADS) void k_decode(const DecodeParams P) {
             const float shape_e = fpc_shape_exponent(feat[19]);
             const float* cfb = P.cfb + ((size_t)b * T + fr) * GB;
             const float cfb_z = cfb[u], cfb_r = cfb[RNN_B + u], cfb_n = cfb[2 * RNN_B + u];
+            const float* fa = feat + (FPC_NB_FEATURES - FPC_LPC_ORDER);  // this frame's LPC, and the next frame's
+            const float* fan = fa + (fr + 1 < T ? FPC_NB_FEATURES : 0);
+            const float a_cur = fa[kl], a_nxt = fan[kl], a0_cur = fa[0], a0_nxt = fan[0];
             if (sl < FPC_FRAME_SIZE)  // first read behind barrier Z3 of this frame's first sample
                 L.uframe[sl] = fpc_philox_uniform(seed, (uint32_t)(fr * FPC_FRAME_SIZE + sl));
 
@@ -353,18 +356,16 @@ __global__ __launch_bounds__(NTHREADS) void k_decode(const DecodeParams P) {
                 const float ub_r = row_bfly16(ub1 * s2k);
                 const float ub_n = row_bfly16(ub2 * s2k);
                 {
-                    // prediction taps 16..2 of the NEXT sample, evaluated by every lane (broadcast LDS
-                    // reads, uniform coefficient loads) so that no extra hand-off is needed
-                    int frn = (t + 1) / FPC_FRAME_SIZE;
-                    frn = frn < T ? frn : T - 1;
-                    const float* a = P.features + ((size_t)b * T + frn) * FPC_NB_FEATURES +
-                                     (FPC_NB_FEATURES - FPC_LPC_ORDER);
-                    float part = 0.0f;
-#pragma unroll
-                    for (int k = FPC_LPC_ORDER; k >= 2; --k) part = fmaf(a[k - 1], L.hist[(t + 1 - k) & 15], part);
+                    // prediction of the NEXT sample: taps 2..16 as a balanced tree over the 16 lanes of
+                    // the row (lane kl holds tap kl+1, lane 0 contributes 0), the newest tap by one fma
+                    const bool lastsmp = i == FPC_FRAME_SIZE - 1;  // next sample belongs to the next frame
+                    const float am = lastsmp ? a_nxt : a_cur;
+                    const float a0 = lastsmp ? a0_nxt : a0_cur;
+                    const float hk = L.hist[(t - kl) & 15];
+                    const float part = row_bfly16(kl ? am * hk : 0.0f);
                     // what the control block becomes if leaf `sl` wins this sample's draw
                     const float cpcm = L.pred + my_ulaw;
-                    const float cpred = -fmaf(a[0], cpcm, part);
+                    const float cpred = -fmaf(a0, cpcm, part);
                     L.cand_pcm[sl] = cpcm;
                     L.cand_pred[sl] = cpred;
                     L.cand_e[sl] = fpc_lin2ulaw_tab(cpcm, L.ulaw_thr) | (fpc_lin2ulaw_tab(cpred, L.ulaw_thr) << 8);

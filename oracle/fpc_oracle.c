@@ -725,10 +725,11 @@ EXPORT void orc_lpcnet_synthesize(const orc_lpcnet* m, const float* feat, int T,
                 if (pcm_f_out) pcm_f_out[t] = 0.0f;
                 continue;
             }
-            /* LPC prediction, oldest tap first (src/utils.py:91-114 sign/tap order) */
-            float acc = 0.0f;
-            for (int k = FPC_LPC_ORDER - 1; k >= 0; --k) acc = fmaf(a[k], hist[k], acc);
-            const float pred = -acc;
+            /* LPC prediction (src/utils.py:91-114 sign/tap order) */
+            float prod[FPC_LPC_ORDER]; /* older taps: balanced tree; newest tap: one fma on top */
+            prod[0] = 0.0f;
+            for (int k = 1; k < FPC_LPC_ORDER; ++k) prod[k] = a[k] * hist[k];
+            const float pred = -fmaf(a[0], hist[0], tree_reduce(prod, FPC_LPC_ORDER));
             const int e_pred = fpc_lin2ulaw(pred);
             /* GRU_A: sparse recurrent product, canonical leaf/tree order */
             float u[GA];
