@@ -144,7 +144,10 @@ __global__ __launch_bounds__(NTHREADS) void k_decode(const DecodeParams P) {
     }
     if (tid < NSAMP) {
 #pragma unroll
-        for (int j = 0; j < 36; ++j) L.fc[((j >> 2) * NSAMP + tid) * 4 + (j & 3)] = P.lane_fc[j * NSAMP + tid];
+        for (int j = 0; j < 36; ++j) {  // source index of slot j: channel pairs side by side -> v_pk_fma operands need no moves
+            const int src = j < 32 ? ((j & 1) * 16 + (j >> 1)) : j;
+            L.fc[((j >> 2) * NSAMP + tid) * 4 + (j & 3)] = P.lane_fc[src * NSAMP + tid];
+        }
     }
     if (tid < 64) L.ulaw_thr[tid] = k_ulaw_thr[tid];
     for (int k = tid; k < FPC_TANH_TABLE_SIZE; k += NTHREADS) L.tt[k] = fpc_tanh_table_entry(k);
@@ -272,19 +275,24 @@ __global__ __launch_bounds__(NTHREADS) void k_decode(const DecodeParams P) {
                 {
                     const int lq = (int)(metap & 0xff), lQ = (int)((metap >> 8) & 0xff);
     // acc += take ? neighbour : 0, as fma(neighbour, 1.0|0.0, acc): exact, one v_fmac_f32_dpp per row
+#define FPC_FMAC_DPP(S, A) \
+    asm volatile("v_fmac_f32_dpp %0, %0, %1 row_shl:" #S " row_mask:0xf bank_mask:0xf bound_ctrl:1" : "+v"(A) : "v"(take))
 #define FPC_TREE_LEVEL(S)                                                  \
     if (maxQ > S) {                                                        \
         const float take = (lq + S < lQ) ? 1.0f : 0.0f;                    \
-        _Pragma("unroll") for (int rp = 0; rp < 4; ++rp) {                 \
-            acc[rp].x = fmaf(dpp_f<DPP_ROW_SHL + S>(acc[rp].x), take, acc[rp].x); \
-            acc[rp].y = fmaf(dpp_f<DPP_ROW_SHL + S>(acc[rp].y), take, acc[rp].y); \
-        }                                                                  \
+        float a0_ = acc[0].x, a1_ = acc[0].y, a2_ = acc[1].x, a3_ = acc[1].y, a4_ = acc[2].x, a5_ = acc[2].y, \
+              a6_ = acc[3].x, a7_ = acc[3].y;                              \
+        asm volatile("s_nop 1" ::"v"(a0_), "v"(take));                     \
+        FPC_FMAC_DPP(S, a0_); FPC_FMAC_DPP(S, a1_); FPC_FMAC_DPP(S, a2_); FPC_FMAC_DPP(S, a3_); \
+        FPC_FMAC_DPP(S, a4_); FPC_FMAC_DPP(S, a5_); FPC_FMAC_DPP(S, a6_); FPC_FMAC_DPP(S, a7_); \
+        acc[0] = mk2(a0_, a1_); acc[1] = mk2(a2_, a3_); acc[2] = mk2(a4_, a5_); acc[3] = mk2(a6_, a7_); \
     }
                     FPC_TREE_LEVEL(1)
                     FPC_TREE_LEVEL(2)
                     FPC_TREE_LEVEL(4)
                     FPC_TREE_LEVEL(8)
 #undef FPC_TREE_LEVEL
+#undef FPC_FMAC_DPP
                 }
                 FPC_BARRIER()  // Z2
                 // ---- Z2..X: diagonal term, publish rec ----
@@ -419,10 +427,10 @@ __global__ __launch_bounds__(NTHREADS) void k_decode(const DecodeParams P) {
 #pragma unroll
                     for (int k4 = 0; k4 < 4; ++k4) {
                         const float4 sv = *reinterpret_cast<const float4*>(&L.s2[4 * k4]);
-                        a01 = fma2(mk2(fw[k4].x, fw[4 + k4].x), splat2(sv.x), a01);
-                        a01 = fma2(mk2(fw[k4].y, fw[4 + k4].y), splat2(sv.y), a01);
-                        a01 = fma2(mk2(fw[k4].z, fw[4 + k4].z), splat2(sv.z), a01);
-                        a01 = fma2(mk2(fw[k4].w, fw[4 + k4].w), splat2(sv.w), a01);
+                        a01 = fma2(mk2(fw[2 * k4].x, fw[2 * k4].y), splat2(sv.x), a01);
+                        a01 = fma2(mk2(fw[2 * k4].z, fw[2 * k4].w), splat2(sv.y), a01);
+                        a01 = fma2(mk2(fw[2 * k4 + 1].x, fw[2 * k4 + 1].y), splat2(sv.z), a01);
+                        a01 = fma2(mk2(fw[2 * k4 + 1].z, fw[2 * k4 + 1].w), splat2(sv.w), a01);
                     }
                     const float a0 = a01.x, a1 = a01.y;
                     const float t0 = fpc_tanh_lut(L.tt, a0), t1 = fpc_tanh_lut(L.tt, a1);
