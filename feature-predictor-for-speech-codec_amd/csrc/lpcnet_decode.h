@@ -335,9 +335,15 @@ __global__ __launch_bounds__(NTHREADS) void k_decode(const DecodeParams P) {
         const int sl = tid;                    // 0..255
         const int u = sl >> 4, kl = sl & 15;   // GRU_B: unit, 24-input slice
         const unsigned long long seed = P.seeds[b];
-        float wb[72];
+        // GRU_B input weights of this lane's 24 inputs: (z,r) gate pairs advance with one v_pk_fma_f32 per
+        // input (h broadcast), the candidate gate with plain fmas
+        f2 wzr[24];
+        float wn[24];
 #pragma unroll
-        for (int j = 0; j < 72; ++j) wb[j] = P.lane_wb[j * NSAMP + sl];
+        for (int k = 0; k < 24; ++k) {
+            wzr[k] = mk2(P.lane_wb[k * NSAMP + sl], P.lane_wb[(24 + k) * NSAMP + sl]);
+            wn[k] = P.lane_wb[(48 + k) * NSAMP + sl];
+        }
         const float ub0 = P.lane_ub[sl], ub1 = P.lane_ub[NSAMP + sl], ub2 = P.lane_ub[2 * NSAMP + sl];
         const float brnb = P.brn_b[u];
         const float my_ulaw = P.ulaw_tab[sl];
@@ -383,28 +389,29 @@ __global__ __launch_bounds__(NTHREADS) void k_decode(const DecodeParams P) {
                 st_phase = 1;
                 {
                     const unsigned klv = opaque((unsigned)kl);
-                    float lf[3][4];
+                    f2 lzr[4];
+                    float ln[4];
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {  // canonical leaf j of this lane: 6 inputs
                         const float2 h0 = *reinterpret_cast<const float2*>(&L.s1[24 * klv + 6 * j]);
                         const float2 h1 = *reinterpret_cast<const float2*>(&L.s1[24 * klv + 6 * j + 2]);
                         const float2 h2 = *reinterpret_cast<const float2*>(&L.s1[24 * klv + 6 * j + 4]);
+                        const float hv[6] = {h0.x, h0.y, h1.x, h1.y, h2.x, h2.y};
+                        f2 azr = splat2(0.0f);
+                        float an = 0.0f;
 #pragma unroll
-                        for (int g = 0; g < 3; ++g) {
-                            const float* wg = &wb[g * 24 + j * 6];
-                            float a = 0.0f;
-                            a = fmaf(wg[0], h0.x, a);
-                            a = fmaf(wg[1], h0.y, a);
-                            a = fmaf(wg[2], h1.x, a);
-                            a = fmaf(wg[3], h1.y, a);
-                            a = fmaf(wg[4], h2.x, a);
-                            a = fmaf(wg[5], h2.y, a);
-                            lf[g][j] = a;
+                        for (int k = 0; k < 6; ++k) {
+                            azr = fma2(wzr[j * 6 + k], splat2(hv[k]), azr);
+                            an = fmaf(wn[j * 6 + k], hv[k], an);
                         }
+                        lzr[j] = azr;
+                        ln[j] = an;
                     }
+                    const f2 tzr = (lzr[0] + lzr[1]) + (lzr[2] + lzr[3]);
                     float a3[3];
-#pragma unroll
-                    for (int g = 0; g < 3; ++g) a3[g] = row_bfly16((lf[g][0] + lf[g][1]) + (lf[g][2] + lf[g][3]));
+                    a3[0] = row_bfly16(tzr.x);
+                    a3[1] = row_bfly16(tzr.y);
+                    a3[2] = row_bfly16((ln[0] + ln[1]) + (ln[2] + ln[3]));
                     if (STAMP) {
                         asm volatile("" ::"v"(a3[0]), "v"(a3[1]), "v"(a3[2]));
                         FPC_STAMP(5)
