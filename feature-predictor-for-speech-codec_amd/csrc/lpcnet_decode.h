@@ -5,18 +5,19 @@
 //   waves 0-3  "sampler":  GRU_B, dual-FC, tree pdf, draw   (GRU_B weights in VGPRs)
 //   waves 4-11 "mat-vec":  embedding-row gather + GRU_A gates, and the block-sparse
 //                          recurrent product for the NEXT sample (weights in VGPRs)
-// Five workgroup barriers per output sample (X, Y, Z1, Z2, Z3):
-//   X  control block (mu-law indices of the drawn sample) published
-//        M: gather 3 table rows, gates -> s1'
-//        S: GRU_B recurrent part, LPC history chain, per-leaf candidates of this sample
+// Four workgroup barriers per output sample (X, Y, Z1, Z2; voiced frames add Z3):
+//   X  control block (table-row offsets selected by the drawn sample) published
+//        M: gather 3 table rows, GRU_A gates -> s1'
+//        S: GRU_B recurrent part, LPC taps 2..16 (DPP tree), per-leaf candidates of this sample
 //   Y  s1' ready
-//        S: GRU_B -> s2'                           M: sparse product (both leaves), DPP tree
+//        S: GRU_B -> s2'                           M: sparse product, both leaves of every lane
 //   Z1 s2' ready
-//        S: dual FC -> 255 node probabilities      M: diagonal term, rec -> LDS
+//        S: dual FC -> 255 node probabilities      M: cross-lane DPP tree
 //   Z2 q ready
-//        S: leaf probabilities                     M: -
-//   Z3 pdf ready
-//        S wave 0: normaliser, tail cut, scan, draw, control block
+//        S wave 0 (unvoiced frame): 4 leaf probabilities per lane, normaliser, tail cut, scan, draw,
+//        control block                             M: diagonal term, rec -> LDS
+//        (voiced frame: all 256 sampler lanes compute leaf probability + sharpening, barrier Z3,
+//         then wave 0 draws)
 // The sparse product (61 % of the algorithmic FLOPs) never sits on the sample-to-sample
 // critical path; HBM is touched only for the gathered table rows (L2-resident), the
 // per-frame conditioning rows and 2 bytes of PCM per sample.
