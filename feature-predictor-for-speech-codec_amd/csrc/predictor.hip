@@ -59,33 +59,67 @@ struct __attribute__((aligned(16))) PredLds {
     double qs;
 };
 
-// ---- GRU layer: both mat-vecs as k-ordered fmaf chains, two rows per thread ----
+// k-ordered fmaf chains of one row over v[0..K) with weights wT[k][R]: 16 loads in flight per block
+__device__ __forceinline__ float chain1(const float* __restrict__ wT, const float* v, int K, int R, int r, float a) {
+    int k = 0;
+    for (; k + 16 <= K; k += 16) {
+        float w[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) w[j] = wT[(size_t)(k + j) * R + r];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) a = fmaf(v[k + j], w[j], a);
+    }
+    for (; k < K; ++k) a = fmaf(v[k], wT[(size_t)k * R + r], a);
+    return a;
+}
+
+// four adjacent rows (r..r+3, R % 4 == 0) advance together: one 16-byte load per k serves 4 chains, 16 k
+// in flight per block (dword loads would be bound by the texture-address unit, not by L2)
+__device__ __forceinline__ void chain4(const float* __restrict__ wT, const float* v, int K, int R, int r, float4& a) {
+    int k = 0;
+    for (; k + 16 <= K; k += 16) {
+        float4 w[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) w[j] = *reinterpret_cast<const float4*>(&wT[(size_t)(k + j) * R + r]);
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const float hv = v[k + j];
+            a.x = fmaf(hv, w[j].x, a.x);
+            a.y = fmaf(hv, w[j].y, a.y);
+            a.z = fmaf(hv, w[j].z, a.z);
+            a.w = fmaf(hv, w[j].w, a.w);
+        }
+    }
+    int rem = K - k;  // tail (e.g. K = 20): all remaining loads in flight together
+    if (rem > 0) {
+        float4 w[15];
+#pragma unroll
+        for (int j = 0; j < 15; ++j)
+            if (j < rem) w[j] = *reinterpret_cast<const float4*>(&wT[(size_t)(k + j) * R + r]);
+#pragma unroll
+        for (int j = 0; j < 15; ++j)
+            if (j < rem) {
+                const float hv = v[k + j];
+                a.x = fmaf(hv, w[j].x, a.x);
+                a.y = fmaf(hv, w[j].y, a.y);
+                a.z = fmaf(hv, w[j].z, a.z);
+                a.w = fmaf(hv, w[j].w, a.w);
+            }
+    }
+}
+
+// ---- GRU layer: both mat-vecs as k-ordered fmaf chains, four adjacent rows per thread ----
 __device__ void gru_layer(const float* __restrict__ wiT, const float* __restrict__ whT,
                           const float* __restrict__ bi, const float* __restrict__ bh,
                           const float* x, int K, float* h, int H, float* gi, float* gh, int tid) {
     const int R = 3 * H;
-    for (int r0 = tid; r0 < R; r0 += 2 * NT) {
-        const int r1 = r0 + NT;
-        const bool two = r1 < R;
-        const int r1c = two ? r1 : r0;
-        float ai0 = bi[r0], ai1 = bi[r1c], ah0 = bh[r0], ah1 = bh[r1c];
-        for (int k = 0; k < K; ++k) {
-            const float xv = x[k];
-            ai0 = fmaf(xv, wiT[(size_t)k * R + r0], ai0);
-            ai1 = fmaf(xv, wiT[(size_t)k * R + r1c], ai1);
-        }
-#pragma unroll 4
-        for (int k = 0; k < H; ++k) {
-            const float hv = h[k];
-            ah0 = fmaf(hv, whT[(size_t)k * R + r0], ah0);
-            ah1 = fmaf(hv, whT[(size_t)k * R + r1c], ah1);
-        }
-        gi[r0] = ai0;
-        gh[r0] = ah0;
-        if (two) {
-            gi[r1] = ai1;
-            gh[r1] = ah1;
-        }
+    for (int r = 4 * tid; r < R; r += 4 * NT) {
+        float4 ai = *reinterpret_cast<const float4*>(&bi[r]);
+        float4 ah = *reinterpret_cast<const float4*>(&bh[r]);
+        chain4(wiT, x, K, R, r, ai);
+        chain4(whT, h, H, R, r, ah);
+        *reinterpret_cast<float4*>(&gi[r]) = ai;
+        *reinterpret_cast<float4*>(&gh[r]) = ah;
     }
     __syncthreads();
     for (int i = tid; i < H; i += NT) {  // torch.nn.GRU gate rows [r; z; n]
@@ -104,8 +138,7 @@ __device__ void pred_step(const PredDev& P, PredLds& L, int tid) {
     for (int i = tid; i < P.h2; i += NT) L.relu[i] = L.h2[i] > 0.0f ? L.h2[i] : 0.0f;
     __syncthreads();
     if (tid < P.fc) {
-        float acc = P.fcb[tid];
-        for (int k = 0; k < P.h2; ++k) acc = fmaf(L.relu[k], P.fcw[(size_t)k * P.fc + tid], acc);
+        const float acc = chain1(P.fcw, L.relu, P.h2, P.fc, tid, P.fcb[tid]);
         const float t = fpc_tanhf(acc);
         L.fo[tid] = t + t;  // the "dual" FC is the same Linear summed twice (wavernn.py:89-92)
     }
@@ -488,7 +521,8 @@ extern "C" int fpc_predictor_create(const fpc_predictor_weights* w, fpc_predicto
     }
     FPC_REQUIRE(w->in_features > 0 && w->in_features <= MAX_IN && w->gru_units1 > 0 &&
                     w->gru_units1 <= MAX_H1 && w->gru_units2 > 0 && w->gru_units2 <= MAX_H2 &&
-                    w->fc_units > 0 && w->fc_units <= MAX_FC && w->fc_units <= w->in_features,
+                    w->fc_units > 0 && w->fc_units <= MAX_FC && w->fc_units <= w->in_features &&
+                    w->gru_units1 % 4 == 0 && w->gru_units2 % 4 == 0,
                 "fpc_predictor_create: unsupported sizes in=%d h1=%d h2=%d fc=%d", w->in_features,
                 w->gru_units1, w->gru_units2, w->fc_units);
     FPC_REQUIRE(w->rnn1_weight_ih && w->rnn1_weight_hh && w->rnn1_bias_ih && w->rnn1_bias_hh &&
