@@ -93,6 +93,18 @@ __device__ __forceinline__ float row_bfly16(float v) {
     v = v + dpp_f<DPP_MIRROR>(v);
     return v;
 }
+// three independent row butterflies interleaved: every DPP read of a register comes >= 2 instructions
+// after its last write (the gfx9 VALU-write -> DPP-read hazard), so no s_nop and no separate v_mov_dpp
+__device__ __forceinline__ void row_bfly16x3(float& a, float& b, float& c) {
+#define FPC_B3(CTRL)                                                              \
+    "v_add_f32_dpp %0, %0, %0 " CTRL " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t" \
+    "v_add_f32_dpp %1, %1, %1 " CTRL " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t" \
+    "v_add_f32_dpp %2, %2, %2 " CTRL " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+    asm volatile("s_nop 1\n\t" FPC_B3("quad_perm:[1,0,3,2]") FPC_B3("quad_perm:[2,3,0,1]") FPC_B3("row_half_mirror")
+                     FPC_B3("row_mirror")
+                 : "+v"(a), "+v"(b), "+v"(c));
+#undef FPC_B3
+}
 __device__ __forceinline__ float lane_val(float v, int l) {
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l));
 }
@@ -367,9 +379,8 @@ __global__ __launch_bounds__(NTHREADS) void k_decode(const DecodeParams P) {
                 //      previous draw: GRU_B recurrent part, LPC history chain, leaf candidates ----
                 st_phase = 0;
                 const float s2k = L.s2[kl];
-                const float ub_z = row_bfly16(ub0 * s2k);
-                const float ub_r = row_bfly16(ub1 * s2k);
-                const float ub_n = row_bfly16(ub2 * s2k);
+                float ub_z = ub0 * s2k, ub_r = ub1 * s2k, ub_n = ub2 * s2k;
+                row_bfly16x3(ub_z, ub_r, ub_n);
                 {
                     // prediction of the NEXT sample: taps 2..16 as a balanced tree over the 16 lanes of
                     // the row (lane kl holds tap kl+1, lane 0 contributes 0), the newest tap by one fma
@@ -410,9 +421,10 @@ __global__ __launch_bounds__(NTHREADS) void k_decode(const DecodeParams P) {
                     }
                     const f2 tzr = (lzr[0] + lzr[1]) + (lzr[2] + lzr[3]);
                     float a3[3];
-                    a3[0] = row_bfly16(tzr.x);
-                    a3[1] = row_bfly16(tzr.y);
-                    a3[2] = row_bfly16((ln[0] + ln[1]) + (ln[2] + ln[3]));
+                    a3[0] = tzr.x;
+                    a3[1] = tzr.y;
+                    a3[2] = (ln[0] + ln[1]) + (ln[2] + ln[3]);
+                    row_bfly16x3(a3[0], a3[1], a3[2]);
                     if (STAMP) {
                         asm volatile("" ::"v"(a3[0]), "v"(a3[1]), "v"(a3[2]));
                         FPC_STAMP(5)
