@@ -105,6 +105,12 @@ __device__ __forceinline__ void row_bfly16x3(float& a, float& b, float& c) {
                  : "+v"(a), "+v"(b), "+v"(c));
 #undef FPC_B3
 }
+// v + (value broadcast from the last lane of the previous row(s)), written only to the rows in ROWMASK
+template <int CTRL, int ROWMASK>
+__device__ __forceinline__ float add_bcast(float v) {
+    return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROWMASK, 0xf, false));
+}
+constexpr int DPP_BCAST15 = 0x142, DPP_BCAST31 = 0x143;
 __device__ __forceinline__ float lane_val(float v, int l) {
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l));
 }
@@ -496,8 +502,10 @@ __global__ __launch_bounds__(NTHREADS) void k_decode(const DecodeParams P) {
                 }
                 // ---- (wave 0): normaliser, tail cut, scan, draw, publish ----
                 if (wave == 0) {
-                    const float rs = row_bfly16((p4.x + p4.y) + (p4.z + p4.w));
-                    const float S1 = (lane_val(rs, 0) + lane_val(rs, 16)) + (lane_val(rs, 32) + lane_val(rs, 48));
+                    float rs = row_bfly16((p4.x + p4.y) + (p4.z + p4.w));
+                    rs = add_bcast<DPP_BCAST15, 0xa>(rs);  // rows 1,3 += rows 0,2
+                    rs = add_bcast<DPP_BCAST31, 0xc>(rs);  // row 3 = (r2+r3)+(r0+r1): the balanced total
+                    const float S1 = lane_val(rs, 63);
                     const float thr = 0.002f * S1;
                     float c0 = p4.x - thr, c1 = p4.y - thr, c2 = p4.z - thr, c3 = p4.w - thr;
                     c0 = c0 > 0.0f ? c0 : 0.0f;
@@ -512,9 +520,8 @@ __global__ __launch_bounds__(NTHREADS) void k_decode(const DecodeParams P) {
                     I = I + dpp_f<DPP_ROW_SHR + 2>(I);
                     I = I + dpp_f<DPP_ROW_SHR + 4>(I);
                     I = I + dpp_f<DPP_ROW_SHR + 8>(I);
-                    const float R0 = lane_val(I, 15), R1 = lane_val(I, 31), R2 = lane_val(I, 47);
-                    const float O2 = R0 + R1, O3 = O2 + R2;
-                    if (lane >= 16) I = (lane < 32 ? R0 : (lane < 48 ? O2 : O3)) + I;
+                    I = add_bcast<DPP_BCAST15, 0xa>(I);  // block offsets by row broadcasts
+                    I = add_bcast<DPP_BCAST31, 0xc>(I);
                     const float S2 = lane_val(I, 63);
                     const float rthr = L.uframe[i] * S2;
                     const int lw = __popcll(__ballot(lane < 63 && I <= rthr));  // winning lane

@@ -821,7 +821,7 @@ EXPORT void orc_lpcnet_synthesize(const orc_lpcnet* m, const float* feat, int T,
             }
             /* three-level inclusive scan: sequential prefix inside each aligned group of 4
              * leaves; Kogge-Stone over the 16 group totals of each aligned block of 64 leaves;
-             * sequential offsets over the 4 block totals */
+             * block offsets as below */
             float I64[64];
             for (int g4 = 0; g4 < 64; ++g4) {
                 float run = p[4 * g4];
@@ -832,7 +832,7 @@ EXPORT void orc_lpcnet_synthesize(const orc_lpcnet* m, const float* feat, int T,
                 }
                 I64[g4] = run;
             }
-            float R4[4], O4[4];
+            float R4[4], O4[3];
             for (int row = 0; row < 4; ++row) {
                 float* x = I64 + 16 * row;
                 for (int d = 1; d < 16; d <<= 1) {
@@ -845,9 +845,13 @@ EXPORT void orc_lpcnet_synthesize(const orc_lpcnet* m, const float* feat, int T,
             O4[0] = 0.0f;
             O4[1] = R4[0];
             O4[2] = R4[0] + R4[1];
-            O4[3] = O4[2] + R4[2];
-            for (int row = 1; row < 4; ++row)
-                for (int l = 0; l < 16; ++l) I64[16 * row + l] = O4[row] + I64[16 * row + l];
+            /* block offsets in the order of the DPP row-broadcast scan: blocks 1 and 3 first take the
+             * total of their left neighbour, then blocks 2 and 3 take the total of blocks 0+1 */
+            for (int l = 0; l < 16; ++l) {
+                I64[16 + l] = I64[16 + l] + R4[0];
+                I64[32 + l] = I64[32 + l] + O4[2];
+                I64[48 + l] = (I64[48 + l] + R4[2]) + O4[2];
+            }
             const float S2 = I64[63];
             const float rthr = fpc_philox_uniform(seed, (uint32_t)t) * S2;
             int wsel = 0; /* group that holds the draw */
