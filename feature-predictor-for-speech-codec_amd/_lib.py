@@ -5,7 +5,7 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libfpcodec.so")
+LIB_PATH = os.environ.get("FPC_LIB_PATH") or os.path.join(_HERE, "libfpcodec.so")  # override: kernel-variant experiments
 _lib = None
 
 SYMBOLS = [

@@ -131,7 +131,7 @@ struct fpc_lpcnet {
     fpc::DevBuf embed_pitch, conv1_k, conv1_b, conv2_k, conv2_b, d1_k, d1_b, d2_k, d2_b;
     fpc::DevBuf ga_k, gb_k, bias_a, bias_b, tab;
     fpc::DevBuf lane_w, lane_meta, lane_wb, lane_ub, lane_fc, diag, brn_a, brn_b, ulaw_tab;
-    int wave_maxQ[NMW];
+    int gate_qp[3];
     int nblocks = 0, nleaves = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool timed = false;
@@ -228,7 +228,7 @@ extern "C" int fpc_lpcnet_create(const fpc_lpcnet_weights* w, fpc_lpcnet** out) 
         return la != lb ? la > lb : a < b;
     });
     int row_fill[NROWS16] = {0};
-    for (int i = 0; i < NMW; ++i) m->wave_maxQ[i] = 1;
+    int gate_q[3] = {1, 1, 1};
     std::vector<float> lane_w((size_t)128 * NMAT, 0.0f);
     std::vector<int> lane_meta(2 * NMAT, 0);
     for (int l = 0; l < NMAT; ++l) lane_meta[NMAT + l] = (1 << 8);  // no group, 1 lane, lane 0
@@ -265,9 +265,13 @@ extern "C" int fpc_lpcnet_create(const fpc_lpcnet_weights* w, fpc_lpcnet** out) 
             lane_meta[l] = (int)colp;
         }
         row_fill[best] += Q;
-        const int wv = best / 4;
-        if (Q > m->wave_maxQ[wv]) m->wave_maxQ[wv] = Q;
+        if (Q > gate_q[gate]) gate_q[gate] = Q;
         m->nleaves += Q;
+    }
+    for (int g = 0; g < 3; ++g) {
+        int qp = 1;
+        while (qp < gate_q[g]) qp <<= 1;
+        m->gate_qp[g] = qp;
     }
     FPC_HIP(m->lane_w.upload(lane_w));
     FPC_HIP(m->lane_meta.upload(lane_meta));
@@ -400,32 +404,46 @@ extern "C" int fpc_lpcnet_synthesize(fpc_lpcnet* m, const float* features_dev, i
     P.brn_b = m->brn_b.as<float>();
     P.ulaw_tab = m->ulaw_tab.as<float>();
     P.dbg_const_rows = getenv("FPC_DBG_CONST_ROWS") != nullptr;
-    for (int i = 0; i < NMW; ++i) P.wave_maxQ[i] = m->wave_maxQ[i];
     const bool stamp = getenv("FPC_DECODE_STAMPS") != nullptr;
     fpc::DevBuf stamps;
     P.stamps = nullptr;
     if (stamp) {
-        FPC_HIP(stamps.alloc(16 * sizeof(unsigned long long)));
-        FPC_HIP(hipMemsetAsync(stamps.p, 0, 16 * sizeof(unsigned long long), st));
+        FPC_HIP(stamps.alloc(192 * sizeof(unsigned long long)));
+        FPC_HIP(hipMemsetAsync(stamps.p, 0, 192 * sizeof(unsigned long long), st));
         P.stamps = stamps.as<unsigned long long>();
     }
     FPC_HIP(hipEventRecord(m->ev0, st));
-    if (stamp)
-        hipLaunchKernelGGL(k_decode<true>, dim3(B), dim3(NTHREADS), 0, st, P);
+    // kernel instance by the widest row group: (update/reset gates, candidate gate) partial-sum planes
+    const int qzr = m->gate_qp[0] > m->gate_qp[1] ? m->gate_qp[0] : m->gate_qp[1], qn = m->gate_qp[2];
+#define FPC_LAUNCH(QZR, QN)                                                                       \
+    do {                                                                                          \
+        if (stamp)                                                                                \
+            hipLaunchKernelGGL((k_decode<true, QZR, QN>), dim3(B), dim3(NTHREADS), 0, st, P);     \
+        else                                                                                      \
+            hipLaunchKernelGGL((k_decode<false, QZR, QN>), dim3(B), dim3(NTHREADS), 0, st, P);    \
+    } while (0)
+    if (qzr <= 2 && qn <= 8)
+        FPC_LAUNCH(2, 8);
+    else if (qzr <= 4 && qn <= 8)
+        FPC_LAUNCH(4, 8);
     else
-        hipLaunchKernelGGL(k_decode<false>, dim3(B), dim3(NTHREADS), 0, st, P);
+        FPC_LAUNCH(16, 16);
+#undef FPC_LAUNCH
     FPC_HIP(hipEventRecord(m->ev1, st));
     FPC_HIP(hipGetLastError());
     if (stamp) {  // diagnostic path only: synchronises
-        unsigned long long h[16];
+        unsigned long long h[192];
         FPC_HIP(hipStreamSynchronize(st));
         FPC_HIP(hipMemcpy(h, stamps.p, sizeof h, hipMemcpyDeviceToHost));
         const double n = (double)T * FPC_FRAME_SIZE - 17;
-        fprintf(stderr,
-                "[fpc stamps] cycles/sample  sampler wave0: window=%.0f GRU_B=%.0f (dot %.0f) FC=%.0f leaves=%.0f draw=%.0f wait=%.0f"
-                " | mat-vec wave4: gather=%.0f gates=%.0f leaf0=%.0f leaf1=%.0f tree=%.0f wait=%.0f\n",
-                h[0] / n, (h[1] + h[5]) / n, h[5] / n, h[2] / n, h[3] / n, h[4] / n, h[6] / n, h[13] / n, h[15] / n,
-                h[9] / n, h[10] / n, h[11] / n, h[14] / n);
+        for (int w = 0; w < 12; ++w) {
+            const unsigned long long* a = h + 16 * w;
+            fprintf(stderr,
+                    "[fpc stamps] cycles/sample %s wave %2d: work|wait  X..Y %.0f|%.0f  Y..Z1 %.0f|%.0f  Z1..Z2 %.0f|%.0f  "
+                    "(Z2..Z3 %.0f|%.0f)  ..X %.0f|%.0f\n",
+                    w < 4 ? "sampler" : "mat-vec", w, a[0] / n, a[1] / n, a[2] / n, a[3] / n, a[4] / n, a[5] / n, a[6] / n, a[7] / n, a[8] / n,
+                    a[9] / n);
+        }
     }
     m->timed = true;
     return FPC_OK;

@@ -30,6 +30,18 @@ constexpr int NTHREADS = 768;
 constexpr int NSAMP = 256;  // sampler lanes (waves 0-3)
 constexpr int NMAT = 512;   // mat-vec lanes (waves 4-11)
 constexpr int NMW = NMAT / 64;
+// stride between the partial-sum planes of consecutive lanes q of a row group: +4 floats so that the
+// lanes of one group (consecutive lanes of a wave) start their 16-byte stores in different bank groups
+constexpr int PSTRIDE = GA + 4;
+#ifndef FPC_NA
+#define FPC_NA 6  // sparse-product columns (of 16) computed under GRU_B ...
+#endif
+#ifndef FPC_NB
+#define FPC_NB 4  // ... and under the dual FC; the rest runs under the draw
+#endif
+#ifndef FPC_FCREG
+#define FPC_FCREG 1
+#endif
 
 struct DecodeParams {
     const float* tab;       // [3][256][384][3]  embedding x input-kernel tables, gate-interleaved
@@ -48,33 +60,34 @@ struct DecodeParams {
     const float* brn_a;      // [384]
     const float* brn_b;      // [16]
     const float* ulaw_tab;   // [256]
-    int wave_maxQ[NMW];
     unsigned long long* stamps;  // diagnostic only
     int dbg_const_rows;          // diagnostic only (STAMP build): gather fixed table rows
 };
 
 __device__ const float k_ulaw_thr[64] = FPC_ULAW_TABLE_INIT;
 
+// Field order matters: lane-indexed arrays sit in the first 64 KB (their base folds into the DS
+// instruction's offset field instead of a VGPR), the activation table at offset 0 (ds_read2 has 8-bit offsets).
 struct __attribute__((aligned(16))) DecodeLds {
+    float tt[FPC_TANH_TABLE_SIZE + 3];  // fpc_tanh_lut table (tanh(k/512)), built at kernel start
     float s1[RNN_A];
-    float rec[GA];
-    float diag[GA];
     float cfa[GA];            // this frame's GRU_A conditioning rows [z|r|h][unit]
-    float fc[9 * NSAMP * 4];  // dual-FC weights of node = lane, [chunk][lane][4]
+    float diag[GA];
     float brn_a[RNN_A];
-    float uframe[FPC_FRAME_SIZE];
+    float s2[RNN_B];
+    float hist[16];
+    // control block written by the winning lane / the LPC chain lane
+    unsigned o_sig, o_pred, o_exc, pad0;  // float offsets of the three table rows to gather next
+    float pred, partial, a1n, mem;
     float q[256];
     float p[256];
     float cand_pcm[256];
     float cand_pred[256];
     int cand_e[256];  // e_sig | e_pred << 8
     float ulaw_thr[64];  // fpc_lin2ulaw_tab table
-    float tt[FPC_TANH_TABLE_SIZE + 3];  // fpc_tanh_lut table (tanh(k/512)), built at kernel start
-    float s2[RNN_B];
-    float hist[16];
-    // control block written by the winning lane / the LPC chain lane
-    unsigned o_sig, o_pred, o_exc, pad0;  // float offsets of the three table rows to gather next
-    float pred, partial, a1n, mem;
+    float uframe[FPC_FRAME_SIZE];
+    float fc[9 * NSAMP * 4];  // dual-FC weights of node = lane, [chunk][lane][4]
+    float part[16 * PSTRIDE];      // partial row sums of the sparse product: [lane q of the row group][gate row]
 };
 
 // ---- DPP helpers (gfx9 DPP controls; invalid source lanes read 0) ----
@@ -122,6 +135,8 @@ __device__ __forceinline__ f2 mk2(float x, float y) {
     return r;
 }
 __device__ __forceinline__ f2 splat2(float v) { return mk2(v, v); }
+// pins a value where it is computed (the compiler would otherwise sink the whole computation to its only use)
+__device__ __forceinline__ void pin(f2& v) { asm volatile("" : "+v"(v)); }
 __device__ __forceinline__ f2 fma2(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }  // v_pk_fma_f32
 
 // opaque copy: the compiler recomputes what derives from it instead of hoisting + spilling
@@ -130,25 +145,39 @@ __device__ __forceinline__ unsigned opaque(unsigned v) {
     return v;
 }
 
-// STAMP=true is a diagnostic build (env FPC_DECODE_STAMPS=1): lane 0 of wave 0 (slots 0-7) and
-// of wave 4 (slots 8-15) of block 0 accumulate s_memtime deltas per phase; never timed.
+// zero-padded balanced (adjacent-pair) tree over the QP partial sums of one gate row; p0 = &part[0][row]
+template <int QP>
+__device__ __forceinline__ float part_tree(const float* p0) {
+    float v[QP];
+#pragma unroll
+    for (int k = 0; k < QP; ++k) v[k] = p0[k * PSTRIDE];
+#pragma unroll
+    for (int w = QP; w > 1; w >>= 1)
+#pragma unroll
+        for (int k = 0; k < w / 2; ++k) v[k] = v[2 * k] + v[2 * k + 1];
+    return v[0];
+}
+// STAMP=true is a diagnostic build (env FPC_DECODE_STAMPS=1): lane 0 of every wave w of block 0
+// (slots 16w..16w+9) accumulates s_memtime deltas: slot 2k = work before barrier k,
+// slot 2k+1 = wait at barrier k (k: 0 Y, 1 Z1, 2 Z2, 3 Z3, 4 X); perturbs the timing, never timed.
 #define FPC_STAMP(k)                                                  \
     if (STAMP) {                                                      \
         const unsigned long long now_ = __builtin_readcyclecounter(); \
         st_acc[k] += now_ - st_last;                                  \
         st_last = now_;                                               \
     }
-#define FPC_BARRIER()   \
-    FPC_STAMP(st_phase) \
-    __syncthreads();    \
-    FPC_STAMP(6)
+#define FPC_BARRIER(k)   \
+    FPC_STAMP(2 * (k))   \
+    __syncthreads();     \
+    FPC_STAMP(2 * (k) + 1)
 
-template <bool STAMP>
+// QZR / QN: partial-sum planes read per update/reset-gate row and per candidate-gate row (powers of two
+// >= the widest row group of those gates; planes no lane owns hold +0)
+template <bool STAMP, int QZR, int QN>
 __global__ __launch_bounds__(NTHREADS) void k_decode(const DecodeParams P) {
     __shared__ DecodeLds L;
-    unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long st_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long st_last = STAMP ? __builtin_readcyclecounter() : 0;
-    int st_phase = 0;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int b = blockIdx.x, T = P.T;
 
@@ -158,9 +187,9 @@ __global__ __launch_bounds__(NTHREADS) void k_decode(const DecodeParams P) {
         L.brn_a[i] = P.brn_a[i];
     }
     for (int i = tid; i < GA; i += NTHREADS) {
-        L.rec[i] = 0.0f;
         L.diag[i] = P.diag[i];
     }
+    for (int i = tid; i < 16 * PSTRIDE; i += NTHREADS) L.part[i] = 0.0f;  // slots no lane owns stay +0 (exact padding)
     if (tid < NSAMP) {
 #pragma unroll
         for (int j = 0; j < 36; ++j) {  // source index of slot j: channel pairs side by side -> v_pk_fma operands need no moves
@@ -202,11 +231,17 @@ __global__ __launch_bounds__(NTHREADS) void k_decode(const DecodeParams P) {
         }
         const unsigned colp_ = (unsigned)P.lane_meta[ml_];
         const unsigned metap_ = (unsigned)P.lane_meta[NMAT + ml_];
-        int maxQ = 1;
-#pragma unroll
-        for (int i = 0; i < NMW; ++i)
-            if (i == __builtin_amdgcn_readfirstlane(wave - 4)) maxQ = P.wave_maxQ[i];
         const bool gate_lane = ml_ < RNN_A;
+        // where this lane's 8 partial row sums go: part[lane q of the group][first row of the group]
+        // (kept as a finished LDS byte address: one VGPR, no per-sample address math; 0 = lane owns no group)
+        typedef __attribute__((address_space(3))) float lds_float;
+        unsigned paddr_ = 0u;
+        if ((metap_ >> 16) != 0) {
+            const int grp = (int)(metap_ >> 16) - 1;
+            const int gate = grp / (RNN_A / 8), rb = grp - gate * (RNN_A / 8);
+            paddr_ = (unsigned)(size_t)(lds_float*)&L.part[(int)(metap_ & 0xff) * PSTRIDE + gate * RNN_A + rb * 8];
+        }
+        paddr_ = opaque(paddr_);
 
         for (int fr = 0; fr < T; ++fr) {
             // voiced frames (pdf sharpening on) keep a separate parallel leaf phase: one more barrier
@@ -219,7 +254,6 @@ __global__ __launch_bounds__(NTHREADS) void k_decode(const DecodeParams P) {
             }
             for (int i = (fr == 0 ? FPC_LPC_ORDER + 1 : 0); i < FPC_FRAME_SIZE; ++i) {
                 // ---- X..Y: gather the three embedding-table rows, GRU_A gates ----
-                st_phase = 0;
                 if (gate_lane) {
                     const unsigned ml = opaque((unsigned)ml_);
                     struct F3 {
@@ -231,123 +265,90 @@ __global__ __launch_bounds__(NTHREADS) void k_decode(const DecodeParams P) {
                         ob = 384u * GA;
                         oc = 640u * GA;
                     }
-                    const F3 ta = *reinterpret_cast<const F3*>(P.tab + (oa + 3u * ml));
-                    const F3 tb = *reinterpret_cast<const F3*>(P.tab + (ob + 3u * ml));
-                    const F3 tc = *reinterpret_cast<const F3*>(P.tab + (oc + 3u * ml));
-                    const float uz = L.rec[ml], ur = L.rec[RNN_A + ml], un = L.rec[2 * RNN_A + ml];
-                    const float cz = L.cfa[ml], cr = L.cfa[RNN_A + ml], cn = L.cfa[2 * RNN_A + ml];
-                    const float brn = L.brn_a[ml];
+                    // uniform base + 32-bit byte offset (the global_load saddr form: no 64-bit VALU address math)
+                    const char* tabc = reinterpret_cast<const char*>(P.tab);
+                    const F3 ta = *reinterpret_cast<const F3*>(tabc + (size_t)((oa + 3u * ml) * 4u));
+                    const F3 tb = *reinterpret_cast<const F3*>(tabc + (size_t)((ob + 3u * ml) * 4u));
+                    const F3 tc = *reinterpret_cast<const F3*>(tabc + (size_t)((oc + 3u * ml) * 4u));
+                    // while the gather is in flight: recurrent terms of the three rows of unit ml =
+                    // diagonal + tree over the row group's partial sums (written before barrier X)
                     const float h_own = L.s1[ml];
+                    const float unb =
+                        fmaf(L.diag[2 * RNN_A + ml], h_own, part_tree<QN>(&L.part[2 * RNN_A + ml])) + L.brn_a[ml];
+                    __builtin_amdgcn_sched_barrier(0);  // bounds the live registers next to the 128 weight VGPRs
+                    const float uz = fmaf(L.diag[ml], h_own, part_tree<QZR>(&L.part[ml]));
+                    const float ur = fmaf(L.diag[RNN_A + ml], h_own, part_tree<QZR>(&L.part[RNN_A + ml]));
+                    const float cz = L.cfa[ml], cr = L.cfa[RNN_A + ml], cn = L.cfa[2 * RNN_A + ml];
                     const float gz = ((ta.x + tb.x) + tc.x) + cz;
                     const float gr = ((ta.y + tb.y) + tc.y) + cr;
                     const float gn = ((ta.z + tb.z) + tc.z) + cn;
-                    if (STAMP) {
-                        asm volatile("" ::"v"(gz), "v"(gr), "v"(gn));
-                        FPC_STAMP(5)
-                    }
                     const float z = fpc_sigmoid_lut(L.tt, gz + uz);
                     const float r = fpc_sigmoid_lut(L.tt, gr + ur);
-                    const float n = fpc_tanh_lut(L.tt, fmaf(r, un + brn, gn));
+                    const float n = fpc_tanh_lut(L.tt, fmaf(r, unb, gn));
                     const float h_new = fmaf(z, h_own - n, n);
                     L.s1[ml] = h_new;
-                    if (STAMP) {
-                        asm volatile("" ::"v"(h_new));
-                        FPC_STAMP(7)
-                    }
                 }
-                FPC_BARRIER()  // Y
-                // ---- Y..Z1: leaf 0 ----
-                st_phase = 1;
-                f2 acc[4];
-                {
-                    const unsigned colp = opaque(colp_);
-                    const float4 ha = *reinterpret_cast<const float4*>(&L.s1[(colp & 0xff) * 4]);
-                    const float4 hb = *reinterpret_cast<const float4*>(&L.s1[((colp >> 8) & 0xff) * 4]);
-                    const float hv[8] = {ha.x, ha.y, ha.z, ha.w, hb.x, hb.y, hb.z, hb.w};
+                FPC_BARRIER(0)  // Y
+                // ---- the sparse product of s1' with this lane's 4 blocks (16 columns of 8 rows), sliced under
+                //      the sampler phases: FPC_NA columns under GRU_B, FPC_NB under the dual FC, the rest and the
+                //      store of the partial sums under the draw ----
+                f2 acc[4], a[4];
+                float hv0[8], hv1[8];
 #pragma unroll
-                    for (int rp = 0; rp < 4; ++rp) acc[rp] = splat2(0.0f);
-#pragma unroll
-                    for (int bc = 0; bc < 8; ++bc)
-#pragma unroll
-                        for (int rp = 0; rp < 4; ++rp) acc[rp] = fma2(w2[bc * 4 + rp], splat2(hv[bc]), acc[rp]);
-                }
-                // leaf 1, first (in-lane) tree level
-                {
-                    const unsigned colp = opaque(colp_);
-                    const float4 hc = *reinterpret_cast<const float4*>(&L.s1[((colp >> 16) & 0xff) * 4]);
-                    const float4 hd = *reinterpret_cast<const float4*>(&L.s1[(colp >> 24) * 4]);
-                    const float hv[8] = {hc.x, hc.y, hc.z, hc.w, hd.x, hd.y, hd.z, hd.w};
-                    f2 a[4];
-#pragma unroll
-                    for (int rp = 0; rp < 4; ++rp) a[rp] = splat2(0.0f);
-#pragma unroll
-                    for (int bc = 0; bc < 8; ++bc)
-#pragma unroll
-                        for (int rp = 0; rp < 4; ++rp) a[rp] = fma2(w2[32 + bc * 4 + rp], splat2(hv[bc]), a[rp]);
-#pragma unroll
-                    for (int rp = 0; rp < 4; ++rp) acc[rp] = acc[rp] + a[rp];
-                }
-                FPC_BARRIER()  // Z1
-                // ---- Z1..Z2: cross-lane tree (row-local DPP) ----
-                st_phase = 2;
-                const unsigned metap = opaque(metap_);
-                {
-                    const int lq = (int)(metap & 0xff), lQ = (int)((metap >> 8) & 0xff);
-    // acc += take ? neighbour : 0, as fma(neighbour, 1.0|0.0, acc): exact, one v_fmac_f32_dpp per row
-#define FPC_FMAC_DPP(S, A) \
-    asm volatile("v_fmac_f32_dpp %0, %0, %1 row_shl:" #S " row_mask:0xf bank_mask:0xf bound_ctrl:1" : "+v"(A) : "v"(take))
-#define FPC_TREE_LEVEL(S)                                                  \
-    if (maxQ > S) {                                                        \
-        const float take = (lq + S < lQ) ? 1.0f : 0.0f;                    \
-        float a0_ = acc[0].x, a1_ = acc[0].y, a2_ = acc[1].x, a3_ = acc[1].y, a4_ = acc[2].x, a5_ = acc[2].y, \
-              a6_ = acc[3].x, a7_ = acc[3].y;                              \
-        asm volatile("s_nop 1" ::"v"(a0_), "v"(take));                     \
-        FPC_FMAC_DPP(S, a0_); FPC_FMAC_DPP(S, a1_); FPC_FMAC_DPP(S, a2_); FPC_FMAC_DPP(S, a3_); \
-        FPC_FMAC_DPP(S, a4_); FPC_FMAC_DPP(S, a5_); FPC_FMAC_DPP(S, a6_); FPC_FMAC_DPP(S, a7_); \
-        acc[0] = mk2(a0_, a1_); acc[1] = mk2(a2_, a3_); acc[2] = mk2(a4_, a5_); acc[3] = mk2(a6_, a7_); \
+                for (int rp = 0; rp < 4; ++rp) acc[rp] = a[rp] = splat2(0.0f);
+#define FPC_COLS(FROM, TO)                                                                                        \
+    _Pragma("unroll") for (int bc = (FROM); bc < (TO); ++bc) {                                                    \
+        if (bc == 0 || (bc == (FROM) && bc < 8 && false)) {                                                       \
+            const unsigned colp = opaque(colp_);                                                                  \
+            const float4 ha = *reinterpret_cast<const float4*>(&L.s1[(colp & 0xff) * 4]);                         \
+            const float4 hb = *reinterpret_cast<const float4*>(&L.s1[((colp >> 8) & 0xff) * 4]);                  \
+            hv0[0] = ha.x, hv0[1] = ha.y, hv0[2] = ha.z, hv0[3] = ha.w;                                           \
+            hv0[4] = hb.x, hv0[5] = hb.y, hv0[6] = hb.z, hv0[7] = hb.w;                                           \
+        }                                                                                                         \
+        if (bc == 8) {                                                                                            \
+            const unsigned colp = opaque(colp_);                                                                  \
+            const float4 hc = *reinterpret_cast<const float4*>(&L.s1[((colp >> 16) & 0xff) * 4]);                 \
+            const float4 hd = *reinterpret_cast<const float4*>(&L.s1[(colp >> 24) * 4]);                          \
+            hv1[0] = hc.x, hv1[1] = hc.y, hv1[2] = hc.z, hv1[3] = hc.w;                                           \
+            hv1[4] = hd.x, hv1[5] = hd.y, hv1[6] = hd.z, hv1[7] = hd.w;                                           \
+        }                                                                                                         \
+        _Pragma("unroll") for (int rp = 0; rp < 4; ++rp) {                                                        \
+            if (bc < 8)                                                                                           \
+                acc[rp] = fma2(w2[bc * 4 + rp], splat2(hv0[bc]), acc[rp]);                                        \
+            else                                                                                                  \
+                a[rp] = fma2(w2[bc * 4 + rp], splat2(hv1[bc - 8]), a[rp]);                                        \
+        }                                                                                                         \
+    }                                                                                                             \
+    _Pragma("unroll") for (int rp = 0; rp < 4; ++rp) {                                                            \
+        pin(acc[rp]);                                                                                             \
+        pin(a[rp]);                                                                                               \
     }
-                    FPC_TREE_LEVEL(1)
-                    FPC_TREE_LEVEL(2)
-                    FPC_TREE_LEVEL(4)
-                    FPC_TREE_LEVEL(8)
-#undef FPC_TREE_LEVEL
-#undef FPC_FMAC_DPP
-                }
-                FPC_BARRIER()  // Z2
-                // ---- Z2..X: diagonal term, publish rec ----
-                st_phase = 3;
-                {
-                    const int lq = (int)(metap & 0xff);
-                    if ((metap >> 16) != 0 && lq == 0) {
-                        const int grp = (int)(metap >> 16) - 1;
-                        const int gate = grp / (RNN_A / 8), rb = grp - gate * (RNN_A / 8);
-                        const int row0 = gate * RNN_A + rb * 8;
-                        const float4 d0 = *reinterpret_cast<const float4*>(&L.diag[row0]);
-                        const float4 d1 = *reinterpret_cast<const float4*>(&L.diag[row0 + 4]);
-                        const float4 s0 = *reinterpret_cast<const float4*>(&L.s1[rb * 8]);
-                        const float4 s4 = *reinterpret_cast<const float4*>(&L.s1[rb * 8 + 4]);
-                        float4 o0, o1;
-                        o0.x = fmaf(d0.x, s0.x, acc[0].x);
-                        o0.y = fmaf(d0.y, s0.y, acc[0].y);
-                        o0.z = fmaf(d0.z, s0.z, acc[1].x);
-                        o0.w = fmaf(d0.w, s0.w, acc[1].y);
-                        o1.x = fmaf(d1.x, s4.x, acc[2].x);
-                        o1.y = fmaf(d1.y, s4.y, acc[2].y);
-                        o1.z = fmaf(d1.z, s4.z, acc[3].x);
-                        o1.w = fmaf(d1.w, s4.w, acc[3].y);
-                        *reinterpret_cast<float4*>(&L.rec[row0]) = o0;
-                        *reinterpret_cast<float4*>(&L.rec[row0 + 4]) = o1;
-                    }
-                }
+                FPC_COLS(0, FPC_NA)
+                FPC_BARRIER(1)  // Z1
+                FPC_COLS(FPC_NA, FPC_NA + FPC_NB)
+                FPC_BARRIER(2)  // Z2
                 if (voiced) {
-                    FPC_BARRIER()  // Z3 (voiced frames only)
+                    FPC_BARRIER(3)  // Z3 (voiced frames only: the sampler waves' leaf phase ends here)
                 }
-                st_phase = 4;
-                FPC_BARRIER()  // X
+                FPC_COLS(FPC_NA + FPC_NB, 16)
+#undef FPC_COLS
+#pragma unroll
+                for (int rp = 0; rp < 4; ++rp) acc[rp] = acc[rp] + a[rp];  // the in-lane tree level
+                if (paddr_ != 0u) {  // publish this lane's 8 partial row sums
+                    typedef float v4f __attribute__((ext_vector_type(4)));
+                    typedef __attribute__((address_space(3))) v4f lds_v4f;
+                    lds_v4f* pp = (lds_v4f*)(size_t)paddr_;  // 32-byte aligned: two ds_write_b128
+                    v4f lo, hi;
+                    lo.x = acc[0].x, lo.y = acc[0].y, lo.z = acc[1].x, lo.w = acc[1].y;
+                    hi.x = acc[2].x, hi.y = acc[2].y, hi.z = acc[3].x, hi.w = acc[3].y;
+                    pp[0] = lo;
+                    pp[1] = hi;
+                }
+                FPC_BARRIER(4)  // X
             }
         }
-        if (STAMP && blockIdx.x == 0 && tid == NSAMP)
-            for (int k = 0; k < 8; ++k) P.stamps[8 + k] = st_acc[k];
+        if (STAMP && blockIdx.x == 0 && lane == 0)
+            for (int k = 0; k < 10; ++k) P.stamps[16 * wave + k] = st_acc[k];
     } else {
         // =========================== sampler role ===========================
         __builtin_amdgcn_s_setprio(3);  // the sample-to-sample critical path lives in these waves
@@ -366,6 +367,14 @@ __global__ __launch_bounds__(NTHREADS) void k_decode(const DecodeParams P) {
         const float ub0 = P.lane_ub[sl], ub1 = P.lane_ub[NSAMP + sl], ub2 = P.lane_ub[2 * NSAMP + sl];
         const float brnb = P.brn_b[u];
         const float my_ulaw = P.ulaw_tab[sl];
+#if FPC_FCREG
+        // dual-FC weights of tree node sl: 16 (channel 0, channel 1) pairs, then bias pair and factor pair
+        f2 fcw[18];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) fcw[k] = mk2(P.lane_fc[k * NSAMP + sl], P.lane_fc[(16 + k) * NSAMP + sl]);
+        fcw[16] = mk2(P.lane_fc[32 * NSAMP + sl], P.lane_fc[33 * NSAMP + sl]);
+        fcw[17] = mk2(P.lane_fc[34 * NSAMP + sl], P.lane_fc[35 * NSAMP + sl]);
+#endif
         float s2_own = 0.0f;  // state of unit u, replicated over the 16 lanes of its row
 
         for (int fr = 0; fr < T; ++fr) {
@@ -383,7 +392,6 @@ __global__ __launch_bounds__(NTHREADS) void k_decode(const DecodeParams P) {
                 const int t = fr * FPC_FRAME_SIZE + i;
                 // ---- X..Y (the mat-vec waves gather + gate): everything that only needs the
                 //      previous draw: GRU_B recurrent part, LPC history chain, leaf candidates ----
-                st_phase = 0;
                 const float s2k = L.s2[kl];
                 float ub_z = ub0 * s2k, ub_r = ub1 * s2k, ub_n = ub2 * s2k;
                 row_bfly16x3(ub_z, ub_r, ub_n);
@@ -402,9 +410,8 @@ __global__ __launch_bounds__(NTHREADS) void k_decode(const DecodeParams P) {
                     L.cand_pred[sl] = cpred;
                     L.cand_e[sl] = fpc_lin2ulaw_tab(cpcm, L.ulaw_thr) | (fpc_lin2ulaw_tab(cpred, L.ulaw_thr) << 8);
                 }
-                FPC_BARRIER()  // Y
+                FPC_BARRIER(0)  // Y
                 // ---- Y..Z1: GRU_B (row of 16 lanes = unit, lane = 4 leaves of 6 inputs) ----
-                st_phase = 1;
                 {
                     const unsigned klv = opaque((unsigned)kl);
                     f2 lzr[4];
@@ -431,19 +438,31 @@ __global__ __launch_bounds__(NTHREADS) void k_decode(const DecodeParams P) {
                     a3[1] = tzr.y;
                     a3[2] = (ln[0] + ln[1]) + (ln[2] + ln[3]);
                     row_bfly16x3(a3[0], a3[1], a3[2]);
-                    if (STAMP) {
-                        asm volatile("" ::"v"(a3[0]), "v"(a3[1]), "v"(a3[2]));
-                        FPC_STAMP(5)
-                    }
                     const float z = fpc_sigmoid_lut(L.tt, (a3[0] + cfb_z) + ub_z);
                     const float r = fpc_sigmoid_lut(L.tt, (a3[1] + cfb_r) + ub_r);
                     const float n = fpc_tanh_lut(L.tt, fmaf(r, ub_n + brnb, a3[2] + cfb_n));
                     s2_own = fmaf(z, s2_own - n, n);
                     if (kl == 0) L.s2[u] = s2_own;
                 }
-                FPC_BARRIER()  // Z1
+                FPC_BARRIER(1)  // Z1
                 // ---- Z1..Z2: dual FC of tree node `sl` ----
-                st_phase = 2;
+#if FPC_FCREG
+                {
+                    const unsigned slv = opaque((unsigned)sl);
+                    f2 a01 = fcw[16];  // both channels advance together
+#pragma unroll
+                    for (int k4 = 0; k4 < 4; ++k4) {
+                        const float4 sv = *reinterpret_cast<const float4*>(&L.s2[4 * k4]);
+                        a01 = fma2(fcw[4 * k4], splat2(sv.x), a01);
+                        a01 = fma2(fcw[4 * k4 + 1], splat2(sv.y), a01);
+                        a01 = fma2(fcw[4 * k4 + 2], splat2(sv.z), a01);
+                        a01 = fma2(fcw[4 * k4 + 3], splat2(sv.w), a01);
+                    }
+                    const float t0 = fpc_tanh_lut(L.tt, a01.x), t1 = fpc_tanh_lut(L.tt, a01.y);
+                    const float v = fmaf(fcw[17].y, t1, fcw[17].x * t0);
+                    L.q[slv] = fpc_sigmoid_lut(L.tt, v);
+                }
+#else
                 {
                     const unsigned slv = opaque((unsigned)sl);
                     float4 fw[9];
@@ -463,11 +482,11 @@ __global__ __launch_bounds__(NTHREADS) void k_decode(const DecodeParams P) {
                     const float v = fmaf(fw[8].w, t1, fw[8].z * t0);
                     L.q[slv] = fpc_sigmoid_lut(L.tt, v);
                 }
-                FPC_BARRIER()  // Z2
+#endif
+                FPC_BARRIER(2)  // Z2
                 float4 p4;  // wave 0: probabilities of leaves 4*lane .. 4*lane+3
                 if (shape_e > 0.0f) {
                     // ---- voiced frame, Z2..Z3: leaf probability (MSB first) + sharpening, 256 lanes ----
-                    st_phase = 3;
                     {
                         const unsigned slv = opaque((unsigned)sl);
                         float p = 1.0f;
@@ -478,13 +497,11 @@ __global__ __launch_bounds__(NTHREADS) void k_decode(const DecodeParams P) {
                         }
                         L.p[slv] = fpc_shape_pow(p, shape_e);
                     }
-                    FPC_BARRIER()  // Z3
-                    st_phase = 4;
+                    FPC_BARRIER(3)  // Z3
                     if (wave == 0) p4 = *reinterpret_cast<const float4*>(&L.p[4 * lane]);
                 } else if (wave == 0) {
                     // ---- unvoiced frame: the drawing wave builds its 4 leaves per lane straight from
                     //      q (same MSB-first product per leaf); no separate leaf phase, no barrier ----
-                    st_phase = 4;
                     const unsigned lv = opaque((unsigned)lane);
                     float pre = 1.0f;
 #pragma unroll
@@ -545,11 +562,11 @@ __global__ __launch_bounds__(NTHREADS) void k_decode(const DecodeParams P) {
                         out[t] = fpc_pcm16(mem);
                     }
                 }
-                FPC_BARRIER()  // X
+                FPC_BARRIER(4)  // X
             }
         }
-        if (STAMP && blockIdx.x == 0 && tid == 0)
-            for (int k = 0; k < 8; ++k) P.stamps[k] = st_acc[k];
+        if (STAMP && blockIdx.x == 0 && lane == 0)
+            for (int k = 0; k < 10; ++k) P.stamps[16 * wave + k] = st_acc[k];
     }
 }
 #undef FPC_BARRIER
