@@ -39,9 +39,6 @@ constexpr int PSTRIDE = GA + 4;
 #ifndef FPC_NB
 #define FPC_NB 4  // ... and under the dual FC; the rest runs under the draw
 #endif
-#ifndef FPC_FCREG
-#define FPC_FCREG 1
-#endif
 
 struct DecodeParams {
     const float* tab;       // [3][256][384][3]  embedding x input-kernel tables, gate-interleaved
@@ -69,7 +66,7 @@ __device__ const float k_ulaw_thr[64] = FPC_ULAW_TABLE_INIT;
 // Field order matters: lane-indexed arrays sit in the first 64 KB (their base folds into the DS
 // instruction's offset field instead of a VGPR), the activation table at offset 0 (ds_read2 has 8-bit offsets).
 struct __attribute__((aligned(16))) DecodeLds {
-    float tt[FPC_TANH_TABLE_SIZE + 3];  // fpc_tanh_lut table (tanh(k/512)), built at kernel start
+    float2 tt[FPC_TANH_TABLE_SIZE - 1];  // fpc_tanh_lut table as (T[k], T[k+1] - T[k]) pairs, built at kernel start
     float s1[RNN_A];
     float cfa[GA];            // this frame's GRU_A conditioning rows [z|r|h][unit]
     float diag[GA];
@@ -78,15 +75,12 @@ struct __attribute__((aligned(16))) DecodeLds {
     float hist[16];
     // control block written by the winning lane / the LPC chain lane
     unsigned o_sig, o_pred, o_exc, pad0;  // float offsets of the three table rows to gather next
-    float pred, partial, a1n, mem;
+    float pred, pad1, pad2, pad3;
     float q[256];
     float p[256];
-    float cand_pcm[256];
-    float cand_pred[256];
-    int cand_e[256];  // e_sig | e_pred << 8
+    float4 cand[256];  // per leaf: (pcm, next prediction, bits of e_sig | e_pred << 8, -) if it wins the draw
     float ulaw_thr[64];  // fpc_lin2ulaw_tab table
     float uframe[FPC_FRAME_SIZE];
-    float fc[9 * NSAMP * 4];  // dual-FC weights of node = lane, [chunk][lane][4]
     float part[16 * PSTRIDE];      // partial row sums of the sparse product: [lane q of the row group][gate row]
 };
 
@@ -145,6 +139,19 @@ __device__ __forceinline__ unsigned opaque(unsigned v) {
     return v;
 }
 
+// fpc_tanh_lut_scaled / fpc_tanh_lut / fpc_sigmoid_lut (include/fpc_numerics.h) on the pair table: one
+// ds_read_b64, v_fract for the interpolation weight (u - trunc(u) exactly, u >= 0); bit-identical results
+__device__ __forceinline__ float lut_scaled(const float2* T2, float x, float scale) {
+    const float u = fminf(fabsf(x) * scale, 4095.99976f);
+    const float f = __builtin_amdgcn_fractf(u);
+    const float2 td = T2[(uint32_t)u];
+    return copysignf(fmaf(f, td.y, td.x), x);
+}
+__device__ __forceinline__ float lut_tanh(const float2* T2, float x) { return lut_scaled(T2, x, 512.0f); }
+__device__ __forceinline__ float lut_sigmoid(const float2* T2, float x) {
+    return fmaf(0.5f, lut_scaled(T2, x, 256.0f), 0.5f);
+}
+
 // zero-padded balanced (adjacent-pair) tree over the QP partial sums of one gate row; p0 = &part[0][row]
 template <int QP>
 __device__ __forceinline__ float part_tree(const float* p0) {
@@ -190,15 +197,11 @@ __global__ __launch_bounds__(NTHREADS) void k_decode(const DecodeParams P) {
         L.diag[i] = P.diag[i];
     }
     for (int i = tid; i < 16 * PSTRIDE; i += NTHREADS) L.part[i] = 0.0f;  // slots no lane owns stay +0 (exact padding)
-    if (tid < NSAMP) {
-#pragma unroll
-        for (int j = 0; j < 36; ++j) {  // source index of slot j: channel pairs side by side -> v_pk_fma operands need no moves
-            const int src = j < 32 ? ((j & 1) * 16 + (j >> 1)) : j;
-            L.fc[((j >> 2) * NSAMP + tid) * 4 + (j & 3)] = P.lane_fc[src * NSAMP + tid];
-        }
-    }
     if (tid < 64) L.ulaw_thr[tid] = k_ulaw_thr[tid];
-    for (int k = tid; k < FPC_TANH_TABLE_SIZE; k += NTHREADS) L.tt[k] = fpc_tanh_table_entry(k);
+    for (int k = tid; k < FPC_TANH_TABLE_SIZE - 1; k += NTHREADS) {
+        const float t0 = fpc_tanh_table_entry(k), t1 = fpc_tanh_table_entry(k + 1);
+        L.tt[k] = make_float2(t0, t1 - t0);
+    }
     if (tid < RNN_B) {
         L.s2[tid] = 0.0f;
         L.hist[tid] = 0.0f;
@@ -208,9 +211,6 @@ __global__ __launch_bounds__(NTHREADS) void k_decode(const DecodeParams P) {
         L.o_pred = (256u + 128u) * GA;
         L.o_exc = (512u + 128u) * GA;
         L.pred = -0.0f;
-        L.partial = 0.0f;
-        L.a1n = 0.0f;
-        L.mem = 0.0f;
     }
     int16_t* out = P.pcm + (size_t)b * T * FPC_FRAME_SIZE;
     if (tid < FPC_LPC_ORDER + 1) out[tid] = 0;  // test_lpcnet.py skips order+1 samples
@@ -282,9 +282,9 @@ __global__ __launch_bounds__(NTHREADS) void k_decode(const DecodeParams P) {
                     const float gz = ((ta.x + tb.x) + tc.x) + cz;
                     const float gr = ((ta.y + tb.y) + tc.y) + cr;
                     const float gn = ((ta.z + tb.z) + tc.z) + cn;
-                    const float z = fpc_sigmoid_lut(L.tt, gz + uz);
-                    const float r = fpc_sigmoid_lut(L.tt, gr + ur);
-                    const float n = fpc_tanh_lut(L.tt, fmaf(r, unb, gn));
+                    const float z = lut_sigmoid(L.tt, gz + uz);
+                    const float r = lut_sigmoid(L.tt, gr + ur);
+                    const float n = lut_tanh(L.tt, fmaf(r, unb, gn));
                     const float h_new = fmaf(z, h_own - n, n);
                     L.s1[ml] = h_new;
                 }
@@ -355,26 +355,28 @@ __global__ __launch_bounds__(NTHREADS) void k_decode(const DecodeParams P) {
         const int sl = tid;                    // 0..255
         const int u = sl >> 4, kl = sl & 15;   // GRU_B: unit, 24-input slice
         const unsigned long long seed = P.seeds[b];
-        // GRU_B input weights of this lane's 24 inputs: (z,r) gate pairs advance with one v_pk_fma_f32 per
-        // input (h broadcast), the candidate gate with plain fmas
-        f2 wzr[24];
-        float wn[24];
+        // GRU_B input weights of this lane's 24 inputs (lane_wb[gate*24 + k] = weight of input 24*kl + k):
+        // wB[g][m][h] pairs the weights of inputs 4m+2h and 4m+2h+1, i.e. of the leaf pair (2h, 2h+1) at
+        // step m: one v_pk_fma_f32 per half of a float4 of state advances two leaves of one gate
+        f2 wB[3][6][2];
 #pragma unroll
-        for (int k = 0; k < 24; ++k) {
-            wzr[k] = mk2(P.lane_wb[k * NSAMP + sl], P.lane_wb[(24 + k) * NSAMP + sl]);
-            wn[k] = P.lane_wb[(48 + k) * NSAMP + sl];
-        }
+        for (int g = 0; g < 3; ++g)
+#pragma unroll
+            for (int m = 0; m < 6; ++m)
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+                    wB[g][m][h] = mk2(P.lane_wb[(g * 24 + 4 * m + 2 * h) * NSAMP + sl],
+                                      P.lane_wb[(g * 24 + 4 * m + 2 * h + 1) * NSAMP + sl]);
         const float ub0 = P.lane_ub[sl], ub1 = P.lane_ub[NSAMP + sl], ub2 = P.lane_ub[2 * NSAMP + sl];
         const float brnb = P.brn_b[u];
         const float my_ulaw = P.ulaw_tab[sl];
-#if FPC_FCREG
         // dual-FC weights of tree node sl: 16 (channel 0, channel 1) pairs, then bias pair and factor pair
         f2 fcw[18];
 #pragma unroll
         for (int k = 0; k < 16; ++k) fcw[k] = mk2(P.lane_fc[k * NSAMP + sl], P.lane_fc[(16 + k) * NSAMP + sl]);
         fcw[16] = mk2(P.lane_fc[32 * NSAMP + sl], P.lane_fc[33 * NSAMP + sl]);
         fcw[17] = mk2(P.lane_fc[34 * NSAMP + sl], P.lane_fc[35 * NSAMP + sl]);
-#endif
+        float mem = 0.0f;     // de-emphasis state (tracked by every lane of the drawing wave)
         float s2_own = 0.0f;  // state of unit u, replicated over the 16 lanes of its row
 
         for (int fr = 0; fr < T; ++fr) {
@@ -406,109 +408,86 @@ __global__ __launch_bounds__(NTHREADS) void k_decode(const DecodeParams P) {
                     // what the control block becomes if leaf `sl` wins this sample's draw
                     const float cpcm = L.pred + my_ulaw;
                     const float cpred = -fmaf(a0, cpcm, part);
-                    L.cand_pcm[sl] = cpcm;
-                    L.cand_pred[sl] = cpred;
-                    L.cand_e[sl] = fpc_lin2ulaw_tab(cpcm, L.ulaw_thr) | (fpc_lin2ulaw_tab(cpred, L.ulaw_thr) << 8);
+                    L.cand[sl] = make_float4(
+                        cpcm, cpred,
+                        __int_as_float(fpc_lin2ulaw_tab(cpcm, L.ulaw_thr) | (fpc_lin2ulaw_tab(cpred, L.ulaw_thr) << 8)), 0.0f);
                 }
                 FPC_BARRIER(0)  // Y
-                // ---- Y..Z1: GRU_B (row of 16 lanes = unit, lane = 4 leaves of 6 inputs) ----
+                // ---- Y..Z1: GRU_B (row of 16 lanes = unit; lane = 24 inputs = 4 leaves of 6, leaf of
+                //      float4 component c takes inputs c + 4m) ----
                 {
                     const unsigned klv = opaque((unsigned)kl);
-                    f2 lzr[4];
-                    float ln[4];
+                    f2 acc[3][2];
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {  // canonical leaf j of this lane: 6 inputs
-                        const float2 h0 = *reinterpret_cast<const float2*>(&L.s1[24 * klv + 6 * j]);
-                        const float2 h1 = *reinterpret_cast<const float2*>(&L.s1[24 * klv + 6 * j + 2]);
-                        const float2 h2 = *reinterpret_cast<const float2*>(&L.s1[24 * klv + 6 * j + 4]);
-                        const float hv[6] = {h0.x, h0.y, h1.x, h1.y, h2.x, h2.y};
-                        f2 azr = splat2(0.0f);
-                        float an = 0.0f;
+                    for (int g = 0; g < 3; ++g) acc[g][0] = acc[g][1] = splat2(0.0f);
 #pragma unroll
-                        for (int k = 0; k < 6; ++k) {
-                            azr = fma2(wzr[j * 6 + k], splat2(hv[k]), azr);
-                            an = fmaf(wn[j * 6 + k], hv[k], an);
+                    for (int m = 0; m < 6; ++m) {
+                        const float4 h4 = *reinterpret_cast<const float4*>(&L.s1[24 * klv + 4 * m]);
+#pragma unroll
+                        for (int g = 0; g < 3; ++g) {
+                            acc[g][0] = fma2(wB[g][m][0], mk2(h4.x, h4.y), acc[g][0]);
+                            acc[g][1] = fma2(wB[g][m][1], mk2(h4.z, h4.w), acc[g][1]);
                         }
-                        lzr[j] = azr;
-                        ln[j] = an;
                     }
-                    const f2 tzr = (lzr[0] + lzr[1]) + (lzr[2] + lzr[3]);
                     float a3[3];
-                    a3[0] = tzr.x;
-                    a3[1] = tzr.y;
-                    a3[2] = (ln[0] + ln[1]) + (ln[2] + ln[3]);
+#pragma unroll
+                    for (int g = 0; g < 3; ++g) {  // (leaf x + leaf z) + (leaf y + leaf w)
+                        const f2 pr = acc[g][0] + acc[g][1];
+                        a3[g] = pr.x + pr.y;
+                    }
                     row_bfly16x3(a3[0], a3[1], a3[2]);
-                    const float z = fpc_sigmoid_lut(L.tt, (a3[0] + cfb_z) + ub_z);
-                    const float r = fpc_sigmoid_lut(L.tt, (a3[1] + cfb_r) + ub_r);
-                    const float n = fpc_tanh_lut(L.tt, fmaf(r, ub_n + brnb, a3[2] + cfb_n));
+                    const float z = lut_sigmoid(L.tt, (a3[0] + cfb_z) + ub_z);
+                    const float r = lut_sigmoid(L.tt, (a3[1] + cfb_r) + ub_r);
+                    const float n = lut_tanh(L.tt, fmaf(r, ub_n + brnb, a3[2] + cfb_n));
                     s2_own = fmaf(z, s2_own - n, n);
                     if (kl == 0) L.s2[u] = s2_own;
                 }
                 FPC_BARRIER(1)  // Z1
                 // ---- Z1..Z2: dual FC of tree node `sl` ----
-#if FPC_FCREG
                 {
                     const unsigned slv = opaque((unsigned)sl);
-                    f2 a01 = fcw[16];  // both channels advance together
+                    f2 a01 = fcw[16], b01 = splat2(0.0f);  // both channels advance together; even / odd inputs
 #pragma unroll
                     for (int k4 = 0; k4 < 4; ++k4) {
                         const float4 sv = *reinterpret_cast<const float4*>(&L.s2[4 * k4]);
                         a01 = fma2(fcw[4 * k4], splat2(sv.x), a01);
-                        a01 = fma2(fcw[4 * k4 + 1], splat2(sv.y), a01);
+                        b01 = fma2(fcw[4 * k4 + 1], splat2(sv.y), b01);
                         a01 = fma2(fcw[4 * k4 + 2], splat2(sv.z), a01);
-                        a01 = fma2(fcw[4 * k4 + 3], splat2(sv.w), a01);
+                        b01 = fma2(fcw[4 * k4 + 3], splat2(sv.w), b01);
                     }
-                    const float t0 = fpc_tanh_lut(L.tt, a01.x), t1 = fpc_tanh_lut(L.tt, a01.y);
+                    a01 = a01 + b01;
+                    const float t0 = lut_tanh(L.tt, a01.x), t1 = lut_tanh(L.tt, a01.y);
                     const float v = fmaf(fcw[17].y, t1, fcw[17].x * t0);
-                    L.q[slv] = fpc_sigmoid_lut(L.tt, v);
+                    L.q[slv] = lut_sigmoid(L.tt, v);
                 }
-#else
-                {
-                    const unsigned slv = opaque((unsigned)sl);
-                    float4 fw[9];
-#pragma unroll
-                    for (int c = 0; c < 9; ++c) fw[c] = *reinterpret_cast<const float4*>(&L.fc[(c * NSAMP + slv) * 4]);
-                    f2 a01 = mk2(fw[8].x, fw[8].y);  // both channels advance together
-#pragma unroll
-                    for (int k4 = 0; k4 < 4; ++k4) {
-                        const float4 sv = *reinterpret_cast<const float4*>(&L.s2[4 * k4]);
-                        a01 = fma2(mk2(fw[2 * k4].x, fw[2 * k4].y), splat2(sv.x), a01);
-                        a01 = fma2(mk2(fw[2 * k4].z, fw[2 * k4].w), splat2(sv.y), a01);
-                        a01 = fma2(mk2(fw[2 * k4 + 1].x, fw[2 * k4 + 1].y), splat2(sv.z), a01);
-                        a01 = fma2(mk2(fw[2 * k4 + 1].z, fw[2 * k4 + 1].w), splat2(sv.w), a01);
-                    }
-                    const float a0 = a01.x, a1 = a01.y;
-                    const float t0 = fpc_tanh_lut(L.tt, a0), t1 = fpc_tanh_lut(L.tt, a1);
-                    const float v = fmaf(fw[8].w, t1, fw[8].z * t0);
-                    L.q[slv] = fpc_sigmoid_lut(L.tt, v);
-                }
-#endif
                 FPC_BARRIER(2)  // Z2
                 float4 p4;  // wave 0: probabilities of leaves 4*lane .. 4*lane+3
                 if (shape_e > 0.0f) {
-                    // ---- voiced frame, Z2..Z3: leaf probability (MSB first) + sharpening, 256 lanes ----
+                    // ---- voiced frame, Z2..Z3: leaf probability + sharpening, 256 lanes ----
                     {
                         const unsigned slv = opaque((unsigned)sl);
-                        float p = 1.0f;
+                        float f[8];
 #pragma unroll
                         for (int j = 0; j < 8; ++j) {
                             const float qq = L.q[(1u << j) + (slv >> (8 - j))];
-                            p = p * (((slv >> (7 - j)) & 1u) ? qq : 1.0f - qq);
+                            f[j] = ((slv >> (7 - j)) & 1u) ? qq : 1.0f - qq;
                         }
+                        const float p = ((((f[0] * f[1]) * (f[2] * f[3])) * (f[4] * f[5])) * f[6]) * f[7];
                         L.p[slv] = fpc_shape_pow(p, shape_e);
                     }
                     FPC_BARRIER(3)  // Z3
                     if (wave == 0) p4 = *reinterpret_cast<const float4*>(&L.p[4 * lane]);
                 } else if (wave == 0) {
                     // ---- unvoiced frame: the drawing wave builds its 4 leaves per lane straight from
-                    //      q (same MSB-first product per leaf); no separate leaf phase, no barrier ----
+                    //      q (same product order per leaf); no separate leaf phase, no barrier ----
                     const unsigned lv = opaque((unsigned)lane);
-                    float pre = 1.0f;
+                    float f[6];
 #pragma unroll
                     for (int j = 0; j < 6; ++j) {
                         const float qq = L.q[(1u << j) + (lv >> (6 - j))];
-                        pre = pre * (((lv >> (5 - j)) & 1u) ? qq : 1.0f - qq);
+                        f[j] = ((lv >> (5 - j)) & 1u) ? qq : 1.0f - qq;
                     }
+                    const float pre = ((f[0] * f[1]) * (f[2] * f[3])) * (f[4] * f[5]);
                     const float q6 = L.q[64u + lv];
                     const float2 q7 = *reinterpret_cast<const float2*>(&L.q[128u + 2u * lv]);
                     const float lo = pre * (1.0f - q6), hi = pre * q6;
@@ -519,11 +498,13 @@ __global__ __launch_bounds__(NTHREADS) void k_decode(const DecodeParams P) {
                 }
                 // ---- (wave 0): normaliser, tail cut, scan, draw, publish ----
                 if (wave == 0) {
-                    float rs = row_bfly16((p4.x + p4.y) + (p4.z + p4.w));
-                    rs = add_bcast<DPP_BCAST15, 0xa>(rs);  // rows 1,3 += rows 0,2
-                    rs = add_bcast<DPP_BCAST31, 0xc>(rs);  // row 3 = (r2+r3)+(r0+r1): the balanced total
-                    const float S1 = lane_val(rs, 63);
-                    const float thr = 0.002f * S1;
+                    float thr = 0.002f;  // the tree pdf sums to 1 by construction: only sharpened pdfs are totalled
+                    if (shape_e > 0.0f) {
+                        float rs = row_bfly16((p4.x + p4.y) + (p4.z + p4.w));
+                        rs = add_bcast<DPP_BCAST15, 0xa>(rs);  // rows 1,3 += rows 0,2
+                        rs = add_bcast<DPP_BCAST31, 0xc>(rs);  // row 3 = (r2+r3)+(r0+r1): the balanced total
+                        thr = 0.002f * lane_val(rs, 63);
+                    }
                     float c0 = p4.x - thr, c1 = p4.y - thr, c2 = p4.z - thr, c3 = p4.w - thr;
                     c0 = c0 > 0.0f ? c0 : 0.0f;
                     c1 = c1 > 0.0f ? c1 : 0.0f;
@@ -548,17 +529,16 @@ __global__ __launch_bounds__(NTHREADS) void k_decode(const DecodeParams P) {
                     cnt = cnt > 3 ? 3 : cnt;
                     // the winning lane's result, made wave-uniform
                     const int exc = __builtin_amdgcn_readlane(4 * lane + cnt, lw);
-                    const int ce = L.cand_e[exc];
+                    const float4 cd = L.cand[exc];  // one broadcast read: what the control block becomes
+                    mem = fmaf(FPC_PREEMPH, mem, cd.x);
                     if (lane == lw) {
-                        const float cpcm = L.cand_pcm[exc];
+                        const int ce = __float_as_int(cd.z);
                         const unsigned es = (unsigned)(ce & 0xff), ep = 256u + (unsigned)(ce >> 8), ee = 512u + (unsigned)exc;
                         L.o_sig = (es << 10) + (es << 7);  // x GA (1152 = 1024 + 128)
                         L.o_pred = (ep << 10) + (ep << 7);
                         L.o_exc = (ee << 10) + (ee << 7);
-                        L.pred = L.cand_pred[exc];
-                        L.hist[t & 15] = cpcm;
-                        const float mem = fmaf(FPC_PREEMPH, L.mem, cpcm);
-                        L.mem = mem;
+                        L.pred = cd.y;
+                        L.hist[t & 15] = cd.x;
                         out[t] = fpc_pcm16(mem);
                     }
                 }

@@ -675,6 +675,19 @@ static float tree_reduce(float* a, int P) {
     return a[0];
 }
 
+/* probability of mu-law level v under the 8-level binary tree with node probabilities q[1..255] */
+static float tree_leaf_prob(const float* q, int v) {
+    float f[8];
+    int node = 1;
+    for (int l = 0; l < 8; ++l) {
+        const int bit = (v >> (7 - l)) & 1;
+        const float qq = q[node];
+        f[l] = bit ? qq : 1.0f - qq;
+        node = 2 * node + bit;
+    }
+    return ((((f[0] * f[1]) * (f[2] * f[3])) * (f[4] * f[5])) * f[6]) * f[7];
+}
+
 static float g_tanh_tab[FPC_TANH_TABLE_SIZE + 3];
 static int g_tanh_ready = 0;
 static const float* tanh_tab(void) {
@@ -766,14 +779,20 @@ EXPORT void orc_lpcnet_synthesize(const orc_lpcnet* m, const float* feat, int T,
                 s1n[j] = fmaf(z, s1[j] - n, n);
             }
             memcpy(s1, s1n, sizeof s1);
-            /* GRU_B: 64 leaves of 6 inputs, balanced tree */
+            /* GRU_B: 64 leaves of 6 inputs, balanced tree.  Leaf l = 4*kl + j of input slice kl (24 inputs)
+             * takes inputs 24*kl + c(j) + 4*m, m = 0..5, with c = {0, 2, 1, 3}: the kernel advances the
+             * leaf pairs (c, c+1) with one packed fma per float4 of state and adds the pairs crosswise */
             float s2n[RNN_B];
             float gb[GB], ub[GB];
             for (int o = 0; o < GB; ++o) {
                 float part[64];
                 for (int l = 0; l < 64; ++l) {
                     float sacc = 0.0f;
-                    for (int k = 6 * l; k < 6 * l + 6; ++k) sacc = fmaf(w->gb_k[(size_t)k * GB + o], s1[k], sacc);
+                    static const int comp[4] = {0, 2, 1, 3};
+                    for (int mm = 0; mm < 6; ++mm) {
+                        const int k = 24 * (l >> 2) + comp[l & 3] + 4 * mm;
+                        sacc = fmaf(w->gb_k[(size_t)k * GB + o], s1[k], sacc);
+                    }
                     part[l] = sacc;
                 }
                 gb[o] = tree_reduce(part, 64) + cfb[o];
@@ -793,28 +812,30 @@ EXPORT void orc_lpcnet_synthesize(const orc_lpcnet* m, const float* feat, int T,
             for (int j = 1; j < 256; ++j) {
                 float tc[2];
                 for (int ch = 0; ch < 2; ++ch) {
-                    float dacc = w->md_b[j * 2 + ch];
-                    for (int k = 0; k < RNN_B; ++k) dacc = fmaf(w->md_k[((size_t)j * RNN_B + k) * 2 + ch], s2[k], dacc);
-                    tc[ch] = fpc_tanh_lut(TT, dacc);
+                    /* two chains: bias + even inputs, odd inputs; then their sum */
+                    float dacc = w->md_b[j * 2 + ch], dodd = 0.0f;
+                    for (int k = 0; k < RNN_B; k += 2) {
+                        dacc = fmaf(w->md_k[((size_t)j * RNN_B + k) * 2 + ch], s2[k], dacc);
+                        dodd = fmaf(w->md_k[((size_t)j * RNN_B + k + 1) * 2 + ch], s2[k + 1], dodd);
+                    }
+                    tc[ch] = fpc_tanh_lut(TT, dacc + dodd);
                 }
                 const float v = fmaf(w->md_f[j * 2 + 1], tc[1], w->md_f[j * 2] * tc[0]);
                 q[j] = fpc_sigmoid_lut(TT, v);
             }
-            /* 8-level binary tree -> pdf over 256 mu-law levels, MSB first */
+            /* 8-level binary tree -> pdf over 256 mu-law levels; branch factors f0..f7 MSB first, multiplied
+             * as (((f0 f1)(f2 f3))(f4 f5)) f6 f7 */
             for (int v = 0; v < 256; ++v) {
-                float pv = 1.0f;
-                int node = 1;
-                for (int l = 0; l < 8; ++l) {
-                    const int bit = (v >> (7 - l)) & 1;
-                    const float qq = q[node];
-                    pv = pv * (bit ? qq : 1.0f - qq);
-                    node = 2 * node + bit;
-                }
+                const float pv = tree_leaf_prob(q, v);
                 p[v] = shape_e > 0.0f ? fpc_shape_pow(pv, shape_e) : pv; /* src/train.py:82 */
             }
-            memcpy(tmp, p, sizeof p);
-            const float S1 = tree_reduce(tmp, 256);
-            const float thr = 0.002f * S1; /* train.py:83-85 without the division */
+            /* train.py:83-85 without the division: the cut is 0.002 of the pdf's total.  Without
+             * sharpening the tree pdf sums to 1 by construction, so the total is not computed */
+            float thr = 0.002f;
+            if (shape_e > 0.0f) {
+                memcpy(tmp, p, sizeof p);
+                thr = 0.002f * tree_reduce(tmp, 256);
+            }
             for (int v = 0; v < 256; ++v) {
                 const float d = p[v] - thr;
                 p[v] = d > 0.0f ? d : 0.0f;
@@ -881,14 +902,5 @@ EXPORT void orc_lpcnet_synthesize(const orc_lpcnet* m, const float* feat, int T,
 
 /* debugging/known-answer helper: pdf of one step from given node probabilities */
 EXPORT void orc_tree_pdf(const float* q, float* p) {
-    for (int v = 0; v < 256; ++v) {
-        float pv = 1.0f;
-        int node = 1;
-        for (int l = 0; l < 8; ++l) {
-            const int bit = (v >> (7 - l)) & 1;
-            pv = pv * (bit ? q[node] : 1.0f - q[node]);
-            node = 2 * node + bit;
-        }
-        p[v] = pv;
-    }
+    for (int v = 0; v < 256; ++v) p[v] = tree_leaf_prob(q, v);
 }
