@@ -33,6 +33,9 @@ constexpr int NMW = NMAT / 64;
 // stride between the partial-sum planes of consecutive lanes q of a row group: +4 floats so that the
 // lanes of one group (consecutive lanes of a wave) start their 16-byte stores in different bank groups
 constexpr int PSTRIDE = GA + 4;
+#ifndef FPC_PRIO
+#define FPC_PRIO 3  // priority of the mat-vec waves while they gather and gate (the sampler waves drop to 0 there)
+#endif
 #ifndef FPC_NA
 #define FPC_NA 6  // sparse-product columns (of 16) computed under GRU_B ...
 #endif
@@ -254,6 +257,9 @@ __global__ __launch_bounds__(NTHREADS) void k_decode(const DecodeParams P) {
             }
             for (int i = (fr == 0 ? FPC_LPC_ORDER + 1 : 0); i < FPC_FRAME_SIZE; ++i) {
                 // ---- X..Y: gather the three embedding-table rows, GRU_A gates ----
+#if FPC_PRIO
+                __builtin_amdgcn_s_setprio(FPC_PRIO);  // the gates are on the sample-to-sample critical path
+#endif
                 if (gate_lane) {
                     const unsigned ml = opaque((unsigned)ml_);
                     struct F3 {
@@ -288,6 +294,9 @@ __global__ __launch_bounds__(NTHREADS) void k_decode(const DecodeParams P) {
                     const float h_new = fmaf(z, h_own - n, n);
                     L.s1[ml] = h_new;
                 }
+#if FPC_PRIO
+                __builtin_amdgcn_s_setprio(0);
+#endif
                 FPC_BARRIER(0)  // Y
                 // ---- the sparse product of s1' with this lane's 4 blocks (16 columns of 8 rows), sliced under
                 //      the sampler phases: FPC_NA columns under GRU_B, FPC_NB under the dual FC, the rest and the
@@ -392,6 +401,9 @@ __global__ __launch_bounds__(NTHREADS) void k_decode(const DecodeParams P) {
 
             for (int i = (fr == 0 ? FPC_LPC_ORDER + 1 : 0); i < FPC_FRAME_SIZE; ++i) {
                 const int t = fr * FPC_FRAME_SIZE + i;
+#if FPC_PRIO
+                __builtin_amdgcn_s_setprio(0);  // window work has slack; the gate waves do not
+#endif
                 // ---- X..Y (the mat-vec waves gather + gate): everything that only needs the
                 //      previous draw: GRU_B recurrent part, LPC history chain, leaf candidates ----
                 const float s2k = L.s2[kl];
@@ -412,6 +424,9 @@ __global__ __launch_bounds__(NTHREADS) void k_decode(const DecodeParams P) {
                         cpcm, cpred,
                         __int_as_float(fpc_lin2ulaw_tab(cpcm, L.ulaw_thr) | (fpc_lin2ulaw_tab(cpred, L.ulaw_thr) << 8)), 0.0f);
                 }
+#if FPC_PRIO
+                __builtin_amdgcn_s_setprio(3);
+#endif
                 FPC_BARRIER(0)  // Y
                 // ---- Y..Z1: GRU_B (row of 16 lanes = unit; lane = 24 inputs = 4 leaves of 6, leaf of
                 //      float4 component c takes inputs c + 4m) ----
@@ -529,7 +544,8 @@ __global__ __launch_bounds__(NTHREADS) void k_decode(const DecodeParams P) {
                     cnt = cnt > 3 ? 3 : cnt;
                     // the winning lane's result, made wave-uniform
                     const int exc = __builtin_amdgcn_readlane(4 * lane + cnt, lw);
-                    const float4 cd = L.cand[exc];  // one broadcast read: what the control block becomes
+                    float4 cd = L.cand[exc];  // one broadcast read: what the control block becomes
+                    asm volatile("" : "+v"(cd.x), "+v"(cd.y), "+v"(cd.z));  // (keeps it one ds_read_b128 up here)
                     mem = fmaf(FPC_PREEMPH, mem, cd.x);
                     if (lane == lw) {
                         const int ce = __float_as_int(cd.z);
