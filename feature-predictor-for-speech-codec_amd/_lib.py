@@ -15,6 +15,7 @@ SYMBOLS = [
     "fpc_encode", "fpc_vq_quantize", "fpc_scl_quantize", "fpc_ceps2lpc",
     "fpc_lpcnet_create", "fpc_lpcnet_destroy", "fpc_lpcnet_workspace_bytes",
     "fpc_lpcnet_synthesize", "fpc_lpcnet_condition", "fpc_lpcnet_last_decode_ms",
+    "fpc_lpcnet_kernel_variant",
 ]
 
 
@@ -66,6 +67,7 @@ def lib():
         L.fpc_lpcnet_workspace_bytes.argtypes = [C.c_void_p, C.c_int, C.c_int]
         L.fpc_lpcnet_last_decode_ms.restype = C.c_float
         L.fpc_lpcnet_last_decode_ms.argtypes = [C.c_void_p]
+        L.fpc_lpcnet_kernel_variant.argtypes = [C.c_void_p]
         L.fpc_predictor_create.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
         L.fpc_predictor_destroy.argtypes = [C.c_void_p]
         L.fpc_predictor_forward.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p,

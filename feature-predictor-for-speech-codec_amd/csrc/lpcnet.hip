@@ -313,6 +313,18 @@ extern "C" int fpc_lpcnet_create(const fpc_lpcnet_weights* w, fpc_lpcnet** out) 
     return FPC_OK;
 }
 
+namespace {
+// kernel instance by the widest row group: (update/reset gates, candidate gate) partial-sum planes
+int decode_variant(const fpc_lpcnet* m) {
+    const int qzr = m->gate_qp[0] > m->gate_qp[1] ? m->gate_qp[0] : m->gate_qp[1], qn = m->gate_qp[2];
+    if (qzr <= 2 && qn <= 8) return 208;
+    if (qzr <= 4 && qn <= 8) return 408;
+    return 1616;
+}
+}  // namespace
+
+extern "C" int fpc_lpcnet_kernel_variant(const fpc_lpcnet* m) { return m ? decode_variant(m) : -1; }
+
 extern "C" void fpc_lpcnet_destroy(fpc_lpcnet* m) {
     if (!m) return;
     if (m->ev0) (void)hipEventDestroy(m->ev0);
@@ -413,8 +425,7 @@ extern "C" int fpc_lpcnet_synthesize(fpc_lpcnet* m, const float* features_dev, i
         P.stamps = stamps.as<unsigned long long>();
     }
     FPC_HIP(hipEventRecord(m->ev0, st));
-    // kernel instance by the widest row group: (update/reset gates, candidate gate) partial-sum planes
-    const int qzr = m->gate_qp[0] > m->gate_qp[1] ? m->gate_qp[0] : m->gate_qp[1], qn = m->gate_qp[2];
+    const int variant = decode_variant(m);
 #define FPC_LAUNCH(QZR, QN)                                                                       \
     do {                                                                                          \
         if (stamp)                                                                                \
@@ -422,9 +433,9 @@ extern "C" int fpc_lpcnet_synthesize(fpc_lpcnet* m, const float* features_dev, i
         else                                                                                      \
             hipLaunchKernelGGL((k_decode<false, QZR, QN>), dim3(B), dim3(NTHREADS), 0, st, P);    \
     } while (0)
-    if (qzr <= 2 && qn <= 8)
+    if (variant == 208)
         FPC_LAUNCH(2, 8);
-    else if (qzr <= 4 && qn <= 8)
+    else if (variant == 408)
         FPC_LAUNCH(4, 8);
     else
         FPC_LAUNCH(16, 16);

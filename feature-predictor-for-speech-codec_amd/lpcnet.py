@@ -79,6 +79,10 @@ class LPCNet:
     def last_decode_ms(self):
         return float(_lib.lib().fpc_lpcnet_last_decode_ms(self.handle))
 
+    def kernel_variant(self):
+        """diagnostic: decode-kernel instance selected by the sparsity pattern (208, 408 or 1616)"""
+        return int(_lib.lib().fpc_lpcnet_kernel_variant(self.handle))
+
 
 def read_features(path):
     """(frames,36) float32 from raw .f32 (LPCNet dumps, data_preprocess/write_small_files.py:18-24)

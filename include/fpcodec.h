@@ -182,6 +182,11 @@ FPC_API int fpc_lpcnet_condition(fpc_lpcnet* m, const float* features_dev, int B
  * events on the launch stream; synchronises on those events. <0 if none. */
 FPC_API float fpc_lpcnet_last_decode_ms(fpc_lpcnet* m);
 
+/* diagnostic: which decode-kernel instance the model's sparsity pattern selects, as
+ * 100 * (partial-sum planes of the update/reset gates) + (planes of the candidate gate):
+ * 208, 408 or 1616 ("sparse product").  <0 on a null handle. */
+FPC_API int fpc_lpcnet_kernel_variant(const fpc_lpcnet* m);
+
 #ifdef __cplusplus
 }
 #endif

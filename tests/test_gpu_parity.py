@@ -184,6 +184,36 @@ def test_lpcnet_decode_bit_identical_small(torch_cuda, vocoder, synth, oracle):
     assert (pcm[:, :17] == 0).all()
 
 
+@pytest.mark.parametrize("density,variant", [((0.02, 0.02, 0.10), 208), ((0.05, 0.05, 0.20), 408),
+                                             ((0.05, 0.05, 0.26), 1616)])
+def test_lpcnet_decode_kernel_instances(torch_cuda, synth, oracle, density, variant):
+    """every decode-kernel instance (row groups 2/4/16 lanes wide) against the oracle, on frames
+    forced fully unvoiced (constant tail cut) and fully voiced (sharpened pdf, fifth barrier)"""
+    from fpcodec_amd.lpcnet import LPCNet
+    w = synth.lpcnet_weights(density=density)
+    voc = LPCNet(w)
+    assert voc.kernel_variant() == variant
+    orc = oracle.LPCNet(w)
+    B, T = 2, 4
+    f = _voc_features(synth, oracle, B, T)
+    f[0, :, 19] = -0.4   # pitch gain -> exponent 0 on every frame
+    f[1, :, 19] = 0.9    # -> exponent 0.85 on every frame
+    sd = synth.seeds(B, utt0=40)
+    pcm = voc.synthesize(f, sd).cpu().numpy()
+    for b in range(B):
+        ref = orc.synthesize(f[b], int(sd[b]))
+        nz = np.nonzero(pcm[b] != ref)[0]
+        assert nz.size == 0, f"variant {variant} utt {b}: first mismatch at sample {nz[:5]}"
+
+
+def test_lpcnet_too_dense_is_refused(torch_cuda, synth):
+    """a recurrent matrix that does not fit the register-resident layout fails loudly at create"""
+    from fpcodec_amd._lib import FpcError
+    from fpcodec_amd.lpcnet import LPCNet
+    with pytest.raises(FpcError, match="too dense"):
+        LPCNet(synth.lpcnet_weights(density=(0.3, 0.3, 0.5)))
+
+
 def test_lpcnet_config2_single_stream_3s(torch_cuda, vocoder, synth, oracle):
     """BASELINE config 2: one 3 s utterance, fixed RNG, bit-compared with the oracle."""
     voc, w = vocoder
