@@ -33,6 +33,9 @@ constexpr int NMW = NMAT / 64;
 // stride between the partial-sum planes of consecutive lanes q of a row group: +4 floats so that the
 // lanes of one group (consecutive lanes of a wave) start their 16-byte stores in different bank groups
 constexpr int PSTRIDE = GA + 4;
+#ifndef FPC_X_RP
+#define FPC_X_RP 4  // (timing experiments only: < 4 drops part of the sparse product)
+#endif
 #ifndef FPC_PRIO
 #define FPC_PRIO 3  // priority of the mat-vec waves while they gather and gate (the sampler waves drop to 0 there)
 #endif
@@ -77,11 +80,11 @@ struct __attribute__((aligned(16))) DecodeLds {
     float s2[RNN_B];
     float hist[16];
     // control block written by the winning lane / the LPC chain lane
-    unsigned o_sig, o_pred, o_exc, pad0;  // float offsets of the three table rows to gather next
-    float pred, pad1, pad2, pad3;
+    unsigned o_sig, o_pred, o_exc;  // float offsets of the three table rows to gather next
+    float pred;                     // prediction of the next sample
     float q[256];
     float p[256];
-    float4 cand[256];  // per leaf: (pcm, next prediction, bits of e_sig | e_pred << 8, -) if it wins the draw
+    float4 cand[256];  // per leaf, if it wins the draw: (pcm, next prediction, bits of o_sig, bits of o_pred)
     float ulaw_thr[64];  // fpc_lin2ulaw_tab table
     float uframe[FPC_FRAME_SIZE];
     float part[16 * PSTRIDE];      // partial row sums of the sparse product: [lane q of the row group][gate row]
@@ -321,7 +324,7 @@ __global__ __launch_bounds__(NTHREADS) void k_decode(const DecodeParams P) {
             hv1[0] = hc.x, hv1[1] = hc.y, hv1[2] = hc.z, hv1[3] = hc.w;                                           \
             hv1[4] = hd.x, hv1[5] = hd.y, hv1[6] = hd.z, hv1[7] = hd.w;                                           \
         }                                                                                                         \
-        _Pragma("unroll") for (int rp = 0; rp < 4; ++rp) {                                                        \
+        _Pragma("unroll") for (int rp = 0; rp < FPC_X_RP; ++rp) {                                                 \
             if (bc < 8)                                                                                           \
                 acc[rp] = fma2(w2[bc * 4 + rp], splat2(hv0[bc]), acc[rp]);                                        \
             else                                                                                                  \
@@ -420,9 +423,11 @@ __global__ __launch_bounds__(NTHREADS) void k_decode(const DecodeParams P) {
                     // what the control block becomes if leaf `sl` wins this sample's draw
                     const float cpcm = L.pred + my_ulaw;
                     const float cpred = -fmaf(a0, cpcm, part);
-                    L.cand[sl] = make_float4(
-                        cpcm, cpred,
-                        __int_as_float(fpc_lin2ulaw_tab(cpcm, L.ulaw_thr) | (fpc_lin2ulaw_tab(cpred, L.ulaw_thr) << 8)), 0.0f);
+                    // ... with the float offsets of the table rows of its signal and prediction levels (x GA = 1024 + 128)
+                    const unsigned es = (unsigned)fpc_lin2ulaw_tab(cpcm, L.ulaw_thr);
+                    const unsigned ep = 256u + (unsigned)fpc_lin2ulaw_tab(cpred, L.ulaw_thr);
+                    L.cand[sl] = make_float4(cpcm, cpred, __uint_as_float((es << 10) + (es << 7)),
+                                             __uint_as_float((ep << 10) + (ep << 7)));
                 }
 #if FPC_PRIO
                 __builtin_amdgcn_s_setprio(3);
@@ -480,7 +485,7 @@ __global__ __launch_bounds__(NTHREADS) void k_decode(const DecodeParams P) {
                 if (shape_e > 0.0f) {
                     // ---- voiced frame, Z2..Z3: leaf probability + sharpening, 256 lanes ----
                     {
-                        const unsigned slv = opaque((unsigned)sl);
+                        const unsigned slv = opaque((unsigned)sl);  // (recomputed per sample: no registers to spare)
                         float f[8];
 #pragma unroll
                         for (int j = 0; j < 8; ++j) {
@@ -495,7 +500,9 @@ __global__ __launch_bounds__(NTHREADS) void k_decode(const DecodeParams P) {
                 } else if (wave == 0) {
                     // ---- unvoiced frame: the drawing wave builds its 4 leaves per lane straight from
                     //      q (same product order per leaf); no separate leaf phase, no barrier ----
-                    const unsigned lv = opaque((unsigned)lane);
+                    // (node addresses and branch predicates are lane constants: left to the compiler to keep in
+                    //  registers / lane masks, so that the LDS reads issue right behind the barrier)
+                    const unsigned lv = (unsigned)lane;
                     float f[6];
 #pragma unroll
                     for (int j = 0; j < 6; ++j) {
@@ -537,7 +544,8 @@ __global__ __launch_bounds__(NTHREADS) void k_decode(const DecodeParams P) {
                     I = add_bcast<DPP_BCAST31, 0xc>(I);
                     const float S2 = lane_val(I, 63);
                     const float rthr = L.uframe[i] * S2;
-                    const int lw = __popcll(__ballot(lane < 63 && I <= rthr));  // winning lane
+                    // winning lane = number of the first 63 lanes whose inclusive prefix is <= the draw (v_cmp -> s_bcnt1)
+                    const int lw = __popcll(__builtin_amdgcn_fcmpf(I, rthr, 5 /* FCMP_OLE */) & 0x7fffffffffffffffull);
                     const float Iprev = dpp_f<DPP_WAVE_SHR1>(I);
                     const float O = lane > 0 ? Iprev : 0.0f;
                     int cnt = ((O + c0) <= rthr) + ((O + c1) <= rthr) + ((O + c2) <= rthr) + ((O + c3) <= rthr);
@@ -545,15 +553,12 @@ __global__ __launch_bounds__(NTHREADS) void k_decode(const DecodeParams P) {
                     // the winning lane's result, made wave-uniform
                     const int exc = __builtin_amdgcn_readlane(4 * lane + cnt, lw);
                     float4 cd = L.cand[exc];  // one broadcast read: what the control block becomes
-                    asm volatile("" : "+v"(cd.x), "+v"(cd.y), "+v"(cd.z));  // (keeps it one ds_read_b128 up here)
+                    asm volatile("" : "+v"(cd.x), "+v"(cd.y), "+v"(cd.z), "+v"(cd.w));  // (keeps it one ds_read_b128 up here)
                     mem = fmaf(FPC_PREEMPH, mem, cd.x);
                     if (lane == lw) {
-                        const int ce = __float_as_int(cd.z);
-                        const unsigned es = (unsigned)(ce & 0xff), ep = 256u + (unsigned)(ce >> 8), ee = 512u + (unsigned)exc;
-                        L.o_sig = (es << 10) + (es << 7);  // x GA (1152 = 1024 + 128)
-                        L.o_pred = (ep << 10) + (ep << 7);
-                        L.o_exc = (ee << 10) + (ee << 7);
-                        L.pred = cd.y;
+                        // control block {o_sig, o_pred, o_exc, pred}: one 16-byte store
+                        *reinterpret_cast<float4*>(&L.o_sig) =
+                            make_float4(cd.z, cd.w, __uint_as_float((512u + (unsigned)exc) * (unsigned)GA), cd.y);
                         L.hist[t & 15] = cd.x;
                         out[t] = fpc_pcm16(mem);
                     }
