@@ -436,7 +436,7 @@ __global__ __launch_bounds__(NTHREADS) void k_decode(const DecodeParams P) {
                 // ---- Y..Z1: GRU_B (row of 16 lanes = unit; lane = 24 inputs = 4 leaves of 6, leaf of
                 //      float4 component c takes inputs c + 4m) ----
                 {
-                    const unsigned klv = opaque((unsigned)kl);
+                    const unsigned klv = (unsigned)kl;  // (24 * kl: a lane constant the compiler keeps in a register)
                     f2 acc[3][2];
 #pragma unroll
                     for (int g = 0; g < 3; ++g) acc[g][0] = acc[g][1] = splat2(0.0f);
