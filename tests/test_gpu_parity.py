@@ -238,6 +238,41 @@ def test_lpcnet_batch_invariance(torch_cuda, vocoder, synth, oracle):
     assert np.array_equal(p2, full[perm])
 
 
+def test_lpcnet_config3_full_batch_properties(torch_cuda, vocoder, synth, oracle):
+    """BASELINE config 3 at full size (256 x 3 s, one workgroup per CU): utterances repeated with the
+    same seed must come out identical from every CU, an utterance must not depend on its neighbours,
+    and three rows are bit-compared with the oracle."""
+    voc, w = vocoder
+    B, T, nu = 256, 300, 8
+    base = _voc_features(synth, oracle, nu, T, utt0=900)
+    f = np.tile(base, (B // nu, 1, 1))
+    sd = np.tile(synth.seeds(nu, utt0=900), B // nu)
+    sd[200:] += 7  # the last 56 get their own random streams
+    pcm = voc.synthesize(f, sd).cpu().numpy()
+    assert pcm.shape == (B, T * 160) and (pcm[:, :17] == 0).all()
+    for r in range(1, 200 // nu):  # replicas of the first 8 on other CUs
+        assert np.array_equal(pcm[r * nu:(r + 1) * nu], pcm[:nu]), f"replica block {r} differs"
+    assert not np.array_equal(pcm[200], pcm[0])  # another seed, another waveform
+    orc = oracle.LPCNet(w)
+    for b in (0, 133, 255):
+        ref = orc.synthesize(f[b], int(sd[b]))
+        nz = np.nonzero(pcm[b] != ref)[0]
+        assert nz.size == 0, f"utt {b}: first mismatch at sample {nz[:5]}"
+
+
+def test_lpcnet_shortest_inputs(torch_cuda, vocoder, synth, oracle):
+    """one frame (143 audible samples after the 17 skipped ones) and a single utterance"""
+    voc, w = vocoder
+    f = _voc_features(synth, oracle, 2, 1, utt0=77)
+    sd = synth.seeds(2, utt0=77)
+    pcm = voc.synthesize(f, sd).cpu().numpy()
+    orc = oracle.LPCNet(w)
+    for b in range(2):
+        assert np.array_equal(pcm[b], orc.synthesize(f[b], int(sd[b])))
+    one = voc.synthesize(f[1:2], sd[1:2]).cpu().numpy()
+    assert np.array_equal(one[0], pcm[1])
+
+
 def test_synthesis_qtz_harness_vs_reference_golden(torch_cuda, synth, golden, cb_paths, tmp_path, monkeypatch):
     """rows a9/a10: the synthesis_qtz.py driver (checkpoint file -> encoder -> x24.1 -> ceps2lpc ->
     36-float frames, src/synthesis_qtz.py:67-166) against the reference's own output (G2+G4)."""
