@@ -260,6 +260,19 @@ def test_lpcnet_config3_full_batch_properties(torch_cuda, vocoder, synth, oracle
         assert nz.size == 0, f"utt {b}: first mismatch at sample {nz[:5]}"
 
 
+def test_lpcnet_more_utterances_than_cus(torch_cuda, vocoder, synth, oracle):
+    """600 workgroups on 256 CUs: the grid runs in several rounds; rows spot-checked against the oracle"""
+    voc, w = vocoder
+    B, T, nu = 600, 2, 6
+    base = _voc_features(synth, oracle, nu, T, utt0=300)
+    f = np.tile(base, (B // nu, 1, 1))
+    sd = synth.seeds(B, utt0=300)
+    pcm = voc.synthesize(f, sd).cpu().numpy()
+    orc = oracle.LPCNet(w)
+    for b in (0, 255, 256, 599):
+        assert np.array_equal(pcm[b], orc.synthesize(f[b], int(sd[b]))), f"utt {b}"
+
+
 def test_lpcnet_shortest_inputs(torch_cuda, vocoder, synth, oracle):
     """one frame (143 audible samples after the 17 skipped ones) and a single utterance"""
     voc, w = vocoder
