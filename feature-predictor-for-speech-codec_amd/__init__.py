@@ -19,9 +19,9 @@ def __getattr__(name):
     lazy = {
         "Wavernn": ".wavernn", "vq_quantize": ".vq_func", "scl_quantize": ".vq_func",
         "ceps2lpc_v": ".ceps2lpc", "LPCNet": ".lpcnet", "synthesis": ".synthesis_qtz",
-        "cal_entropy": ".vq_func", "lib": "._lib",
+        "cal_entropy": ".vq_func", "lib": "._lib", "cb_func": ".cb_func",
     }
     if name in lazy:
         mod = importlib.import_module(lazy[name], __name__)
-        return getattr(mod, name) if name != "lib" else mod
+        return mod if name in ("lib", "cb_func") else getattr(mod, name)
     raise AttributeError(name)

@@ -166,3 +166,13 @@ def peaked_cepstra():
         c[0] -= 4.0
         rows.append(np.concatenate([c, [0.0, 0.0]]))
     return np.array(rows, np.float32)
+
+
+def cb_training_vectors(n, seed=SEED_CODEBOOKS, seed_offset=0, ndims=17):
+    """Residual-like training vectors for the codebook trainer (train_cb.py:170-178 hands over float32
+    rows): a mixture of 12 anisotropic Gaussian clusters around zero, float32."""
+    rng = np.random.default_rng(seed + 1000 + seed_offset)
+    centres = rng.normal(0, 0.12, (12, ndims))
+    scale = rng.uniform(0.01, 0.05, (12, ndims))
+    which = rng.integers(0, 12, n)
+    return (centres[which] + rng.normal(0, 1, (n, ndims)) * scale[which]).astype(np.float32)

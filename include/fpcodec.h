@@ -187,6 +187,27 @@ FPC_API float fpc_lpcnet_last_decode_ms(fpc_lpcnet* m);
  * 208, 408 or 1616 ("sparse product").  <0 on a null handle. */
 FPC_API int fpc_lpcnet_kernel_variant(const fpc_lpcnet* m);
 
+/* ---- codebook training primitives (src/quantization/cb_func.py) ----
+ * 17-dimensional vectors only (cfg['code_dims'] of the production codebooks); entries <= 4096.
+ * data_dev: [nv][nd] rows, float32 (data_f64 = 0: what train_cb.py:170-178 hands to the first stage) or
+ * float64 (data_f64 = 1: the residual `qr - r` later stages train on, train_cb.py:191-192);
+ * codebooks float64 [entries][nd]. */
+
+/* bytes of workspace_dev fpc_cb_update needs */
+FPC_API long long fpc_cb_workspace_bytes(int nv, int entries);
+
+/* find_nearest (cb_func.py:56-68): idx_dev[i] = first entry with the smallest float64 squared distance */
+FPC_API int fpc_cb_find_nearest(const void* data_dev, int data_f64, int nv, int nd, const double* cb_dev,
+                        int entries, int* idx_dev, fpc_stream s);
+
+/* update (cb_func.py:71-100): cb_out[n] = (float64 sum, in index order, of the vectors nearest to
+ * cb_in[n]) / (count[n] + 1e-20); count_dev (float64 [entries]) may be NULL */
+FPC_API int fpc_cb_update(const void* data_dev, int data_f64, int nv, int nd, const double* cb_in_dev, int entries,
+                  double* cb_out_dev, double* count_dev, void* workspace_dev, fpc_stream s);
+
+/* np.mean(data, 0) as vq_train takes it (cb_func.py:34): accumulated in the data's own precision */
+FPC_API int fpc_cb_mean0(const void* data_dev, int data_f64, int nv, int nd, double* out_dev, fpc_stream s);
+
 #ifdef __cplusplus
 }
 #endif

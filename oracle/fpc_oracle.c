@@ -904,3 +904,77 @@ EXPORT void orc_lpcnet_synthesize(const orc_lpcnet* m, const float* feat, int T,
 EXPORT void orc_tree_pdf(const float* q, float* p) {
     for (int v = 0; v < 256; ++v) p[v] = tree_leaf_prob(q, v);
 }
+
+/* ====================================================================
+ * Codebook training: src/quantization/cb_func.py
+ * ==================================================================== */
+
+/* Training vectors arrive as float32 (train_cb.py:170-178) for the first stage and as float64 for
+ * later stages (the residual `qr - r` of train_cb.py:191-192): data_f64 selects how `data` is read. */
+static double cb_at(const void* data, int data_f64, size_t k) {
+    return data_f64 ? ((const double*)data)[k] : (double)((const float*)data)[k];
+}
+
+/* find_nearest (cb_func.py:56-68): dist = np.sum((data - codebook)**2, -1) in float64 (float32 data is
+ * broadcast against the float64 codebook), np.argmin over entries = first minimum.  17 dimensions:
+ * numpy's pairwise association as in dist17 above. */
+EXPORT int orc_cb_find_nearest(const void* data, int data_f64, int nv, int nd, const double* cb, int e, int* idx) {
+    if (nd != ORC_NDIM) return -1;
+    for (int i = 0; i < nv; ++i) {
+        double x[ORC_NDIM];
+        for (int j = 0; j < ORC_NDIM; ++j) x[j] = cb_at(data, data_f64, (size_t)i * nd + j);
+        double best = INFINITY;
+        int bi = 0;
+        for (int n = 0; n < e; ++n) {
+            const double d = dist17(x, cb + (size_t)n * nd);
+            if (n == 0 || d < best) { /* np.argmin: first index of the minimum (NaN-free input) */
+                best = d;
+                bi = n;
+            }
+        }
+        idx[i] = bi;
+    }
+    return 0;
+}
+
+/* update (cb_func.py:71-100): nearest entry per vector, then per entry the float64 sum of its
+ * members accumulated in index order, divided by (count + 1e-20).  count_out may be NULL. */
+EXPORT int orc_cb_update(const void* data, int data_f64, int nv, int nd, const double* cb_in, int e, double* cb_out,
+                         double* count_out) {
+    int* idx = (int*)malloc(sizeof(int) * (size_t)(nv > 0 ? nv : 1));
+    if (orc_cb_find_nearest(data, data_f64, nv, nd, cb_in, e, idx) != 0) {
+        free(idx);
+        return -1;
+    }
+    double* count = (double*)calloc((size_t)e, sizeof(double));
+    for (size_t k = 0; k < (size_t)e * nd; ++k) cb_out[k] = 0.0;
+    for (int i = 0; i < nv; ++i) {
+        const int n = idx[i];
+        count[n] += 1.0;
+        for (int j = 0; j < nd; ++j) cb_out[(size_t)n * nd + j] += cb_at(data, data_f64, (size_t)i * nd + j);
+    }
+    for (int n = 0; n < e; ++n)
+        for (int j = 0; j < nd; ++j) cb_out[(size_t)n * nd + j] /= count[n] + 1e-20;
+    if (count_out) memcpy(count_out, count, sizeof(double) * (size_t)e);
+    free(count);
+    free(idx);
+    return 0;
+}
+
+/* np.mean(data, 0) of a C-contiguous (nv, nd) array (cb_func.py:34): accumulation row after row in the
+ * array's own precision, division by nv in that precision; widened to float64 on assignment */
+EXPORT void orc_cb_mean0(const void* data, int data_f64, int nv, int nd, double* out) {
+    for (int j = 0; j < nd; ++j) {
+        if (data_f64) {
+            const double* d = (const double*)data;
+            double s = d[j];
+            for (int i = 1; i < nv; ++i) s = s + d[(size_t)i * nd + j];
+            out[j] = s / (double)nv;
+        } else {
+            const float* d = (const float*)data;
+            float s = d[j];
+            for (int i = 1; i < nv; ++i) s = s + d[(size_t)i * nd + j];
+            out[j] = (double)(s / (float)nv);
+        }
+    }
+}

@@ -266,3 +266,60 @@ class LPCNet:
         lib().orc_lpcnet_synthesize(C.c_void_p(self.h), _p(f), T, C.c_uint64(int(seed)), _p(pcm),
                                     _p(exc) if trace else None, _p(pf) if trace else None)
         return (pcm, exc, pf) if trace else pcm
+
+
+# ---- codebook training (cb_func.py): update / find_nearest in C, the splitting schedule here ----
+def _cb_data(data):
+    """float32 rows stay float32, anything else is taken as float64 (later stages train on `qr - r`)"""
+    data = np.asarray(data)
+    if data.dtype == np.float32:
+        return np.ascontiguousarray(data), 0
+    return _f64(data), 1
+
+
+def cb_find_nearest(data, codebook):
+    data, f64 = _cb_data(data)
+    cb = _f64(codebook)
+    idx = np.zeros(data.shape[0], np.int32)
+    rc = lib().orc_cb_find_nearest(_p(data), f64, data.shape[0], data.shape[1], _p(cb), cb.shape[0], _p(idx))
+    assert rc == 0, "oracle: 17 dimensions only"
+    return idx.astype(np.int64)
+
+
+def cb_update(data, codebook, nb_entries_tmp, return_count=False):
+    data, f64 = _cb_data(data)
+    cb = _f64(codebook[:nb_entries_tmp])
+    out = np.zeros_like(cb)
+    count = np.zeros(nb_entries_tmp, np.float64)
+    rc = lib().orc_cb_update(_p(data), f64, data.shape[0], data.shape[1], _p(cb), nb_entries_tmp, _p(out), _p(count))
+    assert rc == 0, "oracle: 17 dimensions only"
+    return (out, count) if return_count else out
+
+
+def cb_mean0(data):
+    data, f64 = _cb_data(data)
+    out = np.zeros(data.shape[1], np.float64)
+    lib().orc_cb_mean0(_p(data), f64, data.shape[0], data.shape[1], _p(out))
+    return out
+
+
+def cb_quantize(codebook, data):
+    return _f64(codebook)[cb_find_nearest(data, codebook)]
+
+
+def cb_vq_train(data, codebook, nb_entries):
+    """cb_func.py:28-54: LBG splitting; draws its perturbations from numpy's global RNG like the reference"""
+    ndims = data.shape[1]
+    codebook = _f64(codebook).copy()
+    codebook[0] = cb_mean0(data)
+    e = 1
+    while e < nb_entries:
+        codebook[e, :] = codebook[0, :]
+        delta = .001 * (np.random.rand(e, ndims) / 2)
+        codebook[:e, :] += delta
+        e += 1
+        for _ in range(4):
+            codebook[:e, :] = cb_update(data, codebook[:e, :], e)
+    for _ in range(10):
+        codebook = cb_update(data, codebook, nb_entries)
+    return codebook

@@ -364,3 +364,69 @@ def test_lpcnet_cli_three_args(torch_cuda, vocoder, synth, oracle, tmp_path):
     ref = oracle.LPCNet(w).synthesize(f, 0)
     assert pcm.size == 4 * 160 - 17 and np.array_equal(pcm, ref[17:])
     assert L.main(["only", "two"]) == 2
+
+
+# ---- codebook training on the GPU ----
+def test_cb_primitives_vs_golden_and_oracle(torch_cuda, synth, golden, oracle):
+    from fpcodec_amd import cb_func
+    g = golden("g7_cb_train")
+    data = synth.cb_training_vectors(3000)
+    cb0 = synth.cb_training_vectors(40, seed_offset=1).astype(np.float64)[:32]
+    assert np.array_equal(cb_func.find_nearest(data, cb0), g["idx"])
+    cb1, count = cb_func.update(data, cb0, 32, return_count=True)
+    assert np.array_equal(cb1, g["cb1"]) and count.sum() == 3000
+    assert np.array_equal(cb_func.quantize(cb1, data[:500]), g["qd"])
+    far = cb0.copy()
+    far[5] += 100.0
+    far[17] -= 100.0
+    cb2, count2 = cb_func.update(data, far, 32, return_count=True)
+    assert np.array_equal(cb2, g["cb2"]) and count2[5] == 0 and not cb2[5].any()
+    assert np.array_equal(cb_func.mean0(data), np.mean(data, 0).astype(np.float64))
+    # ragged sizes: one vector, one entry, sizes off the block boundaries
+    for nv, e in ((1, 1), (1, 7), (65, 3), (2049, 33), (4097, 1)):
+        d = synth.cb_training_vectors(nv, seed_offset=nv)
+        c = synth.cb_training_vectors(e, seed_offset=1000 + e).astype(np.float64)
+        assert np.array_equal(cb_func.find_nearest(d, c), oracle.cb_find_nearest(d, c)), (nv, e)
+        assert np.array_equal(cb_func.update(d, c, e), oracle.cb_update(d, c, e)), (nv, e)
+
+
+def test_cb_vq_train_vs_reference_golden(torch_cuda, synth, golden):
+    from fpcodec_amd import cb_func
+    g = golden("g7_cb_train")
+    data = synth.cb_training_vectors(3000)
+    np.random.seed(20221104)
+    assert np.array_equal(cb_func.vq_train(data, np.zeros((24, 17)), 24), g["cbt"])
+    r = data.copy()
+    np.random.seed(7)
+    for i in range(2):
+        c = cb_func.vq_train(r, np.zeros((8, 17)), 8)
+        assert np.array_equal(c, g[f"stage{i}"])
+        r = cb_func.quantize(c, r) - r
+    assert np.array_equal(r, g["r_final"])
+
+
+def test_cb_update_production_size_properties(torch_cuda, synth, oracle):
+    """400 000 vectors x 1024 entries (a 5000-utterance batch at keep-rate 0.3): size-independent
+    properties, and three cells recomputed in float64 on the host in index order"""
+    torch = torch_cuda
+    from fpcodec_amd import cb_func
+    nv, e = 400_000, 1024
+    data = synth.cb_training_vectors(nv, seed_offset=5)
+    cb = data[::nv // e][:e].astype(np.float64) + 1e-3
+    d = torch.from_numpy(data).cuda()
+    idx = cb_func.find_nearest(d, cb)
+    new, count = cb_func.update(d, cb, e, return_count=True)
+    assert count.sum() == nv and np.array_equal(count, np.bincount(idx, minlength=e).astype(np.float64))
+    sel = np.random.default_rng(0).integers(0, nv, 400)  # the chosen entry really is the (first) nearest
+    dist = ((data[sel].astype(np.float64)[:, None, :] - cb[None, :, :]) ** 2).sum(-1)
+    assert np.array_equal(idx[sel], dist.argmin(1))
+    for n in (0, 511, 1023):
+        acc = np.zeros(17)
+        for i in np.nonzero(idx == n)[0]:
+            acc += data[i]
+        assert np.array_equal(new[n], acc / (count[n] + 1e-20))
+    again = cb_func.update(d, cb, e)  # deterministic
+    assert np.array_equal(again, new)
+    d2 = float(((cb_func.quantize(new, data[:20000]) - data[:20000]) ** 2).sum())
+    d1 = float(((cb_func.quantize(cb, data[:20000]) - data[:20000]) ** 2).sum())
+    assert d2 <= d1  # a Lloyd step does not increase the distortion (up to the re-assignment)

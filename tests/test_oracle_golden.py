@@ -161,3 +161,39 @@ def test_entropy(oracle, golden, cbs, pred, synth):
     g2 = golden("g2_encoder")
     for i in range(5):
         assert abs(oracle.cal_entropy(g2[f"full_1x300_hist{i}"]) - g["ent"][i]) < 1e-12
+
+
+# ---- codebook training: oracle vs the reference's cb_func.py (golden G7) ----
+def _cb_inputs(synth):
+    data = synth.cb_training_vectors(3000)
+    cb0 = synth.cb_training_vectors(40, seed_offset=1).astype(np.float64)[:32]
+    return data, cb0
+
+
+def test_cb_find_nearest_update_quantize(oracle, synth, golden):
+    g = golden("g7_cb_train")
+    data, cb0 = _cb_inputs(synth)
+    assert np.array_equal(oracle.cb_find_nearest(data, cb0), g["idx"])
+    cb1, count = oracle.cb_update(data, cb0, 32, return_count=True)
+    assert np.array_equal(cb1, g["cb1"]) and count.sum() == data.shape[0]
+    assert np.array_equal(oracle.cb_quantize(cb1, data[:500]), g["qd"])
+    far = cb0.copy()
+    far[5] += 100.0
+    far[17] -= 100.0
+    cb2, count2 = oracle.cb_update(data, far, 32, return_count=True)
+    assert np.array_equal(cb2, g["cb2"])
+    assert count2[5] == 0 and count2[17] == 0 and not cb2[5].any()  # empty cells collapse to 0 (count + 1e-20)
+
+
+def test_cb_vq_train_bit_exact(oracle, synth, golden):
+    g = golden("g7_cb_train")
+    data, _ = _cb_inputs(synth)
+    np.random.seed(20221104)  # the reference draws the split perturbations from numpy's global RNG
+    assert np.array_equal(oracle.cb_vq_train(data, np.zeros((24, 17)), 24), g["cbt"])
+    r = data.copy()
+    np.random.seed(7)
+    for i in range(2):  # train_cb.py:186-193: stage i trained on the residual of stage i-1
+        c = oracle.cb_vq_train(r, np.zeros((8, 17)), 8)
+        assert np.array_equal(c, g[f"stage{i}"])
+        r = oracle.cb_quantize(c, r) - r
+    assert np.array_equal(r, g["r_final"])
