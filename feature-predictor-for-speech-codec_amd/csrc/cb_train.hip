@@ -11,7 +11,8 @@
 // The reference accumulates `codebook[n] += data[i]` for i = 0..nv-1; floating-point addition does not commute
 // with reordering, so the sums are taken in exactly that order: the assignment is turned into a STABLE counting
 // sort by entry (per-block histograms -> offsets -> in-order scatter), after which the members of an entry are
-// contiguous and ascending and one 17-lane group adds them up one after the other in float64.
+// contiguous (the rows are moved into a staging buffer) and ascending, and one 17-lane group adds them up one
+// after the other in float64.
 #include "fpc_common.h"
 
 namespace {
@@ -123,9 +124,11 @@ __global__ __launch_bounds__(1024) void k_cb_offsets(int* __restrict__ hist, int
 }
 
 // stable scatter: one wave per block of CH vectors walks them in index order, 64 at a time; lanes with the
-// same entry take consecutive slots in lane order
-__global__ __launch_bounds__(64) void k_cb_scatter(const int* __restrict__ idx, int nv, int e,
-                                                   const int* __restrict__ blockbase, int* __restrict__ order) {
+// same entry take consecutive slots in lane order.  The rows themselves are moved (not just their indices), so
+// that the summation below streams contiguous memory instead of chasing two dependent gathers per member.
+template <class T>
+__global__ __launch_bounds__(64) void k_cb_scatter(const T* __restrict__ data, const int* __restrict__ idx, int nv, int e,
+                                                   const int* __restrict__ blockbase, T* __restrict__ sorted) {
     __shared__ int cur[MAXE];
     const int lane = threadIdx.x;
     for (int c = lane; c < e; c += 64) cur[c] = blockbase[(size_t)blockIdx.x * e + c];
@@ -147,33 +150,69 @@ __global__ __launch_bounds__(64) void k_cb_scatter(const int* __restrict__ idx, 
             __syncthreads();
             todo &= ~same;
         }
-        if (valid) order[pos] = i;
+        if (valid) {
+            T row[ND];
+#pragma unroll
+            for (int j = 0; j < ND; ++j) row[j] = data[(size_t)i * ND + j];
+#pragma unroll
+            for (int j = 0; j < ND; ++j) sorted[(size_t)pos * ND + j] = row[j];
+        }
     }
 }
 
-// per entry: float64 sum of its members in ascending index order, / (count + 1e-20); lane = (slot, dim),
-// 3 entries per wave
+// per entry: float64 sum of its members in ascending index order (contiguous rows of `sorted`),
+// / (count + 1e-20).  The add chain is strictly sequential -- that is the specification -- and the reference's
+// splitting schedule leaves cells with half of all vectors, so one chain per dimension is as parallel as it
+// gets; what can overlap is the memory: a 256-thread block per entry streams the rows through a double
+// buffer in LDS (coalesced copies of chunk k+1 in flight while 17 lanes add chunk k).
 template <class T>
-__global__ __launch_bounds__(64) void k_cb_sum(const T* __restrict__ data, const int* __restrict__ order,
-                                               const int* __restrict__ base, int e, double* __restrict__ cb_out) {
-    const int slot = threadIdx.x / ND, dim = threadIdx.x - slot * ND;
-    const int c = blockIdx.x * 3 + slot;
-    if (slot >= 3 || c >= e) return;
+__global__ __launch_bounds__(256) void k_cb_sum(const T* __restrict__ sorted, const int* __restrict__ base, int e,
+                                                double* __restrict__ cb_out) {
+    constexpr int CHK = sizeof(T) == 4 ? 512 : 256;  // rows per chunk: 2 x 34 KB of LDS either way
+    constexpr int PER = CHK * ND / 256;               // elements per thread per chunk
+    __shared__ T buf[2][CHK * ND];
+    const int c = blockIdx.x, tid = threadIdx.x;
     const int b0 = base[c], n = base[c + 1] - b0;
+    const T* src = sorted + (size_t)b0 * ND;
+    const size_t total = (size_t)n * ND;
+    const int nchunks = (n + CHK - 1) / CHK;
     double acc = 0.0;
-    int m = 0;
-    for (; m + 8 <= n; m += 8) {
-        int o[8];
-        T v[8];
+    T stage[PER];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) o[u] = order[b0 + m + u];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) v[u] = data[(size_t)o[u] * ND + dim];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) acc = acc + (double)v[u];
+    for (int u = 0; u < PER; ++u) {
+        const size_t k = (size_t)u * 256 + tid;
+        if (k < total) buf[0][k] = src[k];
     }
-    for (; m < n; ++m) acc = acc + (double)data[(size_t)order[b0 + m] * ND + dim];
-    cb_out[(size_t)c * ND + dim] = acc / ((double)n + 1e-20);
+    __syncthreads();
+    for (int ch = 0; ch < nchunks; ++ch) {
+        const size_t nxt = (size_t)(ch + 1) * CHK * ND;
+        if (ch + 1 < nchunks) {
+#pragma unroll
+            for (int u = 0; u < PER; ++u) {
+                const size_t k = nxt + (size_t)u * 256 + tid;
+                stage[u] = k < total ? src[k] : (T)0;
+            }
+        }
+        if (tid < ND) {
+            const T* b = buf[ch & 1] + tid;
+            const int rows = n - ch * CHK < CHK ? n - ch * CHK : CHK;
+            int r = 0;
+            for (; r + 16 <= rows; r += 16) {
+                T v[16];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) v[u] = b[(r + u) * ND];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) acc = acc + (double)v[u];
+            }
+            for (; r < rows; ++r) acc = acc + (double)b[r * ND];
+        }
+        if (ch + 1 < nchunks) {
+#pragma unroll
+            for (int u = 0; u < PER; ++u) buf[(ch + 1) & 1][(size_t)u * 256 + tid] = stage[u];
+        }
+        __syncthreads();
+    }
+    if (tid < ND) cb_out[(size_t)c * ND + tid] = acc / ((double)n + 1e-20);
 }
 
 // np.mean(data, 0): accumulation row after row and division in the array's own precision
@@ -183,19 +222,20 @@ __global__ __launch_bounds__(64) void k_cb_mean0(const T* __restrict__ data, int
     if (dim >= ND) return;
     T s = data[dim];
     int i = 1;
-    for (; i + 8 <= nv; i += 8) {
-        T v[8];
+    for (; i + 32 <= nv; i += 32) {
+        T v[32];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) v[u] = data[(size_t)(i + u) * ND + dim];
+        for (int u = 0; u < 32; ++u) v[u] = data[(size_t)(i + u) * ND + dim];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) s = s + v[u];
+        for (int u = 0; u < 32; ++u) s = s + v[u];
     }
     for (; i < nv; ++i) s = s + data[(size_t)i * ND + dim];
     out[dim] = (double)(s / (T)nv);
 }
 
 struct CbWs {
-    int *idx, *order, *hist, *base;
+    int *idx, *hist, *base;
+    void* sorted;  // [nv][ND] rows grouped by entry, in index order inside each entry
 };
 inline size_t a256(size_t n) { return (n + 255) / 256 * 256; }
 inline int nblocks(int nv) { return (nv + CH - 1) / CH; }
@@ -204,8 +244,8 @@ CbWs carve_cb(void* ws, int nv, int e) {
     CbWs w;
     w.idx = reinterpret_cast<int*>(p);
     p += a256(sizeof(int) * (size_t)nv);
-    w.order = reinterpret_cast<int*>(p);
-    p += a256(sizeof(int) * (size_t)nv);
+    w.sorted = p;
+    p += a256(sizeof(double) * (size_t)nv * ND);
     w.hist = reinterpret_cast<int*>(p);
     p += a256(sizeof(int) * (size_t)nblocks(nv) * e);
     w.base = reinterpret_cast<int*>(p);
@@ -223,7 +263,8 @@ int check_shape(const char* fn, int nv, int nd, int e) {
 
 extern "C" long long fpc_cb_workspace_bytes(int nv, int e) {
     if (nv <= 0 || e <= 0) return 0;
-    return (long long)(2 * a256(sizeof(int) * (size_t)nv) + a256(sizeof(int) * (size_t)nblocks(nv) * e) +
+    return (long long)(a256(sizeof(int) * (size_t)nv) + a256(sizeof(double) * (size_t)nv * ND) +
+                       a256(sizeof(int) * (size_t)nblocks(nv) * e) +
                        a256(sizeof(int) * (size_t)(e + 1)));
 }
 
@@ -259,13 +300,17 @@ extern "C" int fpc_cb_update(const void* data_dev, int data_f64, int nv, int nd,
                            e, w.idx);
     hipLaunchKernelGGL(k_cb_hist, dim3(nb), dim3(256), 0, st, w.idx, nv, e, w.hist);
     hipLaunchKernelGGL(k_cb_offsets, dim3(1), dim3(1024), 0, st, w.hist, nb, e, w.base, count_dev);
-    hipLaunchKernelGGL(k_cb_scatter, dim3(nb), dim3(64), 0, st, w.idx, nv, e, w.hist, w.order);
-    if (data_f64)
-        hipLaunchKernelGGL(k_cb_sum<double>, dim3((e + 2) / 3), dim3(64), 0, st, static_cast<const double*>(data_dev),
-                           w.order, w.base, e, cb_out_dev);
-    else
-        hipLaunchKernelGGL(k_cb_sum<float>, dim3((e + 2) / 3), dim3(64), 0, st, static_cast<const float*>(data_dev),
-                           w.order, w.base, e, cb_out_dev);
+    if (data_f64) {
+        hipLaunchKernelGGL(k_cb_scatter<double>, dim3(nb), dim3(64), 0, st, static_cast<const double*>(data_dev), w.idx,
+                           nv, e, w.hist, static_cast<double*>(w.sorted));
+        hipLaunchKernelGGL(k_cb_sum<double>, dim3(e), dim3(256), 0, st, static_cast<const double*>(w.sorted),
+                           w.base, e, cb_out_dev);
+    } else {
+        hipLaunchKernelGGL(k_cb_scatter<float>, dim3(nb), dim3(64), 0, st, static_cast<const float*>(data_dev), w.idx, nv,
+                           e, w.hist, static_cast<float*>(w.sorted));
+        hipLaunchKernelGGL(k_cb_sum<float>, dim3(e), dim3(256), 0, st, static_cast<const float*>(w.sorted),
+                           w.base, e, cb_out_dev);
+    }
     FPC_HIP(hipGetLastError());
     return FPC_OK;
 }
