@@ -87,12 +87,27 @@ def e2e_config5(voc, torch, synth, B=128, L=300):
     voc.synthesize(feats, seeds, out=pcm)
     torch.cuda.synchronize()
     t2 = time.perf_counter()
+    # receiver side: the same utterances rebuilt from the symbols alone
+    from fpcodec_amd import bitstream
+    from fpcodec_amd.vq_func import load_codebooks
+    enc = model.encoder(cfg, nm_d[:, :, :20], None, cfg["l1"], cfg["l2"], qtz=True, return_indices=True)
+    idx = enc[7]
+    torch.cuda.synchronize()
+    t3 = time.perf_counter()
+    rec = model.decode_indices(cfg, idx, nm_d[:, :, 18:20])
+    torch.cuda.synchronize()
+    t4 = time.perf_counter()
+    assert torch.equal(rec, enc[0]), "decoder output differs from the encoder's reconstruction"
+    sizes = load_codebooks(cfg["cb_path"], cfg["scl_cb_path"], cfg["bl_cb_path"], cfg["bl_scl_cb_path"]).sizes
+    fixed_bits = bitstream.bits_per_frame(idx.cpu().numpy(), sizes)
     n = B * L
     ent = [cal_entropy(h) if np.sum(h) > 0 else 0.0 for h in cb_tot]
     bits_frame = sum(e * float(np.sum(h)) for e, h in zip(ent, cb_tot)) / n + 2.0  # + the two threshold flags
     return {"utterances": B, "encode_ms": (t1 - t0) * 1e3, "decode_ms": (t2 - t1) * 1e3,
             "rtf_aggregate": B * 3.0 / (t2 - t0), "keep_rates": [float(i1.mean()), float(i2.mean())],
-            "entropy_bits_per_symbol": ent, "bits_per_frame": bits_frame, "bitrate_bps": bits_frame * 100.0}
+            "entropy_bits_per_symbol": ent, "bits_per_frame": bits_frame, "bitrate_bps": bits_frame * 100.0,
+            "fixed_length_bits_per_frame": fixed_bits, "fixed_length_bitrate_bps": fixed_bits * 100.0,
+            "decode_features_ms": (t4 - t3) * 1e3}
 
 
 def main():

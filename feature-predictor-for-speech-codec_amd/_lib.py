@@ -12,7 +12,7 @@ SYMBOLS = [
     "fpc_last_error", "fpc_abi_version", "fpc_device_count",
     "fpc_predictor_create", "fpc_predictor_destroy", "fpc_predictor_forward",
     "fpc_codebooks_create", "fpc_codebooks_destroy", "fpc_codebooks_hist_size",
-    "fpc_encode", "fpc_vq_quantize", "fpc_scl_quantize", "fpc_ceps2lpc",
+    "fpc_encode", "fpc_decode_features", "fpc_vq_quantize", "fpc_scl_quantize", "fpc_ceps2lpc",
     "fpc_lpcnet_create", "fpc_lpcnet_destroy", "fpc_lpcnet_workspace_bytes",
     "fpc_lpcnet_synthesize", "fpc_lpcnet_condition", "fpc_lpcnet_last_decode_ms",
     "fpc_lpcnet_kernel_variant",
@@ -87,6 +87,8 @@ def lib():
         L.fpc_codebooks_hist_size.argtypes = [C.c_void_p]
         L.fpc_encode.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float,
                                  C.c_float, C.c_int] + [C.c_void_p] * 9
+        L.fpc_decode_features.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
+                                          C.c_void_p, C.c_void_p]
         L.fpc_vq_quantize.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p,
                                       C.c_void_p, C.c_void_p]
         L.fpc_scl_quantize.argtypes = L.fpc_vq_quantize.argtypes

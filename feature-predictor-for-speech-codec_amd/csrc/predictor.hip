@@ -464,6 +464,63 @@ __global__ __launch_bounds__(NT) void k_encode(const PredDev P, const CbDev C, c
     }
 }
 
+// receiver side of k_encode: the same predictor steps, the residual looked up from the transmitted symbols
+// (float64 entry sums narrowed to float32 exactly as the encoder does), so c_out equals the encoder's c_in.
+// A symbol outside its codebook sets *bad and decodes as "not coded".
+__global__ __launch_bounds__(NT) void k_decode_feat(const PredDev P, const CbDev C, const float* __restrict__ pitch,
+                                                    const int* __restrict__ idx, int Lf, float* __restrict__ c_out,
+                                                    int* bad) {
+    __shared__ PredLds L;
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int Cc = P.in, F = P.fc;
+    for (int i = tid; i < P.h1; i += NT) L.h1[i] = 0.0f;
+    for (int i = tid; i < P.h2; i += NT) L.h2[i] = 0.0f;
+    if (tid < Cc) L.x[tid] = 0.0f;
+    __syncthreads();
+    for (int i = 0; i < Lf; ++i) {
+        const size_t fi = (size_t)b * Lf + i;
+        pred_step(P, L, tid);
+        if (tid < F) {
+            const int* ix = idx + fi * 4;
+            float rq = 0.0f;
+            if (tid == 0) {
+                const int k = ix[0];
+                if (k >= 0) {
+                    if (k < C.n_hi)
+                        rq = (float)C.scl_hi[k];
+                    else if (C.scl_lo && k - C.n_hi < C.n_lo)
+                        rq = (float)C.scl_lo[k - C.n_hi];
+                    else
+                        atomicOr(bad, 1);
+                }
+            } else {
+                const int d = tid - 1, k1 = ix[1], k2 = ix[2], k3 = ix[3];
+                if (k1 >= 0) {
+                    if (k1 >= C.N_hi0 || (C.S_hi == 2 && (k2 < 0 || k2 >= C.N_hi1))) {
+                        atomicOr(bad, 1);
+                    } else {
+                        const double e0 = C.vq_hi0_r[(size_t)k1 * NDIM + d];
+                        rq = (float)(C.S_hi == 2 ? e0 + C.vq_hi1_r[(size_t)k2 * NDIM + d] : e0);
+                    }
+                } else if (k3 >= 0) {
+                    if (!C.vq_lo_r || k3 >= C.N_lo)
+                        atomicOr(bad, 1);
+                    else
+                        rq = (float)C.vq_lo_r[(size_t)k3 * NDIM + d];
+                }
+            }
+            const float cn = L.fo[tid] + rq;
+            c_out[fi * Cc + tid] = cn;
+            L.x[tid] = cn;
+        } else if (tid < Cc) {
+            const float v = pitch[fi * (Cc - F) + (tid - F)];
+            c_out[fi * Cc + tid] = v;
+            L.x[tid] = v;
+        }
+        __syncthreads();
+    }
+}
+
 // stand-alone quantizers: one workgroup per input row
 __global__ __launch_bounds__(NT) void k_vq(const CbDev C, int which, const float* __restrict__ r, double* qr,
                                            int* idx) {
@@ -640,6 +697,26 @@ extern "C" int fpc_encode(fpc_predictor* p, const fpc_codebooks* cb, const float
               idx_dev,  hist_dev};
     hipLaunchKernelGGL(k_encode, dim3(B), dim3(NT), 0, static_cast<hipStream_t>(s), p->d, cd, a);
     FPC_HIP(hipGetLastError());
+    return FPC_OK;
+}
+
+extern "C" int fpc_decode_features(fpc_predictor* p, const fpc_codebooks* cb, const float* pitch_dev,
+                                   const int32_t* idx_dev, int B, int L, float* c_out_dev, fpc_stream s) {
+    FPC_REQUIRE(p && cb && pitch_dev && idx_dev && c_out_dev, "fpc_decode_features: null argument");
+    FPC_REQUIRE(B > 0 && L >= 0, "fpc_decode_features: bad shape B=%d L=%d", B, L);
+    FPC_REQUIRE(p->d.fc == NDIM + 1, "fpc_decode_features: fc_units must be 18 (c0 + 17-dim VQ), got %d", p->d.fc);
+    if (L == 0) return FPC_OK;
+    hipStream_t st = static_cast<hipStream_t>(s);
+    fpc::DevBuf bad;
+    FPC_HIP(bad.alloc(sizeof(int)));
+    FPC_HIP(hipMemsetAsync(bad.p, 0, sizeof(int), st));
+    hipLaunchKernelGGL(k_decode_feat, dim3(B), dim3(NT), 0, st, p->d, cb->d, pitch_dev, idx_dev, L, c_out_dev,
+                       bad.as<int>());
+    FPC_HIP(hipGetLastError());
+    int h = 0;
+    FPC_HIP(hipMemcpyAsync(&h, bad.p, sizeof(int), hipMemcpyDeviceToHost, st));
+    FPC_HIP(hipStreamSynchronize(st));
+    FPC_REQUIRE(h == 0, "fpc_decode_features: a symbol lies outside its codebook (corrupt stream or wrong codebooks)");
     return FPC_OK;
 }
 

@@ -143,3 +143,19 @@ class Wavernn:
             cb_tot = [0, 0, 0, 0, 0]  # wavernn.py:189
         out = (c_in, r, r_qtz, r_under, ind1, ind2, cb_tot)
         return out + (idx,) if return_indices else out
+
+    def decode_indices(self, cfg, idx, pitch):
+        """Receiver side of `encoder(..., qtz=True, return_indices=True)` (the reference's
+        own `decoder`, wavernn.py:367-379, is dead code): c_in (B, L, 20) rebuilt from the symbols `idx`
+        (B, L, 4) and the pitch columns (B, L, 2) alone -- bit-identical to the encoder's c_in."""
+        h = self._handle()
+        dev = self.device
+        idx = torch.as_tensor(idx).to(dev, torch.int32).contiguous()
+        pitch = torch.as_tensor(pitch).to(dev, torch.float32).contiguous()
+        B, L, _ = idx.shape
+        cb = load_codebooks(cfg["cb_path"], cfg["scl_cb_path"], cfg.get("bl_cb_path") or None,
+                            cfg.get("bl_scl_cb_path") or None)
+        c_out = torch.empty(B, L, 20, device=dev)
+        _lib.check(_lib.lib().fpc_decode_features(h, cb.handle, pitch.data_ptr(), idx.data_ptr(), B, L,
+                                                  c_out.data_ptr(), _lib.stream_ptr()), "fpc_decode_features")
+        return c_out

@@ -112,6 +112,14 @@ FPC_API int fpc_encode(fpc_predictor* p, const fpc_codebooks* cb, const float* f
                float* r_under_dev, float* ind1_dev, float* ind2_dev, int32_t* idx_dev,
                unsigned long long* hist_dev, fpc_stream s);
 
+/* Receiver side of fpc_encode (the reference's own Wavernn.decoder, wavernn.py:367-379,
+ * is dead code): rebuilds c_in [B,L,20] from the symbols alone -- idx [B,L,4] exactly as fpc_encode wrote
+ * them, pitch [B,L,2] = feat[:,:,18:20] (side information) -- with the same predictor steps and the same
+ * dequantisation, so the result equals the encoder's c_in bit for bit.  Synchronises the stream; fails if
+ * a symbol lies outside its codebook. */
+FPC_API int fpc_decode_features(fpc_predictor* p, const fpc_codebooks* cb, const float* pitch_dev,
+                        const int32_t* idx_dev, int B, int L, float* c_out_dev, fpc_stream s);
+
 /* Stand-alone quantizers with the reference call shapes
  * (vq_quantize vq_func.py:134, scl_quantize vq_func.py:167).  Device pointers.
  *   which = 0: above-threshold codebook, 1: below-threshold codebook

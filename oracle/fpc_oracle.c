@@ -347,6 +347,67 @@ EXPORT int orc_encode(const orc_pred* p, const orc_codebooks* cb, const float* f
     return 0;
 }
 
+/* Receiver side of orc_encode (the reference's own Wavernn.decoder, wavernn.py:367-379,
+ * is dead code): rebuild c_in[:,1:,:] from the transmitted symbols alone.  idx [B,L,4] as written by
+ * orc_encode ({scalar idx (+n_hi when from the below-threshold codebook), vq stage 1, vq stage 2,
+ * below-threshold vq idx}, -1 = not coded), pitch [B,L,2] = feat[:,:,18:20] (side information).
+ * Same predictor steps and the same float64 -> float32 dequantisation as the encoder, so the output
+ * equals the encoder's c_in bit for bit. */
+EXPORT int orc_decode_features(const orc_pred* p, const orc_codebooks* cb, const float* pitch, const int* idx,
+                               int B, int L, float* c_out /*[B,L,20]*/) {
+    const int C = p->in, F = p->fc;
+    float* scratch = (float*)malloc(sizeof(float) * 6 * (size_t)(p->h1 > p->h2 ? p->h1 : p->h2));
+    float* h1 = (float*)malloc(sizeof(float) * p->h1);
+    float* h2 = (float*)malloc(sizeof(float) * p->h2);
+    float* cin = (float*)malloc(sizeof(float) * C);
+    float* fo = (float*)malloc(sizeof(float) * F);
+    int rc = 0;
+    for (int b = 0; b < B && rc == 0; ++b) {
+        memset(h1, 0, sizeof(float) * p->h1);
+        memset(h2, 0, sizeof(float) * p->h2);
+        memset(cin, 0, sizeof(float) * C);
+        for (int i = 0; i < L; ++i) {
+            const size_t fi = ((size_t)b * L + i);
+            const int* ix = idx + fi * 4;
+            pred_step(p, cin, h1, h2, fo, scratch);
+            float rq[18];
+            for (int d = 0; d < F; ++d) rq[d] = 0.0f;
+            if (ix[0] >= 0) {
+                if (ix[0] < cb->n_hi)
+                    rq[0] = (float)cb->scl_hi[ix[0]];
+                else if (cb->scl_lo && ix[0] - cb->n_hi < cb->n_lo)
+                    rq[0] = (float)cb->scl_lo[ix[0] - cb->n_hi];
+                else
+                    rc = -1;
+            }
+            if (ix[1] >= 0) {
+                if (ix[1] >= cb->N_hi[0] || (cb->S_hi == 2 && (ix[2] < 0 || ix[2] >= cb->N_hi[1]))) {
+                    rc = -1;
+                } else {
+                    const double* e0 = cb->vq_hi + (size_t)ix[1] * ORC_NDIM;
+                    const double* e1 = cb->S_hi == 2 ? cb->vq_hi + ((size_t)cb->N_hi[0] + ix[2]) * ORC_NDIM : NULL;
+                    for (int d = 0; d < ORC_NDIM; ++d) rq[1 + d] = (float)(e1 ? e0[d] + e1[d] : e0[d]);
+                }
+            } else if (ix[3] >= 0) {
+                if (!cb->vq_lo || ix[3] >= cb->N_lo)
+                    rc = -1;
+                else
+                    for (int d = 0; d < ORC_NDIM; ++d) rq[1 + d] = (float)cb->vq_lo[(size_t)ix[3] * ORC_NDIM + d];
+            }
+            float* cnext = c_out + fi * C;
+            for (int d = 0; d < F; ++d) cnext[d] = fo[d] + rq[d];
+            for (int d = F; d < C; ++d) cnext[d] = pitch[fi * (C - F) + (d - F)];
+            memcpy(cin, cnext, sizeof(float) * C);
+        }
+    }
+    free(scratch);
+    free(h1);
+    free(h2);
+    free(cin);
+    free(fo);
+    return rc;
+}
+
 /* ======================================================================
  * 4. cepstrum -> LPC  (src/ceps2lpc/ceps2lpc_vct.py)
  * ==================================================================== */

@@ -103,6 +103,17 @@ class Predictor:
         return out
 
 
+    def decode(self, cb, idx, pitch):
+        """receiver side: c_in[:,1:,:] from the symbols of encode() and the pitch columns"""
+        idx = np.ascontiguousarray(idx, dtype=np.int32)
+        pitch = _f32(pitch)
+        B, L, _ = idx.shape
+        out = np.zeros((B, L, 20), np.float32)
+        rc = lib().orc_decode_features(C.byref(self.s), C.byref(cb.s), _p(pitch), _p(idx), B, L, _p(out))
+        assert rc == 0, "oracle: symbol outside its codebook"
+        return out
+
+
 class _CB(C.Structure):
     _fields_ = [("S_hi", C.c_int), ("N_hi", C.c_int * 2), ("vq_hi", C.c_void_p), ("N_lo", C.c_int),
                 ("vq_lo", C.c_void_p), ("n_hi", C.c_int), ("scl_hi", C.c_void_p), ("n_lo", C.c_int),

@@ -430,3 +430,36 @@ def test_cb_update_production_size_properties(torch_cuda, synth, oracle):
     d2 = float(((cb_func.quantize(new, data[:20000]) - data[:20000]) ** 2).sum())
     d1 = float(((cb_func.quantize(cb, data[:20000]) - data[:20000]) ** 2).sum())
     assert d2 <= d1  # a Lloyd step does not increase the distortion (up to the re-assignment)
+
+
+# ---- receiver side on the GPU ----
+@pytest.mark.parametrize("which", ["full", "hi_only", "one_stage"])
+def test_decode_features_closes_the_loop(torch_cuda, model, synth, oracle, cb_paths, which):
+    """encode -> symbols -> bits -> symbols -> decode gives back the encoder's own reconstruction bit for bit"""
+    torch = torch_cuda
+    from fpcodec_amd import bitstream
+    from fpcodec_amd.vq_func import load_codebooks
+    cfg = dict(scl_cb_path=cb_paths["scl_hi"], cb_path=cb_paths["vq_hi"], bl_scl_cb_path=cb_paths["scl_lo"],
+               bl_cb_path=cb_paths["vq_lo"])
+    if which == "hi_only":
+        cfg.update(bl_scl_cb_path="", bl_cb_path="")
+    if which == "one_stage":
+        cfg.update(cb_path=cb_paths["vq_lo"], bl_cb_path="")
+    feat = synth.predictor_features(5, 90, utt0=800)
+    out = model.encoder(cfg, torch.from_numpy(feat), None, 0.09, 0.28, qtz=True, return_indices=True)
+    c_in, idx = out[0].cpu().numpy(), out[7].cpu().numpy()
+    sizes = load_codebooks(cfg["cb_path"], cfg["scl_cb_path"], cfg.get("bl_cb_path") or None,
+                           cfg.get("bl_scl_cb_path") or None).sizes
+    rebuilt = np.stack([bitstream.unpack(bitstream.pack(idx[b], sizes)[0], feat.shape[1], sizes) for b in range(5)])
+    assert np.array_equal(rebuilt, idx)
+    dec = model.decode_indices(cfg, rebuilt, feat[:, :, 18:20]).cpu().numpy()
+    assert np.array_equal(dec, c_in)
+    if which == "full":
+        c = synth.codebooks()
+        CB = oracle.Codebooks(c["vq_hi"], c["scl_hi"], c["vq_lo"], c["scl_lo"])
+        assert np.array_equal(dec, oracle.Predictor(synth.predictor_state_dict()).decode(CB, idx, feat[:, :, 18:20]))
+        bad = rebuilt.copy()
+        bad[0, 3, 0] = 100000  # not a symbol of any scalar codebook
+        from fpcodec_amd._lib import FpcError
+        with pytest.raises(FpcError, match="outside its codebook"):
+            model.decode_indices(cfg, bad, feat[:, :, 18:20])

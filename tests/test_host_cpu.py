@@ -213,3 +213,30 @@ def test_gloo_world2_sharding(tmp_path, oracle):
                        env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "rank 0 ok 0 3" in r.stdout and "rank 1 ok 3 6" in r.stdout
+
+
+# ---- receiver side: bitstream pack/unpack and the decoder restatement ----
+def test_bitstream_roundtrip_and_oracle_decoder(oracle, synth):
+    from fpcodec_amd import bitstream
+    c = synth.codebooks()
+    P = oracle.Predictor(synth.predictor_state_dict())
+    feat = synth.predictor_features(3, 60, utt0=700)
+    for CB in (oracle.Codebooks(c["vq_hi"], c["scl_hi"], c["vq_lo"], c["scl_lo"]),   # production: all four
+               oracle.Codebooks(c["vq_hi"], c["scl_hi"]),                               # nothing below threshold
+               oracle.Codebooks(c["vq_hi"][:1], c["scl_hi"], c["vq_lo"], None)):        # 1-stage VQ, no low scalar
+        o = P.encode(feat, CB, 0.09, 0.28, True)
+        rebuilt = np.zeros_like(o["idx"])
+        total = 0
+        for b in range(feat.shape[0]):
+            data, nbits = bitstream.pack(o["idx"][b], CB.sizes)
+            assert len(data) == (nbits + 7) // 8
+            rebuilt[b] = bitstream.unpack(data, feat.shape[1], CB.sizes)
+            total += nbits
+        assert np.array_equal(rebuilt, o["idx"])
+        assert abs(total / (feat.shape[0] * feat.shape[1]) - bitstream.bits_per_frame(o["idx"], CB.sizes)) < 1e-9
+        # the receiver needs nothing but the symbols and the pitch columns
+        dec = P.decode(CB, rebuilt, feat[:, :, 18:20])
+        assert np.array_equal(dec, o["c_in"])
+    # an all-quiet utterance costs the two flag bits (+ the below-threshold fields when those codebooks exist)
+    quiet = np.full((10, 4), -1, np.int32)
+    assert bitstream.pack(quiet, [256, 0, 1024, 1024, 0])[1] == 20
