@@ -240,3 +240,42 @@ def test_bitstream_roundtrip_and_oracle_decoder(oracle, synth):
     # an all-quiet utterance costs the two flag bits (+ the below-threshold fields when those codebooks exist)
     quiet = np.full((10, 4), -1, np.int32)
     assert bitstream.pack(quiet, [256, 0, 1024, 1024, 0])[1] == 20
+
+
+# ---- feature-file formats either side of the path ----
+def test_feature_windows_and_synthesis_frames(tmp_path):
+    from fpcodec_amd import features_io as F
+    nfr = 15 * 7 + 9
+    a = np.arange(nfr * 36, dtype=np.float32).reshape(nfr, 36)
+    a.tofile(tmp_path / "u_features.f32")
+    w = F.f32_to_windows(str(tmp_path / "u_features.f32"))
+    assert w.shape == (7, 19, 36)           # len // (15*36) windows (write_small_files.py:56), all inside the data
+    for k in range(7):                      # hop 15, 19 frames each (strides of write_small_files.py:60-64)
+        assert np.array_equal(w[k], a[15 * k:15 * k + 19])
+    q = w + 1000.0
+    nm, qf = F.synthesis_frames(w, q, chunks=3)
+    assert nm.shape == (45, 36) and qf.shape == (45, 36)
+    centre = np.concatenate([a[15 * k + 2:15 * k + 17] for k in (4, 5, 6)])  # the LAST 3 windows, centre frames
+    expect = centre.copy()
+    expect[:, -2:] += 1000.0               # pitch columns come from the quantised file (dataset_syn.py:72)
+    assert np.array_equal(nm, expect / np.float32(24.1))
+    assert np.array_equal(qf, centre + 1000.0)
+    nm2, _ = F.synthesis_frames(w[:2], None, chunks=5)   # short utterance: doubled until long enough
+    assert nm2.shape == (75, 36)
+    F.frames_to_f32(str(tmp_path / "o.f32"), centre)
+    from fpcodec_amd.lpcnet import read_features
+    assert np.array_equal(read_features(str(tmp_path / "o.f32")), centre)
+    assert F.f32_to_windows(a[:10].ravel()).shape == (0, 19, 36)
+
+
+def test_wav_writer_normalisation(tmp_path):
+    import wave
+    from fpcodec_amd import features_io as F
+    x = np.random.default_rng(3).normal(0, 300.0, 4000)
+    pcm = F.write_wav(str(tmp_path / "t.wav"), x)
+    ref = x / np.std(x)
+    ref = ref / np.max(np.abs(ref))        # synthesis_qtz.py:46-47
+    assert np.array_equal(pcm, np.rint(ref * 32767.0).astype(np.int16)) and np.abs(pcm).max() == 32767
+    with wave.open(str(tmp_path / "t.wav"), "rb") as w:
+        assert (w.getnchannels(), w.getsampwidth(), w.getframerate(), w.getnframes()) == (1, 2, 16000, 4000)
+        assert np.array_equal(np.frombuffer(w.readframes(4000), dtype="<i2"), pcm)
