@@ -1,0 +1,20 @@
+import sys, os, time, tempfile; sys.path.insert(0,'.')
+import numpy as np, torch, fpcodec_amd
+from fpcodec_amd.wavernn import Wavernn
+synth=fpcodec_amd.synth
+d=tempfile.mkdtemp(); c=synth.codebooks(); p={}
+for k,v in c.items():
+    p[k]=os.path.join(d,k+'.npy'); np.save(p[k],v)
+cfg=dict(scl_cb_path=p['scl_hi'],cb_path=p['vq_hi'],bl_scl_cb_path=p['scl_lo'],bl_cb_path=p['vq_lo'])
+cfg_hi=dict(scl_cb_path=p['scl_hi'],cb_path=p['vq_hi'],bl_scl_cb_path='',bl_cb_path='')
+m=Wavernn(20,384,128,18); m.load_state_dict(synth.predictor_state_dict())
+B=128
+f=torch.from_numpy(np.tile(synth.predictor_features(8,300),(16,1,1))[:B].copy()).cuda()
+def tm(fn):
+    fn(); torch.cuda.synchronize(); t=time.perf_counter(); fn(); torch.cuda.synchronize(); return (time.perf_counter()-t)*1e3
+print("encode full      %.2f ms"%tm(lambda: m.encoder(cfg,f,None,0.09,0.28)))
+print("encode hi only   %.2f ms"%tm(lambda: m.encoder(cfg_hi,f,None,0.09,0.28)))
+print("encode qtz=False %.2f ms"%tm(lambda: m.encoder(cfg,f,None,0.09,0.28,qtz=False)))
+print("encode l1=l2=0 (all frames coded) %.2f ms"%tm(lambda: m.encoder(cfg,f,None,0.0,0.0)))
+print("encode l=inf (none above) %.2f ms"%tm(lambda: m.encoder(cfg,f,None,1e9,1e9)))
+print("forward          %.2f ms"%tm(lambda: m.forward(f)))
