@@ -42,8 +42,9 @@ struct __attribute__((aligned(16))) PredLds {
     float x[MAX_IN];
     float h1[MAX_H1];
     float h2[MAX_H2];
-    float gi[3 * MAX_H1];
-    float gh[3 * MAX_H1];
+    float pi[4][3 * MAX_H1];  // segment sums of the input mat-vec rows [segment][row]
+    float ph[4][3 * MAX_H1];  // ... of the recurrent mat-vec rows
+    float pf[8][MAX_FC];      // ... of the output layer
     float relu[MAX_H2];
     float fo[MAX_FC];
     float rs[MAX_FC];
@@ -73,16 +74,17 @@ __device__ __forceinline__ float chain1(const float* __restrict__ wT, const floa
     return a;
 }
 
-// four adjacent rows (r..r+3, R % 4 == 0) advance together: one 16-byte load per k serves 4 chains, 16 k
+// four adjacent rows (r..r+3, R % 4 == 0) advance together: one 16-byte load per k serves 4 chains, CD k
 // in flight per block (dword loads would be bound by the texture-address unit, not by L2)
+constexpr int CD = 16;  // k-steps of 16-byte loads in flight per thread and block
 __device__ __forceinline__ void chain4(const float* __restrict__ wT, const float* v, int K, int R, int r, float4& a) {
     int k = 0;
-    for (; k + 16 <= K; k += 16) {
-        float4 w[16];
+    for (; k + CD <= K; k += CD) {
+        float4 w[CD];
 #pragma unroll
-        for (int j = 0; j < 16; ++j) w[j] = *reinterpret_cast<const float4*>(&wT[(size_t)(k + j) * R + r]);
+        for (int j = 0; j < CD; ++j) w[j] = *reinterpret_cast<const float4*>(&wT[(size_t)(k + j) * R + r]);
 #pragma unroll
-        for (int j = 0; j < 16; ++j) {
+        for (int j = 0; j < CD; ++j) {
             const float hv = v[k + j];
             a.x = fmaf(hv, w[j].x, a.x);
             a.y = fmaf(hv, w[j].y, a.y);
@@ -92,12 +94,12 @@ __device__ __forceinline__ void chain4(const float* __restrict__ wT, const float
     }
     int rem = K - k;  // tail (e.g. K = 20): all remaining loads in flight together
     if (rem > 0) {
-        float4 w[15];
+        float4 w[CD - 1];
 #pragma unroll
-        for (int j = 0; j < 15; ++j)
+        for (int j = 0; j < CD - 1; ++j)
             if (j < rem) w[j] = *reinterpret_cast<const float4*>(&wT[(size_t)(k + j) * R + r]);
 #pragma unroll
-        for (int j = 0; j < 15; ++j)
+        for (int j = 0; j < CD - 1; ++j)
             if (j < rem) {
                 const float hv = v[k + j];
                 a.x = fmaf(hv, w[j].x, a.x);
@@ -108,24 +110,43 @@ __device__ __forceinline__ void chain4(const float* __restrict__ wT, const float
     }
 }
 
-// ---- GRU layer: both mat-vecs as k-ordered fmaf chains, four adjacent rows per thread ----
+// Rows are evaluated in S contiguous segments of the input, one thread per (4 adjacent rows, segment): segment 0
+// is a k-ordered fmaf chain from the bias, the others start from 0, and the segment sums are added as a
+// balanced tree (oracle: fpc_segments / matvec_seg).  S depends on the row length only.
+__device__ __forceinline__ int segments(int K) {
+    const int S = K >= 256 ? 4 : (K >= 64 ? 2 : 1);
+    return K % S == 0 ? S : 1;
+}
+__device__ __forceinline__ float seg_tree(const float (*p)[3 * MAX_H1], int S, int row) {
+    if (S == 4) return (p[0][row] + p[1][row]) + (p[2][row] + p[3][row]);
+    if (S == 2) return p[0][row] + p[1][row];
+    return p[0][row];
+}
+
+// ---- GRU layer: both mat-vecs in one pass over (matrix, row quad, segment) work items ----
 __device__ void gru_layer(const float* __restrict__ wiT, const float* __restrict__ whT,
                           const float* __restrict__ bi, const float* __restrict__ bh,
-                          const float* x, int K, float* h, int H, float* gi, float* gh, int tid) {
-    const int R = 3 * H;
-    for (int r = 4 * tid; r < R; r += 4 * NT) {
-        float4 ai = *reinterpret_cast<const float4*>(&bi[r]);
-        float4 ah = *reinterpret_cast<const float4*>(&bh[r]);
-        chain4(wiT, x, K, R, r, ai);
-        chain4(whT, h, H, R, r, ah);
-        *reinterpret_cast<float4*>(&gi[r]) = ai;
-        *reinterpret_cast<float4*>(&gh[r]) = ah;
+                          const float* x, int K, float* h, int H, PredLds& L, int tid) {
+    const int R = 3 * H, Q = R / 4;
+    const int Si = segments(K), Sh = segments(H);
+    const int n_h = Q * Sh, n_all = n_h + Q * Si;
+    for (int it = tid; it < n_all; it += NT) {
+        const bool is_h = it < n_h;
+        const int j = is_h ? it : it - n_h;
+        const int q = j % Q, sg = j / Q;  // consecutive threads -> adjacent row quads: coalesced 16-byte loads
+        const int len = (is_h ? H : K) / (is_h ? Sh : Si), k0 = sg * len, r = 4 * q;
+        float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (sg == 0) a = *reinterpret_cast<const float4*>(&(is_h ? bh : bi)[r]);
+        chain4((is_h ? whT : wiT) + (size_t)k0 * R, (is_h ? h : x) + k0, len, R, r, a);
+        *reinterpret_cast<float4*>(&(is_h ? L.ph : L.pi)[sg][r]) = a;
     }
     __syncthreads();
     for (int i = tid; i < H; i += NT) {  // torch.nn.GRU gate rows [r; z; n]
-        const float r = fpc_sigmoidf(gi[i] + gh[i]);
-        const float z = fpc_sigmoidf(gi[H + i] + gh[H + i]);
-        const float n = fpc_tanhf(fmaf(r, gh[2 * H + i], gi[2 * H + i]));
+        const float gir = seg_tree(L.pi, Si, i), giz = seg_tree(L.pi, Si, H + i), gin = seg_tree(L.pi, Si, 2 * H + i);
+        const float ghr = seg_tree(L.ph, Sh, i), ghz = seg_tree(L.ph, Sh, H + i), ghn = seg_tree(L.ph, Sh, 2 * H + i);
+        const float r = fpc_sigmoidf(gir + ghr);
+        const float z = fpc_sigmoidf(giz + ghz);
+        const float n = fpc_tanhf(fmaf(r, ghn, gin));
         h[i] = fmaf(z, h[i] - n, n);
     }
     __syncthreads();
@@ -133,12 +154,22 @@ __device__ void gru_layer(const float* __restrict__ wiT, const float* __restrict
 
 // one frame of Wavernn.forward: L.x -> L.fo, states in L.h1/L.h2
 __device__ void pred_step(const PredDev& P, PredLds& L, int tid) {
-    gru_layer(P.w1i, P.w1h, P.b1i, P.b1h, L.x, P.in, L.h1, P.h1, L.gi, L.gh, tid);
-    gru_layer(P.w2i, P.w2h, P.b2i, P.b2h, L.h1, P.h1, L.h2, P.h2, L.gi, L.gh, tid);
+    gru_layer(P.w1i, P.w1h, P.b1i, P.b1h, L.x, P.in, L.h1, P.h1, L, tid);
+    gru_layer(P.w2i, P.w2h, P.b2i, P.b2h, L.h1, P.h1, L.h2, P.h2, L, tid);
     for (int i = tid; i < P.h2; i += NT) L.relu[i] = L.h2[i] > 0.0f ? L.h2[i] : 0.0f;
     __syncthreads();
+    const int Sf = (P.h2 % 8 == 0 && P.h2 >= 64) ? 8 : 1;  // the few output rows: 8 segments each
+    const int lenf = P.h2 / Sf;
+    if (tid < P.fc * Sf) {
+        const int o = tid % P.fc, sg = tid / P.fc;
+        L.pf[sg][o] = chain1(P.fcw + (size_t)sg * lenf * P.fc, L.relu + sg * lenf, lenf, P.fc, o, sg == 0 ? P.fcb[o] : 0.0f);
+    }
+    __syncthreads();
     if (tid < P.fc) {
-        const float acc = chain1(P.fcw, L.relu, P.h2, P.fc, tid, P.fcb[tid]);
+        float acc = L.pf[0][tid];
+        if (Sf == 8)
+            acc = ((L.pf[0][tid] + L.pf[1][tid]) + (L.pf[2][tid] + L.pf[3][tid])) +
+                  ((L.pf[4][tid] + L.pf[5][tid]) + (L.pf[6][tid] + L.pf[7][tid]));
         const float t = fpc_tanhf(acc);
         L.fo[tid] = t + t;  // the "dual" FC is the same Linear summed twice (wavernn.py:89-92)
     }

@@ -37,23 +37,35 @@ typedef struct {
     const float *fc_w, *fc_b;
 } orc_pred;
 
-/* y[row] = bias[row] + sum_k W[row][k] x[k]  as a k-ordered fmaf chain
- * (this is also what a gfx950 f32 MFMA accumulates, so the kernel can match). */
-static void matvec_chain(const float* W, const float* bias, const float* x, int rows, int cols,
-                         float* y) {
+/* The predictor's rows are evaluated in S contiguous segments of the input (the kernel gives every
+ * segment its own thread): segment 0 is a k-ordered fmaf chain from the bias (the order a gfx950 f32 MFMA accumulates in), the others
+ * start from 0, and the
+ * segment sums are added as a balanced tree.  S depends on the row length only. */
+static int fpc_segments(int K) {
+    const int S = K >= 256 ? 4 : (K >= 64 ? 2 : 1);
+    return K % S == 0 ? S : 1;
+}
+static void matvec_seg(const float* W, const float* bias, const float* x, int rows, int cols, int S, float* y) {
+    const int len = cols / S;
     for (int r = 0; r < rows; ++r) {
-        float acc = bias[r];
+        float part[8];
         const float* w = W + (size_t)r * cols;
-        for (int k = 0; k < cols; ++k) acc = fmaf(x[k], w[k], acc);
-        y[r] = acc;
+        for (int sgm = 0; sgm < S; ++sgm) {
+            float acc = sgm == 0 ? bias[r] : 0.0f;
+            for (int k = sgm * len; k < (sgm + 1) * len; ++k) acc = fmaf(x[k], w[k], acc);
+            part[sgm] = acc;
+        }
+        for (int st = 1; st < S; st <<= 1)
+            for (int q = 0; q + st < S; q += 2 * st) part[q] = part[q] + part[q + st];
+        y[r] = part[0];
     }
 }
 
 /* torch.nn.GRU cell, gate rows [r; z; n]  (wavernn.py:37-38,71,76) */
 static void gru_cell(const float* w_ih, const float* w_hh, const float* b_ih, const float* b_hh,
                      const float* x, int in, float* h, int H, float* gi, float* gh) {
-    matvec_chain(w_ih, b_ih, x, 3 * H, in, gi);
-    matvec_chain(w_hh, b_hh, h, 3 * H, H, gh);
+    matvec_seg(w_ih, b_ih, x, 3 * H, in, fpc_segments(in), gi);
+    matvec_seg(w_hh, b_hh, h, 3 * H, H, fpc_segments(H), gh);
     for (int i = 0; i < H; ++i) {
         const float r = fpc_sigmoidf(gi[i] + gh[i]);
         const float z = fpc_sigmoidf(gi[H + i] + gh[H + i]);
@@ -72,10 +84,11 @@ static void pred_step(const orc_pred* p, const float* x, float* h1, float* h2, f
     gru_cell(p->w2_ih, p->w2_hh, p->b2_ih, p->b2_hh, h1, p->h1, h2, p->h2, gi, gh);
     float* relu = gi;
     for (int i = 0; i < p->h2; ++i) relu[i] = h2[i] > 0.0f ? h2[i] : 0.0f;
+    float pre[64];
+    const int Sfc = (p->h2 % 8 == 0 && p->h2 >= 64) ? 8 : 1; /* the few output rows: 8 segments each */
+    matvec_seg(p->fc_w, p->fc_b, relu, p->fc, p->h2, Sfc, pre);
     for (int o = 0; o < p->fc; ++o) {
-        float acc = p->fc_b[o];
-        for (int k = 0; k < p->h2; ++k) acc = fmaf(relu[k], p->fc_w[(size_t)o * p->h2 + k], acc);
-        const float t = fpc_tanhf(acc);
+        const float t = fpc_tanhf(pre[o]);
         y[o] = t + t;
     }
 }
