@@ -1052,3 +1052,180 @@ EXPORT void orc_cb_mean0(const void* data, int data_f64, int nv, int nd, double*
         }
     }
 }
+
+/* ====================================================================
+ * Predictor training step: src/train_frame.py:53-120, the live branch (batch_idx <= 10):
+ * teacher-forced Wavernn.forward over the whole window, nn.MSELoss(feat_out[:, :-1], feat[:, 1:, :18]),
+ * autograd, torch.optim.Adam(lr).  Restated with explicit evaluation orders the kernels follow:
+ *  - forward = pred_step above (segmented chains), activations kept per frame;
+ *  - backward through time per utterance; transposed products (W^T d) as fmaf chains over the rows from 0;
+ *  - weight gradients = fmaf chains over the samples n = b*L + t in ascending order from 0 (what an f32 MFMA
+ *    accumulates), bias gradients = plain sums in the same order;
+ *  - Adam as torch's single-tensor path (lerp for the first moment), scalars in double on the host.
+ * ==================================================================== */
+typedef struct {
+    float *w1_ih, *w1_hh, *b1_ih, *b1_hh, *w2_ih, *w2_hh, *b2_ih, *b2_hh, *fc_w, *fc_b;
+} orc_params; /* torch layouts: weight [3H][K], bias [3H], fc_w [fc][H2], fc_b [fc] */
+
+static void gru_fwd_save(const float* w_ih, const float* w_hh, const float* b_ih, const float* b_hh, const float* x,
+                         int in, const float* h_prev, int H, float* r, float* z, float* n, float* hn, float* h,
+                         float* gi, float* gh) {
+    matvec_seg(w_ih, b_ih, x, 3 * H, in, fpc_segments(in), gi);
+    matvec_seg(w_hh, b_hh, h_prev, 3 * H, H, fpc_segments(H), gh);
+    for (int i = 0; i < H; ++i) {
+        r[i] = fpc_sigmoidf(gi[i] + gh[i]);
+        z[i] = fpc_sigmoidf(gi[H + i] + gh[H + i]);
+        hn[i] = gh[2 * H + i];
+        n[i] = fpc_tanhf(fmaf(r[i], hn[i], gi[2 * H + i]));
+        h[i] = fmaf(z[i], h_prev[i] - n[i], n[i]);
+    }
+}
+
+/* d_in[k] = sum_row W[row][k] d[row], fmaf chain over rows from 0 */
+static void matvec_t(const float* W, const float* d, int rows, int cols, float* out) {
+    for (int k = 0; k < cols; ++k) {
+        float acc = 0.0f;
+        for (int r = 0; r < rows; ++r) acc = fmaf(W[(size_t)r * cols + k], d[r], acc);
+        out[k] = acc;
+    }
+}
+
+static void gru_bwd(const float* w_ih, const float* w_hh, int in, int H, const float* dh, const float* r,
+                    const float* z, const float* n, const float* hn, const float* h_prev, float* dgi, float* dgh,
+                    float* dh_prev, float* dx) {
+    for (int i = 0; i < H; ++i) {
+        const float dn_raw = dh[i] * (1.0f - z[i]);
+        const float dnpre = dn_raw * fmaf(-n[i], n[i], 1.0f);
+        const float dz_raw = dh[i] * (h_prev[i] - n[i]);
+        const float dzpre = dz_raw * (z[i] * (1.0f - z[i]));
+        const float drpre = (dnpre * hn[i]) * (r[i] * (1.0f - r[i]));
+        dgi[i] = drpre;
+        dgi[H + i] = dzpre;
+        dgi[2 * H + i] = dnpre;
+        dgh[i] = drpre;
+        dgh[H + i] = dzpre;
+        dgh[2 * H + i] = dnpre * r[i];
+    }
+    matvec_t(w_hh, dgh, 3 * H, H, dh_prev);
+    for (int i = 0; i < H; ++i) dh_prev[i] = fmaf(dh[i], z[i], dh_prev[i]);
+    if (dx) matvec_t(w_ih, dgi, 3 * H, in, dx);
+}
+
+/* dW[row][k] = chain over n of d[n][row] * a[n][k];  db[row] = sum over n of d[n][row] */
+static void grad_w(const float* d, const float* a, size_t N, int rows, int cols, float* dW, float* db) {
+    for (int r = 0; r < rows; ++r) {
+        for (int k = 0; k < cols; ++k) {
+            float acc = 0.0f;
+            for (size_t n = 0; n < N; ++n) acc = fmaf(d[n * rows + r], a[n * cols + k], acc);
+            dW[(size_t)r * cols + k] = acc;
+        }
+        float s = 0.0f;
+        for (size_t n = 0; n < N; ++n) s = s + d[n * rows + r];
+        db[r] = s;
+    }
+}
+
+static void adam(float* p, float* m, float* v, const float* g, size_t n, float step_size, float bc2_sqrt) {
+    for (size_t i = 0; i < n; ++i) {
+        m[i] = fmaf(0.1f, g[i] - m[i], m[i]);              /* exp_avg.lerp_(grad, 1 - beta1) */
+        v[i] = fmaf(0.001f, g[i] * g[i], v[i] * 0.999f);   /* exp_avg_sq.mul_(beta2).addcmul_(grad, grad, 1 - beta2) */
+        const float denom = sqrtf(v[i]) / bc2_sqrt + 1e-8f;
+        p[i] = p[i] - step_size * (m[i] / denom);
+    }
+}
+
+/* One training step.  in/h1/h2/fc = 20/384/128/18 style sizes; params updated in place; m, v: Adam moments
+ * (10 arrays each, same shapes); step counts from 1.  grads (10 arrays) may be NULL.  Returns the loss. */
+EXPORT float orc_train_step(int in, int H1, int H2, int F, orc_params* P, orc_params* M, orc_params* V,
+                            orc_params* G, const float* feat, int B, int L, double lr, int step) {
+    const size_t N = (size_t)B * L;
+    float* x = (float*)calloc(N * in, 4);
+    float *h1p = calloc(N * H1, 4), *r1 = calloc(N * H1, 4), *z1 = calloc(N * H1, 4), *n1 = calloc(N * H1, 4),
+          *hn1 = calloc(N * H1, 4), *h1 = calloc(N * H1, 4);
+    float *h2p = calloc(N * H2, 4), *r2 = calloc(N * H2, 4), *z2 = calloc(N * H2, 4), *n2 = calloc(N * H2, 4),
+          *hn2 = calloc(N * H2, 4), *h2 = calloc(N * H2, 4), *relu = calloc(N * H2, 4);
+    float *th = calloc(N * F, 4), *dpre = calloc(N * F, 4);
+    float *dgi1 = calloc(N * 3 * H1, 4), *dgh1 = calloc(N * 3 * H1, 4), *dgi2 = calloc(N * 3 * H2, 4),
+          *dgh2 = calloc(N * 3 * H2, 4);
+    float* gi = (float*)malloc(4 * 3 * (size_t)(H1 > H2 ? H1 : H2));
+    float* gh = (float*)malloc(4 * 3 * (size_t)(H1 > H2 ? H1 : H2));
+    const int Sfc = (H2 % 8 == 0 && H2 >= 64) ? 8 : 1;
+    /* ---- forward, activations kept ---- */
+    for (int b = 0; b < B; ++b)
+        for (int t = 0; t < L; ++t) {
+            const size_t n = (size_t)b * L + t;
+            memcpy(x + n * in, feat + n * in, 4 * (size_t)in);
+            if (t > 0) {
+                memcpy(h1p + n * H1, h1 + (n - 1) * H1, 4 * (size_t)H1);
+                memcpy(h2p + n * H2, h2 + (n - 1) * H2, 4 * (size_t)H2);
+            }
+            gru_fwd_save(P->w1_ih, P->w1_hh, P->b1_ih, P->b1_hh, x + n * in, in, h1p + n * H1, H1, r1 + n * H1,
+                         z1 + n * H1, n1 + n * H1, hn1 + n * H1, h1 + n * H1, gi, gh);
+            gru_fwd_save(P->w2_ih, P->w2_hh, P->b2_ih, P->b2_hh, h1 + n * H1, H1, h2p + n * H2, H2, r2 + n * H2,
+                         z2 + n * H2, n2 + n * H2, hn2 + n * H2, h2 + n * H2, gi, gh);
+            for (int i = 0; i < H2; ++i) relu[n * H2 + i] = h2[n * H2 + i] > 0.0f ? h2[n * H2 + i] : 0.0f;
+            float pre[64];
+            matvec_seg(P->fc_w, P->fc_b, relu + n * H2, F, H2, Sfc, pre);
+            for (int o = 0; o < F; ++o) th[n * F + o] = fpc_tanhf(pre[o]);
+        }
+    /* ---- loss (float64 accumulation per utterance, then over utterances) and dL/dpre ---- */
+    const double cnt = (double)B * (L - 1) * F;
+    const float scale = (float)(2.0 / cnt);
+    double loss = 0.0;
+    for (int b = 0; b < B; ++b) {
+        double lb = 0.0;
+        for (int t = 0; t + 1 < L; ++t) {
+            const size_t n = (size_t)b * L + t;
+            for (int o = 0; o < F; ++o) {
+                const float y = th[n * F + o] + th[n * F + o];
+                const float diff = y - feat[(n + 1) * in + o];
+                lb += (double)diff * (double)diff;
+                const float g = diff * scale;
+                dpre[n * F + o] = (g + g) * fmaf(-th[n * F + o], th[n * F + o], 1.0f);
+            }
+        }
+        loss += lb;
+    }
+    loss /= cnt;
+    /* ---- backward through time ---- */
+    float *dh1n = calloc(H1, 4), *dh2n = calloc(H2, 4), *dh = calloc(H1 > H2 ? H1 : H2, 4), *dx2 = calloc(H1, 4),
+          *tmp = calloc(H1 > H2 ? H1 : H2, 4);
+    for (int b = 0; b < B; ++b) {
+        memset(dh1n, 0, 4 * (size_t)H1);
+        memset(dh2n, 0, 4 * (size_t)H2);
+        for (int t = L - 1; t >= 0; --t) {
+            const size_t n = (size_t)b * L + t;
+            matvec_t(P->fc_w, dpre + n * F, F, H2, tmp); /* d relu */
+            for (int i = 0; i < H2; ++i) dh[i] = (h2[n * H2 + i] > 0.0f ? tmp[i] : 0.0f) + dh2n[i];
+            gru_bwd(P->w2_ih, P->w2_hh, H1, H2, dh, r2 + n * H2, z2 + n * H2, n2 + n * H2, hn2 + n * H2, h2p + n * H2,
+                    dgi2 + n * 3 * H2, dgh2 + n * 3 * H2, dh2n, dx2);
+            for (int i = 0; i < H1; ++i) dh[i] = dx2[i] + dh1n[i];
+            gru_bwd(P->w1_ih, P->w1_hh, in, H1, dh, r1 + n * H1, z1 + n * H1, n1 + n * H1, hn1 + n * H1, h1p + n * H1,
+                    dgi1 + n * 3 * H1, dgh1 + n * 3 * H1, dh1n, NULL);
+        }
+    }
+    /* ---- parameter gradients ---- */
+    orc_params g;
+    const size_t sz[10] = {(size_t)3 * H1 * in, (size_t)3 * H1 * H1, (size_t)3 * H1, (size_t)3 * H1, (size_t)3 * H2 * H1,
+                           (size_t)3 * H2 * H2, (size_t)3 * H2, (size_t)3 * H2, (size_t)F * H2, (size_t)F};
+    float** gp = (float**)&g;
+    for (int k = 0; k < 10; ++k) gp[k] = (float*)calloc(sz[k], 4);
+    grad_w(dgi1, x, N, 3 * H1, in, g.w1_ih, g.b1_ih);
+    grad_w(dgh1, h1p, N, 3 * H1, H1, g.w1_hh, g.b1_hh);
+    grad_w(dgi2, h1, N, 3 * H2, H1, g.w2_ih, g.b2_ih);
+    grad_w(dgh2, h2p, N, 3 * H2, H2, g.w2_hh, g.b2_hh);
+    grad_w(dpre, relu, N, F, H2, g.fc_w, g.fc_b);
+    /* ---- Adam (torch.optim.Adam defaults: betas (0.9, 0.999), eps 1e-8) ---- */
+    const double bc1 = 1.0 - pow(0.9, step), bc2 = 1.0 - pow(0.999, step);
+    const float step_size = (float)(lr / bc1), bc2_sqrt = (float)sqrt(bc2);
+    float **pp = (float**)P, **mp = (float**)M, **vp = (float**)V, **go = G ? (float**)G : NULL;
+    for (int k = 0; k < 10; ++k) {
+        adam(pp[k], mp[k], vp[k], gp[k], sz[k], step_size, bc2_sqrt);
+        if (go) memcpy(go[k], gp[k], 4 * sz[k]);
+        free(gp[k]);
+    }
+    float* fr[] = {x, h1p, r1, z1, n1, hn1, h1, h2p, r2, z2, n2, hn2, h2, relu, th, dpre, dgi1, dgh1, dgi2, dgh2, gi,
+                   gh, dh1n, dh2n, dh, dx2, tmp};
+    for (size_t k = 0; k < sizeof fr / sizeof fr[0]; ++k) free(fr[k]);
+    return (float)loss;
+}

@@ -334,3 +334,40 @@ def cb_vq_train(data, codebook, nb_entries):
     for _ in range(10):
         codebook = cb_update(data, codebook, nb_entries)
     return codebook
+
+
+# ---- predictor training step (train_frame.py:53-120, live branch) ----
+TRAIN_KEYS = ["rnn1.weight_ih_l0", "rnn1.weight_hh_l0", "rnn1.bias_ih_l0", "rnn1.bias_hh_l0", "rnn2.weight_ih_l0",
+              "rnn2.weight_hh_l0", "rnn2.bias_ih_l0", "rnn2.bias_hh_l0", "dual_fc.0.weight", "dual_fc.0.bias"]
+
+
+class _Params(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("w1_ih", "w1_hh", "b1_ih", "b1_hh", "w2_ih", "w2_hh", "b2_ih", "b2_hh",
+                                          "fc_w", "fc_b")]
+
+
+class Trainer:
+    """state_dict (torch layouts) + Adam moments; step(feat) runs one restated training step in place"""
+
+    def __init__(self, state_dict, lr=1e-4):
+        self.p = {k: _f32(state_dict[k]).copy() for k in TRAIN_KEYS}
+        self.m = {k: np.zeros_like(v) for k, v in self.p.items()}
+        self.v = {k: np.zeros_like(v) for k, v in self.p.items()}
+        self.g = {k: np.zeros_like(v) for k, v in self.p.items()}
+        self.lr, self.t = float(lr), 0
+        self.h1 = self.p["rnn1.weight_hh_l0"].shape[1]
+        self.h2 = self.p["rnn2.weight_hh_l0"].shape[1]
+        self.fc, self.inf = self.p["dual_fc.0.weight"].shape[0], self.p["rnn1.weight_ih_l0"].shape[1]
+
+    def _s(self, d):
+        return _Params(*[d[k].ctypes.data for k in TRAIN_KEYS])
+
+    def step(self, feat):
+        feat = _f32(feat)
+        B, L, _ = feat.shape
+        self.t += 1
+        f = lib().orc_train_step
+        f.restype = C.c_float
+        P, M, V, G = self._s(self.p), self._s(self.m), self._s(self.v), self._s(self.g)
+        return float(f(self.inf, self.h1, self.h2, self.fc, C.byref(P), C.byref(M), C.byref(V), C.byref(G), _p(feat),
+                       B, L, C.c_double(self.lr), self.t))

@@ -197,3 +197,29 @@ def test_cb_vq_train_bit_exact(oracle, synth, golden):
         assert np.array_equal(c, g[f"stage{i}"])
         r = oracle.cb_quantize(c, r) - r
     assert np.array_equal(r, g["r_final"])
+
+
+# ---- predictor training step: oracle vs torch autograd + torch.optim.Adam (golden G8) ----
+def check_train_against_golden(g, losses, grads1, params2):
+    """shared by the CPU and GPU tests: gradients to 5e-6 of each tensor's largest entry (measured 7e-7), loss to
+    1e-6 relative, parameters after two Adam steps to 1e-7 (measured 8e-9; an Adam update is +-lr = 1e-4)"""
+    assert abs(losses[0] / float(g["loss0"]) - 1) < 1e-6 and abs(losses[1] / float(g["loss1"]) - 1) < 1e-6
+    for k, gr in grads1.items():
+        ref = g["g_" + k]
+        got = gr.ravel()[::37]
+        assert got.shape == ref.shape
+        assert np.abs(got - ref).max() <= 5e-6 * np.abs(ref).max() + 1e-12, k
+        assert abs(np.sqrt((gr.astype(np.float64) ** 2).sum()) / float(g["gn_" + k]) - 1) < 1e-4, k
+    for k, pr in params2.items():
+        assert np.abs(pr.ravel()[::37] - g["p_" + k]).max() <= 1e-7, k
+
+
+def test_train_step_vs_torch(oracle, synth, golden):
+    g = golden("g8_train_step")
+    tr = oracle.Trainer(synth.predictor_state_dict(), lr=1e-4)
+    feat = synth.predictor_features(6, 40, utt0=4000)
+    l0 = tr.step(feat)
+    grads1 = {k: v.copy() for k, v in tr.g.items()}
+    l1 = tr.step(feat)
+    check_train_against_golden(g, (l0, l1), grads1, tr.p)
+    assert l1 < l0  # the step goes downhill
