@@ -16,6 +16,7 @@
 // distances in float64 with numpy's pairwise association, so results match the CPU
 // oracle bit for bit and the reference's indices exactly.
 #include "fpc_common.h"
+#include <cmath>
 
 namespace {
 
@@ -124,9 +125,9 @@ __device__ __forceinline__ float seg_tree(const float (*p)[3 * MAX_H1], int S, i
 }
 
 // ---- GRU layer: both mat-vecs in one pass over (matrix, row quad, segment) work items ----
-__device__ void gru_layer(const float* __restrict__ wiT, const float* __restrict__ whT,
-                          const float* __restrict__ bi, const float* __restrict__ bh,
-                          const float* x, int K, float* h, int H, PredLds& L, int tid) {
+__device__ void gru_rows(const float* __restrict__ wiT, const float* __restrict__ whT,
+                         const float* __restrict__ bi, const float* __restrict__ bh,
+                         const float* x, int K, const float* h, int H, PredLds& L, int tid) {
     const int R = 3 * H, Q = R / 4;
     const int Si = segments(K), Sh = segments(H);
     const int n_h = Q * Sh, n_all = n_h + Q * Si;
@@ -141,6 +142,13 @@ __device__ void gru_layer(const float* __restrict__ wiT, const float* __restrict
         *reinterpret_cast<float4*>(&(is_h ? L.ph : L.pi)[sg][r]) = a;
     }
     __syncthreads();
+}
+
+__device__ void gru_layer(const float* __restrict__ wiT, const float* __restrict__ whT,
+                          const float* __restrict__ bi, const float* __restrict__ bh,
+                          const float* x, int K, float* h, int H, PredLds& L, int tid) {
+    gru_rows(wiT, whT, bi, bh, x, K, h, H, L, tid);
+    const int Si = segments(K), Sh = segments(H);
     for (int i = tid; i < H; i += NT) {  // torch.nn.GRU gate rows [r; z; n]
         const float gir = seg_tree(L.pi, Si, i), giz = seg_tree(L.pi, Si, H + i), gin = seg_tree(L.pi, Si, 2 * H + i);
         const float ghr = seg_tree(L.ph, Sh, i), ghz = seg_tree(L.ph, Sh, H + i), ghn = seg_tree(L.ph, Sh, 2 * H + i);
@@ -578,7 +586,275 @@ __global__ __launch_bounds__(NT) void k_scl(const CbDev C, int which, const floa
     }
 }
 
+// ---------------------------------------------------------------------------------
+// Predictor training step (src/train_frame.py:53-120, the live branch): teacher-forced
+// forward with the activations kept, MSE against the next frame, back-propagation through time, weight
+// gradients on the matrix cores, Adam.  Every evaluation order is the one of oracle/fpc_oracle.c
+// (orc_train_step): results are bit-identical to it; the oracle is pinned to torch autograd + torch.optim.Adam.
+// Weights, gradients and Adam moments live in the transposed layouts the inference kernels use ([K][3H]).
+// ---------------------------------------------------------------------------------
+struct TrainBufs {              // per sample n = b*L + t
+    float *h1p, *r1, *z1, *n1, *hn1, *h1;         // [N][H1]
+    float *h2p, *r2, *z2, *n2, *hn2, *h2, *relu;  // [N][H2]
+    float *th, *dpre;                             // [N][F]
+    float *dgi1, *dgh1;                           // [N][3*H1]
+    float *dgi2, *dgh2;                           // [N][3*H2]
+    double* lossb;                                // [B]
+};
+
+__device__ void gates_save(const float* h_prev_lds, float* h_lds, int K, int H, PredLds& L, size_t n, float* r_, float* z_,
+                           float* n_, float* hn_, float* hout, int tid) {
+    const int Si = segments(K), Sh = segments(H);
+    for (int i = tid; i < H; i += NT) {
+        const float gir = seg_tree(L.pi, Si, i), giz = seg_tree(L.pi, Si, H + i), gin = seg_tree(L.pi, Si, 2 * H + i);
+        const float ghr = seg_tree(L.ph, Sh, i), ghz = seg_tree(L.ph, Sh, H + i), ghn = seg_tree(L.ph, Sh, 2 * H + i);
+        const float r = fpc_sigmoidf(gir + ghr);
+        const float z = fpc_sigmoidf(giz + ghz);
+        const float nn = fpc_tanhf(fmaf(r, ghn, gin));
+        const float hv = fmaf(z, h_prev_lds[i] - nn, nn);
+        r_[n * H + i] = r;
+        z_[n * H + i] = z;
+        n_[n * H + i] = nn;
+        hn_[n * H + i] = ghn;
+        hout[n * H + i] = hv;
+        h_lds[i] = hv;
+    }
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(NT) void k_train_fwd(const PredDev P, const float* __restrict__ feat, int Lf,
+                                                  const TrainBufs T) {
+    __shared__ PredLds L;
+    const int b = blockIdx.x, tid = threadIdx.x;
+    for (int i = tid; i < P.h1; i += NT) L.h1[i] = 0.0f;
+    for (int i = tid; i < P.h2; i += NT) L.h2[i] = 0.0f;
+    __syncthreads();
+    for (int t = 0; t < Lf; ++t) {
+        const size_t n = (size_t)b * Lf + t;
+        if (tid < P.in) L.x[tid] = feat[n * P.in + tid];
+        for (int i = tid; i < P.h1; i += NT) T.h1p[n * P.h1 + i] = L.h1[i];
+        for (int i = tid; i < P.h2; i += NT) T.h2p[n * P.h2 + i] = L.h2[i];
+        __syncthreads();
+        gru_rows(P.w1i, P.w1h, P.b1i, P.b1h, L.x, P.in, L.h1, P.h1, L, tid);
+        gates_save(L.h1, L.h1, P.in, P.h1, L, n, T.r1, T.z1, T.n1, T.hn1, T.h1, tid);
+        gru_rows(P.w2i, P.w2h, P.b2i, P.b2h, L.h1, P.h1, L.h2, P.h2, L, tid);
+        gates_save(L.h2, L.h2, P.h1, P.h2, L, n, T.r2, T.z2, T.n2, T.hn2, T.h2, tid);
+        for (int i = tid; i < P.h2; i += NT) {
+            const float v = L.h2[i] > 0.0f ? L.h2[i] : 0.0f;
+            L.relu[i] = v;
+            T.relu[n * P.h2 + i] = v;
+        }
+        __syncthreads();
+        const int Sf = (P.h2 % 8 == 0 && P.h2 >= 64) ? 8 : 1, lenf = P.h2 / Sf;
+        if (tid < P.fc * Sf) {
+            const int o = tid % P.fc, sg = tid / P.fc;
+            L.pf[sg][o] = chain1(P.fcw + (size_t)sg * lenf * P.fc, L.relu + sg * lenf, lenf, P.fc, o, sg == 0 ? P.fcb[o] : 0.0f);
+        }
+        __syncthreads();
+        if (tid < P.fc) {
+            float acc = L.pf[0][tid];
+            if (Sf == 8)
+                acc = ((L.pf[0][tid] + L.pf[1][tid]) + (L.pf[2][tid] + L.pf[3][tid])) +
+                      ((L.pf[4][tid] + L.pf[5][tid]) + (L.pf[6][tid] + L.pf[7][tid]));
+            T.th[n * P.fc + tid] = fpc_tanhf(acc);
+        }
+        __syncthreads();
+    }
+}
+
+// dL/dpre of every frame and the utterance's share of the loss (float64, frames then outputs in order)
+__global__ __launch_bounds__(256) void k_train_loss(const float* __restrict__ feat, int in, int F, int Lf, float scale,
+                                                    const TrainBufs T) {
+    extern __shared__ float sh[];  // diff[(Lf-1)*F]
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int ne = (Lf - 1) * F;
+    for (int e = tid; e < Lf * F; e += 256) {
+        const int t = e / F, o = e - t * F;
+        const size_t n = (size_t)b * Lf + t;
+        float dp = 0.0f;
+        if (t + 1 < Lf) {
+            const float th = T.th[n * F + o];
+            const float y = th + th;
+            const float diff = y - feat[(n + 1) * in + o];
+            sh[e] = diff;
+            const float g = diff * scale;
+            dp = (g + g) * fmaf(-th, th, 1.0f);
+        }
+        T.dpre[n * F + o] = dp;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        double lb = 0.0;
+        for (int e = 0; e < ne; ++e) lb += (double)sh[e] * (double)sh[e];
+        T.lossb[b] = lb;
+    }
+}
+
+// fmaf chain from 0 over a contiguous weight row (16-byte loads, 16 in flight), len % 4 == 0
+__device__ __forceinline__ float rowdot(const float* __restrict__ w, const float* v, int len) {
+    float acc = 0.0f;
+    int k = 0;
+    for (; k + 64 <= len; k += 64) {
+        float4 q[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) q[j] = *reinterpret_cast<const float4*>(&w[k + 4 * j]);
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            acc = fmaf(q[j].x, v[k + 4 * j], acc);
+            acc = fmaf(q[j].y, v[k + 4 * j + 1], acc);
+            acc = fmaf(q[j].z, v[k + 4 * j + 2], acc);
+            acc = fmaf(q[j].w, v[k + 4 * j + 3], acc);
+        }
+    }
+    for (; k < len; ++k) acc = fmaf(w[k], v[k], acc);
+    return acc;
+}
+
+struct BwdLds {
+    float dh1n[MAX_H1], dh2n[MAX_H2], dh1[MAX_H1], dh2[MAX_H2];
+    float g1i[3 * MAX_H1], g1h[3 * MAX_H1], g2i[3 * MAX_H2], g2h[3 * MAX_H2];
+    float dp[MAX_FC];
+};
+
+__device__ __forceinline__ void gate_grads(float dh, float r, float z, float nn, float hn, float hp, float* gi, float* gh,
+                                           int H, int i) {
+    const float dn_raw = dh * (1.0f - z);
+    const float dnpre = dn_raw * fmaf(-nn, nn, 1.0f);
+    const float dz_raw = dh * (hp - nn);
+    const float dzpre = dz_raw * (z * (1.0f - z));
+    const float drpre = (dnpre * hn) * (r * (1.0f - r));
+    gi[i] = drpre;
+    gi[H + i] = dzpre;
+    gi[2 * H + i] = dnpre;
+    gh[i] = drpre;
+    gh[H + i] = dzpre;
+    gh[2 * H + i] = dnpre * r;
+}
+
+// back-propagation through time of one utterance; the transposed products W^T d are rows of the
+// transposed weight arrays: thread k streams its own contiguous row
+__global__ __launch_bounds__(NT) void k_train_bwd(const PredDev P, int Lf, const TrainBufs T) {
+    __shared__ BwdLds S;
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int H1 = P.h1, H2 = P.h2, F = P.fc;
+    for (int i = tid; i < H1; i += NT) S.dh1n[i] = 0.0f;
+    for (int i = tid; i < H2; i += NT) S.dh2n[i] = 0.0f;
+    __syncthreads();
+    for (int t = Lf - 1; t >= 0; --t) {
+        const size_t n = (size_t)b * Lf + t;
+        if (tid < F) S.dp[tid] = T.dpre[n * F + tid];
+        __syncthreads();
+        for (int i = tid; i < H2; i += NT) {  // output layer back, then the gates of GRU2
+            float dr = 0.0f;
+            for (int o = 0; o < F; ++o) dr = fmaf(P.fcw[(size_t)i * F + o], S.dp[o], dr);
+            const float dh = (T.h2[n * H2 + i] > 0.0f ? dr : 0.0f) + S.dh2n[i];
+            S.dh2[i] = dh;
+            gate_grads(dh, T.r2[n * H2 + i], T.z2[n * H2 + i], T.n2[n * H2 + i], T.hn2[n * H2 + i], T.h2p[n * H2 + i],
+                       S.g2i, S.g2h, H2, i);
+        }
+        __syncthreads();
+        for (int i = tid; i < 3 * H2; i += NT) {
+            T.dgi2[n * 3 * H2 + i] = S.g2i[i];
+            T.dgh2[n * 3 * H2 + i] = S.g2h[i];
+        }
+        for (int w = tid; w < H1 + H2; w += NT) {  // W_ih2^T dgi2 -> dh1 (part), W_hh2^T dgh2 -> dh2 of frame t-1
+            if (w < H1)
+                S.dh1[w] = rowdot(P.w2i + (size_t)w * 3 * H2, S.g2i, 3 * H2) + S.dh1n[w];
+            else {
+                const int k = w - H1;
+                S.dh2n[k] = fmaf(S.dh2[k], T.z2[n * H2 + k], rowdot(P.w2h + (size_t)k * 3 * H2, S.g2h, 3 * H2));
+            }
+        }
+        __syncthreads();
+        for (int i = tid; i < H1; i += NT)
+            gate_grads(S.dh1[i], T.r1[n * H1 + i], T.z1[n * H1 + i], T.n1[n * H1 + i], T.hn1[n * H1 + i],
+                       T.h1p[n * H1 + i], S.g1i, S.g1h, H1, i);
+        __syncthreads();
+        for (int i = tid; i < 3 * H1; i += NT) {
+            T.dgi1[n * 3 * H1 + i] = S.g1i[i];
+            T.dgh1[n * 3 * H1 + i] = S.g1h[i];
+        }
+        for (int k = tid; k < H1; k += NT)
+            S.dh1n[k] = fmaf(S.dh1[k], T.z1[n * H1 + k], rowdot(P.w1h + (size_t)k * 3 * H1, S.g1h, 3 * H1));
+        __syncthreads();
+    }
+}
+
+// C[k][r] = sum over n (ascending, fmaf chain from 0 = what the f32 MFMA accumulates) of A[n][k] * D[n][r]:
+// the gradient of a weight matrix in the transposed layout.  One wave = 16 k-rows x 64 r-columns
+// (1 A fragment, 4 D fragments per 4 samples), 4 waves per block.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void k_grad_tn(const float* __restrict__ A, int K, const float* __restrict__ D, int R,
+                                                 int N, float* __restrict__ C) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int k0 = blockIdx.y * 16, r0 = (blockIdx.x * 4 + wave) * 64;
+    if (r0 >= R) return;
+    const int fi = lane & 15, kq = lane >> 4;
+    const int ka = k0 + fi;
+    f32x4 acc[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    constexpr int UN = 8;  // groups of 4 samples fetched ahead of the MFMA chain (which stays in sample order)
+    for (int n0 = 0; n0 < N; n0 += 4 * UN) {
+        float a[UN], d[UN][4];
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            const int n = n0 + 4 * u + kq;
+            const bool vn = n < N;
+            a[u] = (vn && ka < K) ? A[(size_t)n * K + ka] : 0.0f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int rc = r0 + 16 * j + fi;
+                d[u][j] = (vn && rc < R) ? D[(size_t)n * R + rc] : 0.0f;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < UN; ++u)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u], d[u][j], acc[j], 0, 0, 0);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {  // C/D layout: col = lane & 15, row = (lane >> 4) * 4 + reg
+            const int kr = k0 + kq * 4 + v, rc = r0 + 16 * j + fi;
+            if (kr < K && rc < R) C[(size_t)kr * R + rc] = acc[j][v];
+        }
+}
+
+// bias gradient: plain sum over the samples in ascending order
+__global__ void k_colsum(const float* __restrict__ D, int R, int N, float* __restrict__ out) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= R) return;
+    float s = 0.0f;
+    int n = 0;
+    for (; n + 32 <= N; n += 32) {  // the adds stay in order; 32 loads in flight ahead of them
+        float v[32];
+#pragma unroll
+        for (int u = 0; u < 32; ++u) v[u] = D[(size_t)(n + u) * R + r];
+#pragma unroll
+        for (int u = 0; u < 32; ++u) s = s + v[u];
+    }
+    for (; n < N; ++n) s = s + D[(size_t)n * R + r];
+    out[r] = s;
+}
+
+// torch.optim.Adam, single-tensor path (betas 0.9 / 0.999, eps 1e-8, no weight decay)
+__global__ void k_adam(float* __restrict__ p, float* __restrict__ m, float* __restrict__ v, const float* __restrict__ g,
+                       size_t n, float step_size, float bc2_sqrt) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float gi = g[i];
+    const float mi = fmaf(0.1f, gi - m[i], m[i]);
+    const float vi = fmaf(0.001f, gi * gi, v[i] * 0.999f);
+    m[i] = mi;
+    v[i] = vi;
+    const float denom = sqrtf(vi) / bc2_sqrt + 1e-8f;
+    p[i] = p[i] - step_size * (mi / denom);
+}
+
 }  // namespace
+
 
 // =====================================================================================
 // host side
@@ -748,6 +1024,133 @@ extern "C" int fpc_decode_features(fpc_predictor* p, const fpc_codebooks* cb, co
     FPC_HIP(hipMemcpyAsync(&h, bad.p, sizeof(int), hipMemcpyDeviceToHost, st));
     FPC_HIP(hipStreamSynchronize(st));
     FPC_REQUIRE(h == 0, "fpc_decode_features: a symbol lies outside its codebook (corrupt stream or wrong codebooks)");
+    return FPC_OK;
+}
+
+// ---- training ----
+struct fpc_trainer {
+    fpc_predictor* p = nullptr;
+    int maxB = 0, maxL = 0, step = 0;
+    fpc::DevBuf ws, grad[10], m[10], v[10], lossb;
+    TrainBufs T;
+    size_t sz[10];
+};
+
+static float* param_ptr(fpc_predictor* p, int k) { return p->buf[k].as<float>(); }
+
+extern "C" int fpc_trainer_create(fpc_predictor* p, int max_B, int max_L, fpc_trainer** out) {
+    FPC_REQUIRE(p && out, "fpc_trainer_create: null argument");
+    FPC_REQUIRE(max_B > 0 && max_L > 1, "fpc_trainer_create: bad shape B=%d L=%d (L >= 2: the loss compares with the next frame)",
+                max_B, max_L);
+    FPC_REQUIRE(p->d.h1 % 4 == 0 && p->d.h2 % 4 == 0, "fpc_trainer_create: gru units must be multiples of 4");
+    fpc_trainer* t = new fpc_trainer();
+    t->p = p;
+    t->maxB = max_B;
+    t->maxL = max_L;
+    const int in = p->d.in, H1 = p->d.h1, H2 = p->d.h2, F = p->d.fc;
+    const size_t N = (size_t)max_B * max_L;
+    const size_t sz[10] = {(size_t)3 * H1 * in, (size_t)3 * H1 * H1, (size_t)3 * H1, (size_t)3 * H1, (size_t)3 * H2 * H1,
+                           (size_t)3 * H2 * H2, (size_t)3 * H2, (size_t)3 * H2, (size_t)F * H2, (size_t)F};
+    for (int k = 0; k < 10; ++k) {
+        t->sz[k] = sz[k];
+        FPC_HIP(t->grad[k].alloc(sz[k] * 4));
+        FPC_HIP(t->m[k].alloc(sz[k] * 4));
+        FPC_HIP(t->v[k].alloc(sz[k] * 4));
+        FPC_HIP(hipMemset(t->m[k].p, 0, sz[k] * 4));
+        FPC_HIP(hipMemset(t->v[k].p, 0, sz[k] * 4));
+    }
+    const size_t per = (size_t)6 * H1 + 7 * H2 + 2 * F + 6 * H1 + 6 * H2;
+    FPC_HIP(t->ws.alloc(N * per * 4));
+    FPC_HIP(t->lossb.alloc(sizeof(double) * (size_t)max_B));
+    float* q = t->ws.as<float>();
+    auto take = [&](size_t n) {
+        float* r = q;
+        q += n;
+        return r;
+    };
+    TrainBufs& T = t->T;
+    T.h1p = take(N * H1), T.r1 = take(N * H1), T.z1 = take(N * H1), T.n1 = take(N * H1), T.hn1 = take(N * H1), T.h1 = take(N * H1);
+    T.h2p = take(N * H2), T.r2 = take(N * H2), T.z2 = take(N * H2), T.n2 = take(N * H2), T.hn2 = take(N * H2), T.h2 = take(N * H2);
+    T.relu = take(N * H2);
+    T.th = take(N * F), T.dpre = take(N * F);
+    T.dgi1 = take(N * 3 * H1), T.dgh1 = take(N * 3 * H1), T.dgi2 = take(N * 3 * H2), T.dgh2 = take(N * 3 * H2);
+    T.lossb = t->lossb.as<double>();
+    *out = t;
+    return FPC_OK;
+}
+
+extern "C" void fpc_trainer_destroy(fpc_trainer* t) { delete t; }
+
+extern "C" int fpc_trainer_step(fpc_trainer* t, const float* feat_dev, int B, int L, double lr, float* loss_host,
+                                fpc_stream s) {
+    FPC_REQUIRE(t && feat_dev, "fpc_trainer_step: null argument");
+    FPC_REQUIRE(B > 0 && B <= t->maxB && L > 1 && L <= t->maxL, "fpc_trainer_step: shape B=%d L=%d outside the created %d x %d",
+                B, L, t->maxB, t->maxL);
+    hipStream_t st = static_cast<hipStream_t>(s);
+    fpc_predictor* p = t->p;
+    const PredDev& P = p->d;
+    const int in = P.in, H1 = P.h1, H2 = P.h2, F = P.fc;
+    const int N = B * L;
+    const TrainBufs& T = t->T;  // laid out for maxB x maxL; rows are addressed by n = b*L + t < maxB*maxL
+    hipLaunchKernelGGL(k_train_fwd, dim3(B), dim3(NT), 0, st, P, feat_dev, L, T);
+    const double cnt = (double)B * (L - 1) * F;
+    hipLaunchKernelGGL(k_train_loss, dim3(B), dim3(256), sizeof(float) * (size_t)L * F, st, feat_dev, in, F, L,
+                       (float)(2.0 / cnt), T);
+    hipLaunchKernelGGL(k_train_bwd, dim3(B), dim3(NT), 0, st, P, L, T);
+    struct G {
+        const float* A;
+        int K;
+        const float* D;
+        int R;
+        int w, b;
+    } gs[5] = {{feat_dev, in, T.dgi1, 3 * H1, 0, 2}, {T.h1p, H1, T.dgh1, 3 * H1, 1, 3}, {T.h1, H1, T.dgi2, 3 * H2, 4, 6},
+               {T.h2p, H2, T.dgh2, 3 * H2, 5, 7}, {T.relu, H2, T.dpre, F, 8, 9}};
+    for (const G& g : gs) {
+        hipLaunchKernelGGL(k_grad_tn, dim3((g.R + 255) / 256, (g.K + 15) / 16), dim3(256), 0, st, g.A, g.K, g.D, g.R, N,
+                           t->grad[g.w].as<float>());
+        hipLaunchKernelGGL(k_colsum, dim3((g.R + 63) / 64), dim3(64), 0, st, g.D, g.R, N, t->grad[g.b].as<float>());
+    }
+    t->step += 1;
+    const double bc1 = 1.0 - pow(0.9, t->step), bc2 = 1.0 - pow(0.999, t->step);
+    const float step_size = (float)(lr / bc1), bc2_sqrt = (float)sqrt(bc2);
+    for (int k = 0; k < 10; ++k)
+        hipLaunchKernelGGL(k_adam, dim3((unsigned)((t->sz[k] + 255) / 256)), dim3(256), 0, st, param_ptr(p, k),
+                           t->m[k].as<float>(), t->v[k].as<float>(), t->grad[k].as<float>(), t->sz[k], step_size, bc2_sqrt);
+    FPC_HIP(hipGetLastError());
+    if (loss_host) {
+        std::vector<double> lb(B);
+        FPC_HIP(hipMemcpyAsync(lb.data(), T.lossb, sizeof(double) * (size_t)B, hipMemcpyDeviceToHost, st));
+        FPC_HIP(hipStreamSynchronize(st));
+        double loss = 0.0;
+        for (int b = 0; b < B; ++b) loss += lb[b];
+        *loss_host = (float)(loss / cnt);
+    }
+    return FPC_OK;
+}
+
+// what = 0: parameters, 1: gradients of the last step; host arrays in torch layouts (fpc_predictor_weights)
+extern "C" int fpc_trainer_export(fpc_trainer* t, int what, const fpc_predictor_weights* out_host) {
+    FPC_REQUIRE(t && out_host && (what == 0 || what == 1), "fpc_trainer_export: bad argument");
+    const int in = t->p->d.in, H1 = t->p->d.h1, H2 = t->p->d.h2, F = t->p->d.fc;
+    float* dst[10] = {(float*)out_host->rnn1_weight_ih, (float*)out_host->rnn1_weight_hh, (float*)out_host->rnn1_bias_ih,
+                      (float*)out_host->rnn1_bias_hh,   (float*)out_host->rnn2_weight_ih, (float*)out_host->rnn2_weight_hh,
+                      (float*)out_host->rnn2_bias_ih,   (float*)out_host->rnn2_bias_hh,   (float*)out_host->fc_weight,
+                      (float*)out_host->fc_bias};
+    const int rows[10] = {3 * H1, 3 * H1, 0, 0, 3 * H2, 3 * H2, 0, 0, F, 0};   // torch rows of the matrices
+    const int cols[10] = {in, H1, 0, 0, H1, H2, 0, 0, H2, 0};
+    FPC_HIP(hipDeviceSynchronize());
+    for (int k = 0; k < 10; ++k) {
+        FPC_REQUIRE(dst[k], "fpc_trainer_export: null output pointer %d", k);
+        std::vector<float> h(t->sz[k]);
+        const void* src = what == 0 ? (const void*)param_ptr(t->p, k) : t->grad[k].p;
+        FPC_HIP(hipMemcpy(h.data(), src, t->sz[k] * 4, hipMemcpyDeviceToHost));
+        if (rows[k] == 0) {
+            memcpy(dst[k], h.data(), t->sz[k] * 4);
+        } else {  // device layout [cols][rows] -> torch [rows][cols]
+            for (int r = 0; r < rows[k]; ++r)
+                for (int c = 0; c < cols[k]; ++c) dst[k][(size_t)r * cols[k] + c] = h[(size_t)c * rows[k] + r];
+        }
+    }
     return FPC_OK;
 }
 

@@ -195,6 +195,20 @@ FPC_API float fpc_lpcnet_last_decode_ms(fpc_lpcnet* m);
  * 208, 408 or 1616 ("sparse product").  <0 on a null handle. */
 FPC_API int fpc_lpcnet_kernel_variant(const fpc_lpcnet* m);
 
+/* ---- predictor training step (src/train_frame.py:53-120, the live branch) ----
+ * One step = teacher-forced Wavernn.forward over feat [B,L,in] (device), nn.MSELoss(out[:, :-1],
+ * feat[:, 1:, :fc]), back-propagation, torch.optim.Adam(lr) (betas .9/.999, eps 1e-8).  The trainer updates
+ * the weights of the predictor handle it was created on in place (that handle keeps serving
+ * fpc_predictor_forward / fpc_encode with the new weights). */
+typedef struct fpc_trainer fpc_trainer;
+FPC_API int fpc_trainer_create(fpc_predictor* p, int max_B, int max_L, fpc_trainer** out);
+FPC_API void fpc_trainer_destroy(fpc_trainer* t);
+/* loss_host (host pointer, may be NULL) receives the loss of this step; passing it synchronises the stream */
+FPC_API int fpc_trainer_step(fpc_trainer* t, const float* feat_dev, int B, int L, double lr, float* loss_host,
+                     fpc_stream s);
+/* what = 0: current parameters, 1: gradients of the last step -> host arrays in torch layouts */
+FPC_API int fpc_trainer_export(fpc_trainer* t, int what, const fpc_predictor_weights* out_host);
+
 /* ---- codebook training primitives (src/quantization/cb_func.py) ----
  * 17-dimensional vectors only (cfg['code_dims'] of the production codebooks); entries <= 4096.
  * data_dev: [nv][nd] rows, float32 (data_f64 = 0: what train_cb.py:170-178 hands to the first stage) or

@@ -463,3 +463,45 @@ def test_decode_features_closes_the_loop(torch_cuda, model, synth, oracle, cb_pa
         from fpcodec_amd._lib import FpcError
         with pytest.raises(FpcError, match="outside its codebook"):
             model.decode_indices(cfg, bad, feat[:, :, 18:20])
+
+
+# ---- predictor training step on the GPU ----
+def test_train_step_vs_torch_golden_and_oracle(torch_cuda, synth, golden, oracle):
+    """two Adam steps: GPU == oracle bit for bit (losses, every gradient, every parameter); both within the
+    tolerances of tests/test_oracle_golden.py of torch autograd + torch.optim.Adam on the reference's Wavernn"""
+    torch = torch_cuda
+    from fpcodec_amd.train_frame import Trainer
+    from fpcodec_amd.wavernn import Wavernn
+    from test_oracle_golden import check_train_against_golden
+    m = Wavernn(in_features=20, gru_units1=384, gru_units2=128, fc_units=18)
+    m.load_state_dict(synth.predictor_state_dict())
+    feat = synth.predictor_features(6, 40, utt0=4000)
+    tr = Trainer(m, lr=1e-4, max_batch=8, max_frames=64)
+    ref = oracle.Trainer(synth.predictor_state_dict(), lr=1e-4)
+    l0, r0 = tr.step(feat), ref.step(feat)
+    g1 = tr.gradients()
+    for k in g1:
+        assert np.array_equal(g1[k], ref.g[k]), k
+    l1, r1 = tr.step(feat), ref.step(feat)
+    assert (l0, l1) == (r0, r1)
+    tr.sync()
+    sd = {k: v.numpy() for k, v in m.state_dict().items()}
+    for k in sd:
+        assert np.array_equal(sd[k], ref.p[k]), k
+    check_train_against_golden(golden("g8_train_step"), (l0, l1), g1, sd)
+    # the updated weights are live in the inference entry points
+    y = m.forward(torch.from_numpy(feat[:1]))[0].cpu().numpy()
+    yo = oracle.Predictor(sd).forward(feat[:1])[0]
+    assert np.array_equal(y, yo)
+
+
+def test_train_converges_at_reference_batch(torch_cuda, synth):
+    """train_frame.py:188-192 shapes (batch 100 x 150 frames): the loss falls over a few steps"""
+    from fpcodec_amd.train_frame import Trainer
+    from fpcodec_amd.wavernn import Wavernn
+    m = Wavernn(in_features=20, gru_units1=384, gru_units2=128, fc_units=18)
+    m.load_state_dict(synth.predictor_state_dict())
+    feat = synth.predictor_features(100, 150, utt0=6000)
+    tr = Trainer(m)
+    losses = [tr.step(feat) for _ in range(6)]
+    assert all(np.isfinite(losses)) and all(b < a for a, b in zip(losses, losses[1:])), losses  # lr 1e-4: ~0.3 % a step
