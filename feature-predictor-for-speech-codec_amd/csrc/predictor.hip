@@ -690,31 +690,35 @@ __global__ __launch_bounds__(256) void k_train_loss(const float* __restrict__ fe
     }
 }
 
-// fmaf chain from 0 over a contiguous weight row (16-byte loads, 16 in flight), len % 4 == 0
-__device__ __forceinline__ float rowdot(const float* __restrict__ w, const float* v, int len) {
-    float acc = 0.0f;
-    int k = 0;
-    for (; k + 64 <= len; k += 64) {
-        float4 q[16];
-#pragma unroll
-        for (int j = 0; j < 16; ++j) q[j] = *reinterpret_cast<const float4*>(&w[k + 4 * j]);
-#pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            acc = fmaf(q[j].x, v[k + 4 * j], acc);
-            acc = fmaf(q[j].y, v[k + 4 * j + 1], acc);
-            acc = fmaf(q[j].z, v[k + 4 * j + 2], acc);
-            acc = fmaf(q[j].w, v[k + 4 * j + 3], acc);
-        }
-    }
-    for (; k < len; ++k) acc = fmaf(w[k], v[k], acc);
-    return acc;
-}
-
 struct BwdLds {
     float dh1n[MAX_H1], dh2n[MAX_H2], dh1[MAX_H1], dh2[MAX_H2];
     float g1i[3 * MAX_H1], g1h[3 * MAX_H1], g2i[3 * MAX_H2], g2h[3 * MAX_H2];
+    float pa[4][MAX_H1];  // segment sums of the transposed products [segment][k]
+    float pb[4][MAX_H1];  // (same row pitch as pa: one helper serves both)
     float dp[MAX_FC];
 };
+
+// torch-layout copies ([3H][K], row r contiguous over k) of the matrices whose transposed products the
+// backward pass needs: with them `sum_r W[r][k] d[r]` is a coalesced chain like the forward's
+struct BwdW {
+    const float *w2i, *w2h, *w1h;
+};
+
+// all (4 adjacent k, row segment) work items of one transposed product: part[sg][k] = chain over the rows
+// of segment sg of W[r][k] d[r] from 0
+__device__ __forceinline__ void tprod_items(const float* __restrict__ W, const float* d, int rows, int cols,
+                                            float (*part)[MAX_H1], int item, int tid_unused) {
+    const int Q = cols / 4, S = segments(rows), len = rows / S;
+    const int q = item % Q, sg = item / Q;
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+    chain4(W + (size_t)sg * len * cols, d + sg * len, len, cols, 4 * q, a);
+    *reinterpret_cast<float4*>(&part[sg][4 * q]) = a;
+}
+__device__ __forceinline__ float tree4(const float (*p)[MAX_H1], int S, int k) {
+    if (S == 4) return (p[0][k] + p[1][k]) + (p[2][k] + p[3][k]);
+    if (S == 2) return p[0][k] + p[1][k];
+    return p[0][k];
+}
 
 __device__ __forceinline__ void gate_grads(float dh, float r, float z, float nn, float hn, float hp, float* gi, float* gh,
                                            int H, int i) {
@@ -731,9 +735,9 @@ __device__ __forceinline__ void gate_grads(float dh, float r, float z, float nn,
     gh[2 * H + i] = dnpre * r;
 }
 
-// back-propagation through time of one utterance; the transposed products W^T d are rows of the
-// transposed weight arrays: thread k streams its own contiguous row
-__global__ __launch_bounds__(NT) void k_train_bwd(const PredDev P, int Lf, const TrainBufs T) {
+// back-propagation through time of one utterance; the transposed products W^T d run on torch-layout copies
+// of the matrices as coalesced, row-segmented chains
+__global__ __launch_bounds__(NT) void k_train_bwd(const PredDev P, const BwdW W, int Lf, const TrainBufs T) {
     __shared__ BwdLds S;
     const int b = blockIdx.x, tid = threadIdx.x;
     const int H1 = P.h1, H2 = P.h2, F = P.fc;
@@ -757,12 +761,22 @@ __global__ __launch_bounds__(NT) void k_train_bwd(const PredDev P, int Lf, const
             T.dgi2[n * 3 * H2 + i] = S.g2i[i];
             T.dgh2[n * 3 * H2 + i] = S.g2h[i];
         }
-        for (int w = tid; w < H1 + H2; w += NT) {  // W_ih2^T dgi2 -> dh1 (part), W_hh2^T dgh2 -> dh2 of frame t-1
-            if (w < H1)
-                S.dh1[w] = rowdot(P.w2i + (size_t)w * 3 * H2, S.g2i, 3 * H2) + S.dh1n[w];
-            else {
-                const int k = w - H1;
-                S.dh2n[k] = fmaf(S.dh2[k], T.z2[n * H2 + k], rowdot(P.w2h + (size_t)k * 3 * H2, S.g2h, 3 * H2));
+        {  // W_ih2^T dgi2 -> dh1 (part), W_hh2^T dgh2 -> dh2 of frame t-1: (4 adjacent k, row segment) items
+            const int S2 = segments(3 * H2), na = (H1 / 4) * S2, nb = (H2 / 4) * S2;
+            for (int it = tid; it < na + nb; it += NT) {
+                if (it < na)
+                    tprod_items(W.w2i, S.g2i, 3 * H2, H1, S.pa, it, tid);
+                else
+                    tprod_items(W.w2h, S.g2h, 3 * H2, H2, S.pb, it - na, tid);
+            }
+            __syncthreads();
+            for (int w = tid; w < H1 + H2; w += NT) {
+                if (w < H1)
+                    S.dh1[w] = tree4(S.pa, S2, w) + S.dh1n[w];
+                else {
+                    const int k = w - H1;
+                    S.dh2n[k] = fmaf(S.dh2[k], T.z2[n * H2 + k], tree4(S.pb, S2, k));
+                }
             }
         }
         __syncthreads();
@@ -774,8 +788,12 @@ __global__ __launch_bounds__(NT) void k_train_bwd(const PredDev P, int Lf, const
             T.dgi1[n * 3 * H1 + i] = S.g1i[i];
             T.dgh1[n * 3 * H1 + i] = S.g1h[i];
         }
-        for (int k = tid; k < H1; k += NT)
-            S.dh1n[k] = fmaf(S.dh1[k], T.z1[n * H1 + k], rowdot(P.w1h + (size_t)k * 3 * H1, S.g1h, 3 * H1));
+        {
+            const int S1 = segments(3 * H1), n1 = (H1 / 4) * S1;
+            for (int it = tid; it < n1; it += NT) tprod_items(W.w1h, S.g1h, 3 * H1, H1, S.pa, it, tid);
+            __syncthreads();
+            for (int k = tid; k < H1; k += NT) S.dh1n[k] = fmaf(S.dh1[k], T.z1[n * H1 + k], tree4(S.pa, S1, k));
+        }
         __syncthreads();
     }
 }
@@ -784,8 +802,20 @@ __global__ __launch_bounds__(NT) void k_train_bwd(const PredDev P, int Lf, const
 // the gradient of a weight matrix in the transposed layout.  One wave = 16 k-rows x 64 r-columns
 // (1 A fragment, 4 D fragments per 4 samples), 4 waves per block.
 typedef float f32x4 __attribute__((ext_vector_type(4)));
-__global__ __launch_bounds__(256) void k_grad_tn(const float* __restrict__ A, int K, const float* __restrict__ D, int R,
-                                                 int N, float* __restrict__ C) {
+struct GradJobs {  // the five weight matrices of the predictor in one launch (blockIdx.z = job)
+    const float* A[5];
+    const float* D[5];
+    float* C[5];
+    float* bsum[5];
+    int K[5], R[5];
+};
+__global__ __launch_bounds__(256) void k_grad_tn(const GradJobs J, int N) {
+    const int job = blockIdx.z;
+    const float* __restrict__ A = J.A[job];
+    const float* __restrict__ D = J.D[job];
+    float* __restrict__ C = J.C[job];
+    const int K = J.K[job], R = J.R[job];
+    if ((int)blockIdx.y * 16 >= K) return;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int k0 = blockIdx.y * 16, r0 = (blockIdx.x * 4 + wave) * 64;
     if (r0 >= R) return;
@@ -822,8 +852,20 @@ __global__ __launch_bounds__(256) void k_grad_tn(const float* __restrict__ A, in
         }
 }
 
+// dst[r][k] = src[k][r]: refreshes the torch-layout copies after an Adam step
+__global__ void k_transpose(const float* __restrict__ src, int K, int R, float* __restrict__ dst) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)K * R) return;
+    const int r = (int)(i / K), k = (int)(i - (size_t)r * K);
+    dst[i] = src[(size_t)k * R + r];
+}
+
 // bias gradient: plain sum over the samples in ascending order
-__global__ void k_colsum(const float* __restrict__ D, int R, int N, float* __restrict__ out) {
+__global__ void k_colsum(const GradJobs J, int N) {
+    const int job = blockIdx.y;
+    const float* __restrict__ D = J.D[job];
+    float* __restrict__ out = J.bsum[job];
+    const int R = J.R[job];
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= R) return;
     float s = 0.0f;
@@ -1031,7 +1073,7 @@ extern "C" int fpc_decode_features(fpc_predictor* p, const fpc_codebooks* cb, co
 struct fpc_trainer {
     fpc_predictor* p = nullptr;
     int maxB = 0, maxL = 0, step = 0;
-    fpc::DevBuf ws, grad[10], m[10], v[10], lossb;
+    fpc::DevBuf ws, grad[10], m[10], v[10], lossb, wt[3];  // wt: torch-layout copies of w2i, w2h, w1h
     TrainBufs T;
     size_t sz[10];
 };
@@ -1062,6 +1104,10 @@ extern "C" int fpc_trainer_create(fpc_predictor* p, int max_B, int max_L, fpc_tr
     const size_t per = (size_t)6 * H1 + 7 * H2 + 2 * F + 6 * H1 + 6 * H2;
     FPC_HIP(t->ws.alloc(N * per * 4));
     FPC_HIP(t->lossb.alloc(sizeof(double) * (size_t)max_B));
+    FPC_HIP(t->wt[0].alloc(sz[4] * 4));
+    FPC_HIP(t->wt[1].alloc(sz[5] * 4));
+    FPC_HIP(t->wt[2].alloc(sz[1] * 4));
+    t->step = -1;  // the copies are filled by the first step
     float* q = t->ws.as<float>();
     auto take = [&](size_t n) {
         float* r = q;
@@ -1092,11 +1138,22 @@ extern "C" int fpc_trainer_step(fpc_trainer* t, const float* feat_dev, int B, in
     const int in = P.in, H1 = P.h1, H2 = P.h2, F = P.fc;
     const int N = B * L;
     const TrainBufs& T = t->T;  // laid out for maxB x maxL; rows are addressed by n = b*L + t < maxB*maxL
+    auto refresh = [&]() {  // torch-layout copies for the backward pass
+        const int kk[3] = {4, 5, 1}, Kd[3] = {H1, H2, H1}, Rd[3] = {3 * H2, 3 * H2, 3 * H1};
+        for (int c = 0; c < 3; ++c)
+            hipLaunchKernelGGL(k_transpose, dim3((unsigned)((t->sz[kk[c]] + 255) / 256)), dim3(256), 0, st, param_ptr(p, kk[c]),
+                               Kd[c], Rd[c], t->wt[c].as<float>());
+    };
+    if (t->step < 0) {
+        refresh();
+        t->step = 0;
+    }
     hipLaunchKernelGGL(k_train_fwd, dim3(B), dim3(NT), 0, st, P, feat_dev, L, T);
     const double cnt = (double)B * (L - 1) * F;
     hipLaunchKernelGGL(k_train_loss, dim3(B), dim3(256), sizeof(float) * (size_t)L * F, st, feat_dev, in, F, L,
                        (float)(2.0 / cnt), T);
-    hipLaunchKernelGGL(k_train_bwd, dim3(B), dim3(NT), 0, st, P, L, T);
+    const BwdW bw{t->wt[0].as<float>(), t->wt[1].as<float>(), t->wt[2].as<float>()};
+    hipLaunchKernelGGL(k_train_bwd, dim3(B), dim3(NT), 0, st, P, bw, L, T);
     struct G {
         const float* A;
         int K;
@@ -1105,17 +1162,24 @@ extern "C" int fpc_trainer_step(fpc_trainer* t, const float* feat_dev, int B, in
         int w, b;
     } gs[5] = {{feat_dev, in, T.dgi1, 3 * H1, 0, 2}, {T.h1p, H1, T.dgh1, 3 * H1, 1, 3}, {T.h1, H1, T.dgi2, 3 * H2, 4, 6},
                {T.h2p, H2, T.dgh2, 3 * H2, 5, 7}, {T.relu, H2, T.dpre, F, 8, 9}};
-    for (const G& g : gs) {
-        hipLaunchKernelGGL(k_grad_tn, dim3((g.R + 255) / 256, (g.K + 15) / 16), dim3(256), 0, st, g.A, g.K, g.D, g.R, N,
-                           t->grad[g.w].as<float>());
-        hipLaunchKernelGGL(k_colsum, dim3((g.R + 63) / 64), dim3(64), 0, st, g.D, g.R, N, t->grad[g.b].as<float>());
+    GradJobs J;
+    int maxR = 0, maxK = 0;
+    for (int j = 0; j < 5; ++j) {
+        const G& g = gs[j];
+        J.A[j] = g.A, J.D[j] = g.D, J.C[j] = t->grad[g.w].as<float>(), J.bsum[j] = t->grad[g.b].as<float>();
+        J.K[j] = g.K, J.R[j] = g.R;
+        maxR = g.R > maxR ? g.R : maxR;
+        maxK = g.K > maxK ? g.K : maxK;
     }
+    hipLaunchKernelGGL(k_grad_tn, dim3((maxR + 255) / 256, (maxK + 15) / 16, 5), dim3(256), 0, st, J, N);
+    hipLaunchKernelGGL(k_colsum, dim3((maxR + 63) / 64, 5), dim3(64), 0, st, J, N);
     t->step += 1;
     const double bc1 = 1.0 - pow(0.9, t->step), bc2 = 1.0 - pow(0.999, t->step);
     const float step_size = (float)(lr / bc1), bc2_sqrt = (float)sqrt(bc2);
     for (int k = 0; k < 10; ++k)
         hipLaunchKernelGGL(k_adam, dim3((unsigned)((t->sz[k] + 255) / 256)), dim3(256), 0, st, param_ptr(p, k),
                            t->m[k].as<float>(), t->v[k].as<float>(), t->grad[k].as<float>(), t->sz[k], step_size, bc2_sqrt);
+    refresh();
     FPC_HIP(hipGetLastError());
     if (loss_host) {
         std::vector<double> lb(B);

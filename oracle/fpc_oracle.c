@@ -1081,12 +1081,20 @@ static void gru_fwd_save(const float* w_ih, const float* w_hh, const float* b_ih
     }
 }
 
-/* d_in[k] = sum_row W[row][k] d[row], fmaf chain over rows from 0 */
+/* d_in[k] = sum_row W[row][k] d[row]: the rows in fpc_segments(rows) contiguous segments, each an fmaf chain
+ * from 0, segment sums added as a balanced tree (one thread per (4 adjacent k, segment) in the kernel) */
 static void matvec_t(const float* W, const float* d, int rows, int cols, float* out) {
+    const int S = fpc_segments(rows), len = rows / S;
     for (int k = 0; k < cols; ++k) {
-        float acc = 0.0f;
-        for (int r = 0; r < rows; ++r) acc = fmaf(W[(size_t)r * cols + k], d[r], acc);
-        out[k] = acc;
+        float part[8];
+        for (int sg = 0; sg < S; ++sg) {
+            float acc = 0.0f;
+            for (int r = sg * len; r < (sg + 1) * len; ++r) acc = fmaf(W[(size_t)r * cols + k], d[r], acc);
+            part[sg] = acc;
+        }
+        for (int st = 1; st < S; st <<= 1)
+            for (int q = 0; q + st < S; q += 2 * st) part[q] = part[q] + part[q + st];
+        out[k] = part[0];
     }
 }
 
