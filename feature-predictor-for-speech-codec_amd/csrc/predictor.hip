@@ -205,16 +205,57 @@ __device__ __forceinline__ double dist17(const double* x, const double* __restri
     return res;
 }
 
-__device__ __forceinline__ void wave_argmin(double& d, int& i) {
-#pragma unroll
-    for (int s = 1; s < 64; s <<= 1) {
-        const double od = __shfl_xor(d, s);
-        const int oi = __shfl_xor(i, s);
-        if (od < d || (od == d && oi < i)) {
-            d = od;
-            i = oi;
-        }
+// (distance, index) minimum over the wave, ties to the lower index; every lane gets the result.  The first four
+// exchange steps stay inside the 16-lane rows (DPP: no LDS crossbar), only the last two cross rows.  The result
+// does not depend on the pairing order (a minimum of a set).
+template <int CTRL>
+__device__ __forceinline__ void dpp_pair(double d, int i, double& od, int& oi) {
+    const unsigned long long b = (unsigned long long)__double_as_longlong(d);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)(unsigned)b, CTRL, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(unsigned)(b >> 32), CTRL, 0xf, 0xf, true);
+    od = __longlong_as_double((long long)(((unsigned long long)(unsigned)hi << 32) | (unsigned)lo));
+    oi = __builtin_amdgcn_update_dpp(0, i, CTRL, 0xf, 0xf, true);
+}
+__device__ __forceinline__ void take_min(double& d, int& i, double od, int oi) {
+    if (od < d || (od == d && oi < i)) {
+        d = od;
+        i = oi;
     }
+}
+__device__ __forceinline__ void wave_argmin(double& d, int& i) {
+    double od;
+    int oi;
+    dpp_pair<0xB1>(d, i, od, oi);  // quad_perm [1,0,3,2]
+    take_min(d, i, od, oi);
+    dpp_pair<0x4E>(d, i, od, oi);  // quad_perm [2,3,0,1]
+    take_min(d, i, od, oi);
+    dpp_pair<0x141>(d, i, od, oi);  // row_half_mirror
+    take_min(d, i, od, oi);
+    dpp_pair<0x140>(d, i, od, oi);  // row_mirror
+    take_min(d, i, od, oi);
+    // across rows: rows 1,3 take the minimum of row 0,2 (row_bcast:15), rows 2,3 that of rows 0-1 (row_bcast:31);
+    // lane 63 then holds the wave's minimum, handed to every lane through SGPRs
+    {
+        const unsigned long long b = (unsigned long long)__double_as_longlong(d);
+        const int lo = __builtin_amdgcn_update_dpp((int)(unsigned)b, (int)(unsigned)b, 0x142, 0xa, 0xf, false);
+        const int hi = __builtin_amdgcn_update_dpp((int)(unsigned)(b >> 32), (int)(unsigned)(b >> 32), 0x142, 0xa, 0xf, false);
+        oi = __builtin_amdgcn_update_dpp(i, i, 0x142, 0xa, 0xf, false);
+        od = __longlong_as_double((long long)(((unsigned long long)(unsigned)hi << 32) | (unsigned)lo));
+        take_min(d, i, od, oi);
+    }
+    {
+        const unsigned long long b = (unsigned long long)__double_as_longlong(d);
+        const int lo = __builtin_amdgcn_update_dpp((int)(unsigned)b, (int)(unsigned)b, 0x143, 0xc, 0xf, false);
+        const int hi = __builtin_amdgcn_update_dpp((int)(unsigned)(b >> 32), (int)(unsigned)(b >> 32), 0x143, 0xc, 0xf, false);
+        oi = __builtin_amdgcn_update_dpp(i, i, 0x143, 0xc, 0xf, false);
+        od = __longlong_as_double((long long)(((unsigned long long)(unsigned)hi << 32) | (unsigned)lo));
+        take_min(d, i, od, oi);
+    }
+    const unsigned long long b = (unsigned long long)__double_as_longlong(d);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)b, 63);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(b >> 32), 63);
+    d = __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+    i = __builtin_amdgcn_readlane(i, 63);
 }
 
 // per-wave M-best (5 smallest by (distance, index)) of search `srch` -> L.wd/L.wi
