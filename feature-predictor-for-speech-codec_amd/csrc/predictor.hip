@@ -848,14 +848,17 @@ struct GradJobs {  // the five weight matrices of the predictor in one launch (b
     const float* D[5];
     float* C[5];
     float* bsum[5];
+    float* part[5];  // [GSEG][K][R] segment sums
     int K[5], R[5];
 };
-__global__ __launch_bounds__(256) void k_grad_tn(const GradJobs J, int N) {
-    const int job = blockIdx.z;
+constexpr int GSEG = 8;  // sample segments per gradient tile (oracle: ORC_GSEG)
+__global__ __launch_bounds__(256) void k_grad_tn(const GradJobs J, int N, int seglen) {
+    const int job = blockIdx.z / GSEG, sg = blockIdx.z % GSEG;
     const float* __restrict__ A = J.A[job];
     const float* __restrict__ D = J.D[job];
-    float* __restrict__ C = J.C[job];
     const int K = J.K[job], R = J.R[job];
+    float* __restrict__ C = J.part[job] + (size_t)sg * K * R;
+    const int nbeg = sg * seglen, nend = (sg + 1) * seglen < N ? (sg + 1) * seglen : N;
     if ((int)blockIdx.y * 16 >= K) return;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int k0 = blockIdx.y * 16, r0 = (blockIdx.x * 4 + wave) * 64;
@@ -866,12 +869,12 @@ __global__ __launch_bounds__(256) void k_grad_tn(const GradJobs J, int N) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
     constexpr int UN = 8;  // groups of 4 samples fetched ahead of the MFMA chain (which stays in sample order)
-    for (int n0 = 0; n0 < N; n0 += 4 * UN) {
+    for (int n0 = nbeg; n0 < nend; n0 += 4 * UN) {
         float a[UN], d[UN][4];
 #pragma unroll
         for (int u = 0; u < UN; ++u) {
             const int n = n0 + 4 * u + kq;
-            const bool vn = n < N;
+            const bool vn = n < nend;
             a[u] = (vn && ka < K) ? A[(size_t)n * K + ka] : 0.0f;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -899,6 +902,16 @@ __global__ void k_transpose(const float* __restrict__ src, int K, int R, float* 
     if (i >= (size_t)K * R) return;
     const int r = (int)(i / K), k = (int)(i - (size_t)r * K);
     dst[i] = src[(size_t)k * R + r];
+}
+
+// segment sums -> gradient, balanced tree
+__global__ void k_grad_reduce(const GradJobs J) {
+    const int job = blockIdx.y;
+    const size_t n = (size_t)J.K[job] * J.R[job];
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float* p = J.part[job];
+    J.C[job][i] = ((p[i] + p[n + i]) + (p[2 * n + i] + p[3 * n + i])) + ((p[4 * n + i] + p[5 * n + i]) + (p[6 * n + i] + p[7 * n + i]));
 }
 
 // bias gradient: plain sum over the samples in ascending order
@@ -1114,7 +1127,7 @@ extern "C" int fpc_decode_features(fpc_predictor* p, const fpc_codebooks* cb, co
 struct fpc_trainer {
     fpc_predictor* p = nullptr;
     int maxB = 0, maxL = 0, step = 0;
-    fpc::DevBuf ws, grad[10], m[10], v[10], lossb, wt[3];  // wt: torch-layout copies of w2i, w2h, w1h
+    fpc::DevBuf ws, grad[10], m[10], v[10], lossb, wt[3], gpart[5];  // wt: torch-layout copies of w2i, w2h, w1h
     TrainBufs T;
     size_t sz[10];
 };
@@ -1145,6 +1158,10 @@ extern "C" int fpc_trainer_create(fpc_predictor* p, int max_B, int max_L, fpc_tr
     const size_t per = (size_t)6 * H1 + 7 * H2 + 2 * F + 6 * H1 + 6 * H2;
     FPC_HIP(t->ws.alloc(N * per * 4));
     FPC_HIP(t->lossb.alloc(sizeof(double) * (size_t)max_B));
+    {
+        const int wi[5] = {0, 1, 4, 5, 8};
+        for (int j = 0; j < 5; ++j) FPC_HIP(t->gpart[j].alloc(sz[wi[j]] * 4 * GSEG));
+    }
     FPC_HIP(t->wt[0].alloc(sz[4] * 4));
     FPC_HIP(t->wt[1].alloc(sz[5] * 4));
     FPC_HIP(t->wt[2].alloc(sz[1] * 4));
@@ -1209,10 +1226,13 @@ extern "C" int fpc_trainer_step(fpc_trainer* t, const float* feat_dev, int B, in
         const G& g = gs[j];
         J.A[j] = g.A, J.D[j] = g.D, J.C[j] = t->grad[g.w].as<float>(), J.bsum[j] = t->grad[g.b].as<float>();
         J.K[j] = g.K, J.R[j] = g.R;
+        J.part[j] = t->gpart[j].as<float>();
         maxR = g.R > maxR ? g.R : maxR;
         maxK = g.K > maxK ? g.K : maxK;
     }
-    hipLaunchKernelGGL(k_grad_tn, dim3((maxR + 255) / 256, (maxK + 15) / 16, 5), dim3(256), 0, st, J, N);
+    const int seglen = ((N + 4 * GSEG - 1) / (4 * GSEG)) * 4;
+    hipLaunchKernelGGL(k_grad_tn, dim3((maxR + 255) / 256, (maxK + 15) / 16, 5 * GSEG), dim3(256), 0, st, J, N, seglen);
+    hipLaunchKernelGGL(k_grad_reduce, dim3((unsigned)(((size_t)maxK * maxR + 255) / 256), 5), dim3(256), 0, st, J);
     hipLaunchKernelGGL(k_colsum, dim3((maxR + 63) / 64, 5), dim3(64), 0, st, J, N);
     t->step += 1;
     const double bc1 = 1.0 - pow(0.9, t->step), bc2 = 1.0 - pow(0.999, t->step);

@@ -1059,8 +1059,8 @@ EXPORT void orc_cb_mean0(const void* data, int data_f64, int nv, int nd, double*
  * autograd, torch.optim.Adam(lr).  Restated with explicit evaluation orders the kernels follow:
  *  - forward = pred_step above (segmented chains), activations kept per frame;
  *  - backward through time per utterance; transposed products (W^T d) as fmaf chains over the rows from 0;
- *  - weight gradients = fmaf chains over the samples n = b*L + t in ascending order from 0 (what an f32 MFMA
- *    accumulates), bias gradients = plain sums in the same order;
+ *  - weight gradients = 8 contiguous segments of the samples n = b*L + t, each an fmaf chain from 0 (what an f32
+ *    MFMA accumulates), added as a balanced tree; bias gradients = plain sums over n;
  *  - Adam as torch's single-tensor path (lerp for the first moment), scalars in double on the host.
  * ==================================================================== */
 typedef struct {
@@ -1119,13 +1119,22 @@ static void gru_bwd(const float* w_ih, const float* w_hh, int in, int H, const f
     if (dx) matvec_t(w_ih, dgi, 3 * H, in, dx);
 }
 
-/* dW[row][k] = chain over n of d[n][row] * a[n][k];  db[row] = sum over n of d[n][row] */
+/* dW[row][k] = sum over the samples n of d[n][row] * a[n][k]: the samples in 8 contiguous segments (lengths a
+ * multiple of 4), each an fmaf chain from 0 (what an f32 MFMA accumulates), the segment sums added as a
+ * balanced tree;  db[row] = plain sum over n of d[n][row] */
+#define ORC_GSEG 8
 static void grad_w(const float* d, const float* a, size_t N, int rows, int cols, float* dW, float* db) {
+    const size_t seg = ((N + 4 * ORC_GSEG - 1) / (4 * ORC_GSEG)) * 4;
     for (int r = 0; r < rows; ++r) {
         for (int k = 0; k < cols; ++k) {
-            float acc = 0.0f;
-            for (size_t n = 0; n < N; ++n) acc = fmaf(d[n * rows + r], a[n * cols + k], acc);
-            dW[(size_t)r * cols + k] = acc;
+            float part[ORC_GSEG];
+            for (int sg = 0; sg < ORC_GSEG; ++sg) {
+                float acc = 0.0f;
+                const size_t n1 = (sg + 1) * seg < N ? (sg + 1) * seg : N;
+                for (size_t n = sg * seg; n < n1; ++n) acc = fmaf(d[n * rows + r], a[n * cols + k], acc);
+                part[sg] = acc;
+            }
+            dW[(size_t)r * cols + k] = ((part[0] + part[1]) + (part[2] + part[3])) + ((part[4] + part[5]) + (part[6] + part[7]));
         }
         float s = 0.0f;
         for (size_t n = 0; n < N; ++n) s = s + d[n * rows + r];
