@@ -24,7 +24,8 @@ class Trainer:
         """defaults = train_frame.py:188-192 (batch_size 100, chunks 10 x 15 frames, learning_rate 1e-4)"""
         self.model, self.lr = model, float(lr)
         self._t = C.c_void_p()
-        _lib.check(_lib.lib().fpc_trainer_create(model._handle(), int(max_batch), int(max_frames), C.byref(self._t)),
+        self._h = model._handle()  # the trainer works on this predictor handle's device weights
+        _lib.check(_lib.lib().fpc_trainer_create(self._h, int(max_batch), int(max_frames), C.byref(self._t)),
                    "fpc_trainer_create")
 
     def __del__(self):
@@ -37,6 +38,9 @@ class Trainer:
 
     def step(self, feat):
         """one optimisation step on feat (B, L, 20) normalised frames; returns the loss of this step"""
+        if self.model._h is not self._h:
+            raise _lib.FpcError("Trainer: the model's weights were reloaded (load_state_dict) after this trainer was "
+                                "built; create a new Trainer")
         f = torch.as_tensor(feat).to("cuda", torch.float32).contiguous()
         B, L, Cc = f.shape
         assert Cc == self.model.in_features

@@ -504,4 +504,8 @@ def test_train_converges_at_reference_batch(torch_cuda, synth):
     feat = synth.predictor_features(100, 150, utt0=6000)
     tr = Trainer(m)
     losses = [tr.step(feat) for _ in range(6)]
+    from fpcodec_amd._lib import FpcError
+    m.load_state_dict(synth.predictor_state_dict())  # drops the device handle the trainer was built on
+    with pytest.raises(FpcError, match="reloaded"):
+        tr.step(feat)
     assert all(np.isfinite(losses)) and all(b < a for a, b in zip(losses, losses[1:])), losses  # lr 1e-4: ~0.3 % a step
