@@ -257,9 +257,12 @@ class LPCNet:
         self.nblocks = lib().orc_lpcnet_nblocks(self.h)
 
     def __del__(self):
-        if getattr(self, "h", None):
-            lib().orc_lpcnet_destroy(self.h)
-            self.h = None
+        try:  # (module globals may already be gone at interpreter shutdown)
+            if getattr(self, "h", None):
+                lib().orc_lpcnet_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
 
     def condition(self, feat):
         f = _f32(feat)
