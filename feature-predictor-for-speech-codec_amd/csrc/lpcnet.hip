@@ -11,11 +11,11 @@
 // Kernels
 //   k_embed_tables   one-off: embed_sig x GRU_A input kernel -> three [256][1152] tables
 //   k_frame_mfma     frame-rate layers (conv k=3 / dense) on f32 MFMA (k-ordered fmaf chains)
-//   k_decode         persistent per-utterance sample loop: one 1024-thread workgroup
-//                    (16 wave64) per utterance; sparse GRU_A / GRU_B weights live in
-//                    VGPRs for the whole utterance, recurrent state and the dual-FC
-//                    table live in LDS, HBM is touched only for the per-frame
-//                    conditioning vectors, the embedding-table rows and the PCM output.
+//   k_decode         persistent per-utterance sample loop (lpcnet_decode.h): one 768-thread workgroup
+//                    (12 wave64: 4 sampler + 8 mat-vec waves) per utterance; sparse GRU_A, GRU_B and
+//                    dual-FC weights live in VGPRs for the whole utterance, recurrent state, activation
+//                    table and the partial sums of the sparse product live in LDS, HBM is touched only
+//                    for the per-frame conditioning vectors, the embedding-table rows and the PCM output.
 #include "fpc_common.h"
 #include <algorithm>
 
