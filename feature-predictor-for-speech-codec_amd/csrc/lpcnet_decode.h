@@ -2,25 +2,25 @@
 // (included by lpcnet.hip only; gfx950).
 //
 // One 768-thread workgroup (12 wave64, 3 per SIMD, 168 VGPRs each) per utterance:
-//   waves 0-3  "sampler":  GRU_B, dual-FC, tree pdf, draw   (GRU_B weights in VGPRs)
-//   waves 4-11 "mat-vec":  embedding-row gather + GRU_A gates, and the block-sparse
-//                          recurrent product for the NEXT sample (weights in VGPRs)
+//   waves 0-3  "sampler":  GRU_B, dual FC, tree pdf, draw   (GRU_B and FC weights in VGPRs)
+//   waves 4-11 "mat-vec":  embedding-row gather + GRU_A gates (384 "gate lanes"), and the block-sparse
+//                          recurrent product for the NEXT sample (4 blocks of 8x4 weights per lane in VGPRs)
 // Four workgroup barriers per output sample (X, Y, Z1, Z2; voiced frames add Z3):
-//   X  control block (table-row offsets selected by the drawn sample) published
-//        M: gather 3 table rows, GRU_A gates -> s1'
-//        S: GRU_B recurrent part, LPC taps 2..16 (DPP tree), per-leaf candidates of this sample
+//   X  control block (table-row offsets selected by the drawn sample) and all partial sums published
+//        M: gather 3 table rows; under the gather, reduce the partial sums of the sparse product of the
+//           unit's three rows (balanced tree) + diagonal; GRU_A gates -> s1'
+//        S: GRU_B recurrent part, LPC taps 2..16 (DPP tree), per-leaf candidate records of this sample
 //   Y  s1' ready
-//        S: GRU_B -> s2'                           M: sparse product, both leaves of every lane
+//        S: GRU_B -> s2'                           M: 6 of the 16 columns of the sparse product of s1'
 //   Z1 s2' ready
-//        S: dual FC -> 255 node probabilities      M: cross-lane DPP tree
+//        S: dual FC -> 255 node probabilities      M: 4 more columns
 //   Z2 q ready
-//        S wave 0 (unvoiced frame): 4 leaf probabilities per lane, normaliser, tail cut, scan, draw,
-//        control block                             M: diagonal term, rec -> LDS
-//        (voiced frame: all 256 sampler lanes compute leaf probability + sharpening, barrier Z3,
-//         then wave 0 draws)
-// The sparse product (61 % of the algorithmic FLOPs) never sits on the sample-to-sample
-// critical path; HBM is touched only for the gathered table rows (L2-resident), the
-// per-frame conditioning rows and 2 bytes of PCM per sample.
+//        S wave 0 (unvoiced frame): 4 leaf probabilities per lane, tail cut, scan, draw, control block
+//        (voiced frame: all 256 sampler lanes compute leaf probability + sharpening, barrier Z3, then
+//         wave 0 normalises and draws)              M: last 6 columns, partial sums -> LDS
+// The sparse product (61 % of the algorithmic FLOPs) is hidden completely under the sampler phases;
+// HBM is touched only for the gathered table rows (L2-resident), the per-frame conditioning rows and
+// 2 bytes of PCM per sample.
 //
 // Canonical evaluation orders (DESIGN.md "Vocoder numerics") are those of
 // oracle/fpc_oracle.c::orc_lpcnet_synthesize; results are bit-identical.
