@@ -1,0 +1,95 @@
+"""A second opinion on the vocoder oracle (whose parity is unpinned: xiph/LPCNet is not in the reference).
+
+An independent float64 numpy restatement of the published LPCNet algorithm (frame-rate
+encoder, per-sample GRU_A / GRU_B / dual FC, tree pdf, pitch-gain sharpening, 0.002 floor, categorical draw,
+LPC synthesis), written straight from the Keras layer semantics with no regard for the oracle's evaluation
+orders, table activations or tabulated embeddings, is teacher-forced along the oracle's own trace; with the
+same uniform numbers it must draw the same mu-law level at (practically) every sample."""
+import numpy as np
+
+
+def _sig(x):
+    return 1.0 / (1.0 + np.exp(-x))
+
+
+def _lin2ulaw(x):
+    u = np.sign(x) * 128.0 * np.log(1.0 + 255.0 / 32768.0 * np.abs(x)) / np.log(256.0)
+    return int(np.clip(128 + np.round(u), 0, 255))
+
+
+def _ulaw2lin(u):
+    u = float(u) - 128.0
+    return np.sign(u) * (32768.0 / 255.0) * (np.exp(np.abs(u) / 128.0 * np.log(256.0)) - 1.0)
+
+
+def _gru(x, h, K, R, b, H):
+    gi = x @ K + b[0]
+    gh = h @ R + b[1]
+    z = _sig(gi[:H] + gh[:H])
+    r = _sig(gi[H:2 * H] + gh[H:2 * H])
+    n = np.tanh(gi[2 * H:] + r * gh[2 * H:])     # reset_after=True
+    return z * h + (1.0 - z) * n
+
+
+def _condition(w, feat):
+    T = feat.shape[0]
+    f32 = feat.astype(np.float32)
+    pitch = np.clip((np.float32(0.1) + np.float32(50.0) * f32[:, 18] + np.float32(100.0)).astype(np.int64), 0, 255)
+    x = np.concatenate([feat[:, :20].astype(np.float64), w["embed_pitch"][pitch].astype(np.float64)], 1)
+
+    def conv(x, K, b):
+        xp = np.concatenate([np.zeros((1, x.shape[1])), x, np.zeros((1, x.shape[1]))])
+        return np.tanh(sum(xp[tap:tap + T] @ K[tap].astype(np.float64) for tap in range(3)) + b)
+
+    x = conv(x, w["conv1_kernel"], w["conv1_bias"])
+    x = conv(x, w["conv2_kernel"], w["conv2_bias"])
+    x = np.tanh(x @ w["dense1_kernel"].astype(np.float64) + w["dense1_bias"])
+    return np.tanh(x @ w["dense2_kernel"].astype(np.float64) + w["dense2_bias"])
+
+
+def test_numpy_restatement_draws_what_the_oracle_draws(oracle, synth):
+    w = synth.lpcnet_weights()
+    W = {k: np.asarray(v, np.float64) for k, v in w.items()}
+    T, seed = 3, 4242
+    feat = synth.vocoder_features_raw(1, T, utt0=31)[0]
+    feat[:, 19] = [-0.2, 0.8, 0.5]                       # an unvoiced, a strongly and a mildly sharpened frame
+    feat[:, 20:] = oracle.ceps2lpc(feat[:, :20])[0]
+    orc = oracle.LPCNet(w)
+    pcm, exc_o, pcm_f = orc.synthesize(feat, seed, trace=True)
+    cf = _condition(w, feat)
+    assert np.abs(cf - orc.condition(feat)).max() < 2e-5    # frame-rate stack, float64 vs the oracle's float32 chains
+    s1, s2 = np.zeros(384), np.zeros(16)
+    hist = np.zeros(T * 160 + 16)                            # hist[16 + t] = pcm[t]
+    exc_prev, same, near, n = 128, 0, 0, 0
+    for t in range(17, T * 160):
+        fr = t // 160
+        a = feat[fr, 20:].astype(np.float64)
+        pred = -sum(a[k] * hist[16 + t - 1 - k] for k in range(16))
+        e_sig, e_pred = _lin2ulaw(hist[16 + t - 1]), _lin2ulaw(pred)
+        x = np.concatenate([W["embed_sig"][e_sig], W["embed_sig"][e_pred], W["embed_sig"][exc_prev], cf[fr]])
+        s1 = _gru(x, s1, W["gru_a_kernel"], W["gru_a_recurrent"], W["gru_a_bias"], 384)
+        s2 = _gru(np.concatenate([s1, cf[fr]]), s2, W["gru_b_kernel"], W["gru_b_recurrent"], W["gru_b_bias"], 16)
+        t2 = np.tanh(np.einsum("jic,i->jc", W["md_kernel"], s2) + W["md_bias"])
+        q = _sig((W["md_factor"] * t2).sum(1))
+        p = np.ones(256)
+        for v in range(256):
+            node = 1
+            for l in range(8):
+                bit = (v >> (7 - l)) & 1
+                p[v] *= q[node] if bit else 1.0 - q[node]
+                node = 2 * node + bit
+        p = p * p ** max(0.0, 1.5 * float(feat[fr, 19]) - 0.5)
+        p = p / (1e-18 + p.sum())
+        p = np.maximum(p - 0.002, 0.0)
+        c = np.cumsum(p / (1e-8 + p.sum()))
+        u = oracle.lib().orc_philox_uniform(seed, t)
+        mine = min(int(np.sum(c <= u * c[-1])), 255)
+        n += 1
+        same += mine == int(exc_o[t])
+        near += abs(mine - int(exc_o[t])) <= 1
+        # teacher forcing: continue from the oracle's own sample so that one flipped draw cannot snowball
+        exc_prev = int(exc_o[t])
+        hist[16 + t] = float(pcm_f[t])
+        assert abs((pred + _ulaw2lin(exc_prev)) - float(pcm_f[t])) < 1e-2 * max(1.0, abs(float(pcm_f[t])))
+    print('second opinion:', same, 'of', n, 'draws identical,', near, 'within one level')
+    assert same >= 0.99 * n and near == n, (same, near, n)
