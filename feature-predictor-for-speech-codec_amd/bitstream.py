@@ -111,3 +111,150 @@ def bits_per_frame(idx, sizes):
     b = 2.0 + np.where(ind1, lay.b_scl_hi, lay.b_scl_lo if lay.n_lo else 0) + np.where(
         ind2, lay.b_v0 + (lay.b_v1 if lay.N_hi1 else 0), lay.b_vlo if lay.N_lo else 0)
     return float(b.mean())
+
+
+# ---------------------------------------------------------------------------------------------
+# Entropy-coded framing: a static arithmetic coder (Witten-Neal-Cleary, 32-bit integer range) over
+# the same per-frame fields, driven by symbol counts -- the codebook-usage histograms `cb_tot` the
+# encoder returns (wavernn.py:189) plus the two flag rates.  With the counts of the coded material
+# itself the size lands on the entropy figure of generate_qtz_features.py:94-101,202.
+# ---------------------------------------------------------------------------------------------
+_TOP, _HALF, _QTR = (1 << 32) - 1, 1 << 31, 1 << 30
+_MAXTOT = 1 << 16
+
+
+class Model:
+    """cumulative frequency table of one field; every symbol keeps a count >= 1 so it stays codable"""
+
+    def __init__(self, counts):
+        c = np.maximum(np.asarray(counts, dtype=np.float64), 0.0)
+        n = c.size
+        if c.sum() <= 0:
+            c = np.ones(n)
+        scaled = np.maximum(1, np.floor(c / c.sum() * (_MAXTOT - n)).astype(np.int64))
+        self.cum = np.concatenate([[0], np.cumsum(scaled)]).astype(np.int64)
+        self.total = int(self.cum[-1])
+
+
+class Models:
+    """field models from the encoder's statistics: cb_tot = [scl_hi, scl_lo, vq stage 1, vq stage 2, vq_lo]
+    usage histograms (`Wavernn.encoder`), keep = (ind1 rate, ind2 rate)"""
+
+    def __init__(self, sizes, cb_tot, keep):
+        self.lay = Layout(sizes)
+        n = (self.lay.n_hi, self.lay.n_lo, self.lay.N_hi0, self.lay.N_hi1, self.lay.N_lo)
+        tabs = []
+        for i in range(5):  # an absent codebook has no symbols and no model
+            h = np.asarray(cb_tot[i], dtype=np.float64).ravel()
+            tabs.append(Model(h if h.size == n[i] else np.zeros(n[i])) if n[i] else None)
+        self.scl_hi, self.scl_lo, self.v0, self.v1, self.vlo = tabs
+        self.f1 = Model([1.0 - keep[0], keep[0]])
+        self.f2 = Model([1.0 - keep[1], keep[1]])
+
+
+def _fields(idx, lay):
+    """yield (model name, symbol) in stream order for one utterance"""
+    for s, v0, v1, vl in np.asarray(idx, dtype=np.int64):
+        ind1, ind2 = 0 <= s < lay.n_hi, v0 >= 0
+        yield "f1", int(ind1)
+        yield "f2", int(ind2)
+        if ind1:
+            yield "scl_hi", int(s)
+        elif lay.n_lo:
+            yield "scl_lo", int(s - lay.n_hi)
+        if ind2:
+            yield "v0", int(v0)
+            if lay.N_hi1:
+                yield "v1", int(v1)
+        elif lay.N_lo:
+            yield "vlo", int(vl)
+
+
+def entropy_pack(idx, models):
+    """idx (L, 4) -> (bytes, number of bits)"""
+    low, high, pend, bits = 0, _TOP, 0, []
+
+    def emit(b):
+        nonlocal pend
+        bits.append(b)
+        bits.extend([1 - b] * pend)
+        pend = 0
+
+    for name, sym in _fields(idx, models.lay):
+        m = getattr(models, name)
+        rng = high - low + 1
+        high = low + rng * int(m.cum[sym + 1]) // m.total - 1
+        low = low + rng * int(m.cum[sym]) // m.total
+        while True:
+            if high < _HALF:
+                emit(0)
+            elif low >= _HALF:
+                emit(1)
+                low -= _HALF
+                high -= _HALF
+            elif low >= _QTR and high < _HALF + _QTR:
+                pend += 1
+                low -= _QTR
+                high -= _QTR
+            else:
+                break
+            low, high = low << 1, (high << 1) | 1
+    pend += 1
+    emit(0 if low < _QTR else 1)
+    return np.packbits(np.array(bits, dtype=np.uint8)).tobytes(), len(bits)
+
+
+def entropy_unpack(data, nframes, models):
+    """inverse of entropy_pack: (L, 4) int32 in the encoder's convention"""
+    lay = models.lay
+    bits = np.unpackbits(np.frombuffer(data, dtype=np.uint8))
+    pos = 0
+
+    def nxt():
+        nonlocal pos
+        b = int(bits[pos]) if pos < bits.size else 0
+        pos += 1
+        return b
+
+    low, high, val = 0, _TOP, 0
+    for _ in range(32):
+        val = (val << 1) | nxt()
+
+    def get(name):
+        nonlocal low, high, val
+        m = getattr(models, name)
+        rng = high - low + 1
+        target = ((val - low + 1) * m.total - 1) // rng
+        sym = int(np.searchsorted(m.cum, target, side="right")) - 1
+        high = low + rng * int(m.cum[sym + 1]) // m.total - 1
+        low = low + rng * int(m.cum[sym]) // m.total
+        while True:
+            if high < _HALF:
+                pass
+            elif low >= _HALF:
+                low -= _HALF
+                high -= _HALF
+                val -= _HALF
+            elif low >= _QTR and high < _HALF + _QTR:
+                low -= _QTR
+                high -= _QTR
+                val -= _QTR
+            else:
+                break
+            low, high, val = low << 1, (high << 1) | 1, (val << 1) | nxt()
+        return sym
+
+    out = np.full((nframes, 4), -1, np.int32)
+    for i in range(nframes):
+        ind1, ind2 = get("f1"), get("f2")
+        if ind1:
+            out[i, 0] = get("scl_hi")
+        elif lay.n_lo:
+            out[i, 0] = lay.n_hi + get("scl_lo")
+        if ind2:
+            out[i, 1] = get("v0")
+            if lay.N_hi1:
+                out[i, 2] = get("v1")
+        elif lay.N_lo:
+            out[i, 3] = get("vlo")
+    return out

@@ -279,3 +279,27 @@ def test_wav_writer_normalisation(tmp_path):
     with wave.open(str(tmp_path / "t.wav"), "rb") as w:
         assert (w.getnchannels(), w.getsampwidth(), w.getframerate(), w.getnframes()) == (1, 2, 16000, 4000)
         assert np.array_equal(np.frombuffer(w.readframes(4000), dtype="<i2"), pcm)
+
+
+def test_entropy_coded_stream_meets_the_entropy_figure(oracle, synth):
+    """arithmetic-coded symbols decode exactly and cost what generate_qtz_features.py:94-101,202 predicts"""
+    from fpcodec_amd import bitstream
+    c = synth.codebooks()
+    CB = oracle.Codebooks(c["vq_hi"], c["scl_hi"], c["vq_lo"], c["scl_lo"])
+    P = oracle.Predictor(synth.predictor_state_dict())
+    feat = synth.predictor_features(4, 150, utt0=900)
+    o = P.encode(feat, CB, 0.09, 0.28, True)
+    cb_tot = CB.split_hist(o["hist"])
+    keep = (float(o["ind1"].mean()), float(o["ind2"].mean()))
+    models = bitstream.Models(CB.sizes, cb_tot, keep)
+    total_bits = 0
+    for b in range(4):
+        data, nbits = bitstream.entropy_pack(o["idx"][b], models)
+        assert np.array_equal(bitstream.entropy_unpack(data, 150, models), o["idx"][b])
+        total_bits += nbits
+    n = 4 * 150
+    ent = sum(oracle.cal_entropy(h) * h.sum() for h in cb_tot if h.sum() > 0) / n     # codebook symbols
+    ent += sum(-(p * np.log2(p) + (1 - p) * np.log2(1 - p)) for p in keep)          # the two flags, coded too
+    coded = total_bits / n
+    fixed = bitstream.bits_per_frame(o["idx"], CB.sizes)
+    assert coded < fixed and abs(coded - ent) < 0.03 * ent + 4 * 40 / n, (coded, ent, fixed)
