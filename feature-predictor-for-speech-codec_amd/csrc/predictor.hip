@@ -1139,6 +1139,8 @@ extern "C" int fpc_trainer_create(fpc_predictor* p, int max_B, int max_L, fpc_tr
     FPC_REQUIRE(max_B > 0 && max_L > 1, "fpc_trainer_create: bad shape B=%d L=%d (L >= 2: the loss compares with the next frame)",
                 max_B, max_L);
     FPC_REQUIRE(p->d.h1 % 4 == 0 && p->d.h2 % 4 == 0, "fpc_trainer_create: gru units must be multiples of 4");
+    FPC_REQUIRE((size_t)max_L * p->d.fc * sizeof(float) <= 60 * 1024,
+                "fpc_trainer_create: %d frames x %d outputs do not fit the loss kernel's LDS staging (<= 60 KB)", max_L, p->d.fc);
     fpc_trainer* t = new fpc_trainer();
     t->p = p;
     t->maxB = max_B;
