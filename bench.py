@@ -2,18 +2,25 @@
 """Benchmark of the hot path: LPCNet synthesis samples/s on synthetic 3-second utterances.
 
     python bench.py --gpus 1 --steps 3 --warmup 1
+    python bench.py --gpus 8 ...          # starts one rank per GPU itself (torch.distributed.run child)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
 A step = one pass of the vocoder (frame-rate conditioning kernels + persistent decode kernel)
 over one batch of --streams independent 3 s utterances per GPU (BASELINE config 3: 256
-utterances on one MI355X; with N GPUs every rank decodes its own 256: config 4, weak scaling,
-no collective in the data path - RCCL only gathers the timings).  Inputs (features, seeds,
-weights) are resident in HBM before the timed region.  Rank 0 prints ONE JSON line.
+utterances on one MI355X; with N GPUs the global list of N x 256 utterances is split by
+`parallel.shard_range`: config 4, weak scaling, no collective in the data path - RCCL only
+gathers the report).  Inputs (features, seeds, weights) are resident in HBM before the timed
+region.  Rank 0 prints ONE JSON line.  Outside the timed region the line also carries BASELINE
+config 5 (`e2e`: predictor + residual VQ encode -> ceps2lpc -> decode on this rank's share of
+128 x N utterances, codebook-usage histograms summed over all ranks before the entropy, as
+src/generate_qtz_features.py:184,202 sums them over utterances), the single-stream latency view
+(config 2), a second decode at 50 % voiced frames, and the CPU baselines.
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -24,8 +31,20 @@ sys.path.insert(0, ROOT)
 
 FLOP_PER_SAMPLE = 145600.0      # 2 x 72 797 MAC per output sample per stream
 HBM_BYTES_PER_SAMPLE = 2.9      # 2 B PCM out + 144 B features / 160 samples
-PEAK_F32_TFLOPS = 157.3         # MI355X_MICROARCH.md: FP32 vector == f32 MFMA dense peak
+PEAK_F32_TFLOPS = 157.3         # MI355X_MICROARCH.md: FP32 vector peak (== f32 MFMA dense peak)
 PEAK_HBM_GBS = 8000.0
+E2E_PER_GPU = 128               # BASELINE config 5: 1024 utterances on 8 GPUs
+
+
+def _host_threads():
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:  # a container's CPU share (cgroup v2 quota) rather than the host's thread count
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            cores = max(1, min(cores, int(float(quota) / float(period) + 0.5)))
+    except Exception:
+        pass
+    return min(cores, 16)  # one GPU's share of the host on the measurement boxes
 
 
 def cpu_baseline(frames=64):
@@ -41,23 +60,16 @@ def cpu_baseline(frames=64):
     f[:, 20:] = O.ceps2lpc(f[:, :20])[0]
     per = frames * 160 - 17
     n1, reps1, t0 = 0, 0, time.time()
-    while time.time() - t0 < 5.0:
+    while time.time() - t0 < 4.0:
         orc.synthesize(f, 1004 + reps1)
         n1 += per
         reps1 += 1
     single = n1 / (time.time() - t0)
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    try:  # a container's CPU share (cgroup v2 quota) rather than the host's thread count
-        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
-        if quota != "max":
-            cores = max(1, min(cores, int(float(quota) / float(period) + 0.5)))
-    except Exception:
-        pass
-    cores = min(cores, 16)  # one GPU's share of the host on the measurement boxes
+    cores = _host_threads()
 
     def worker(k):
         n, t1 = 0, time.time()
-        while time.time() - t1 < 8.0:
+        while time.time() - t1 < 6.0:
             orc.synthesize(f, 2000 + 100 * k + n)
             n += 1
         return n
@@ -66,20 +78,67 @@ def cpu_baseline(frames=64):
     with cf.ThreadPoolExecutor(cores) as ex:
         done = sum(ex.map(worker, range(cores)))
     dt = time.time() - t0
-    return {"value": done * per / dt, "unit": "samples/s", "cores": cores, "kind": "port",
-            "single_thread_value": single,
-            "sample": f"{done} x one {frames}-frame utterance ({done * per} samples) through oracle/fpc_oracle.c "
-                      f"(orc_lpcnet_synthesize), one utterance at a time on each of {cores} host threads for 8 s; "
-                      f"single_thread_value from {reps1} utterances on one thread"}
+    out = {"value": done * per / dt, "unit": "samples/s", "cores": cores, "kind": "port",
+           "single_thread_value": single,
+           "sample": f"{done} x one {frames}-frame utterance ({done * per} samples) through oracle/fpc_oracle.c "
+                     f"(orc_lpcnet_synthesize), one utterance at a time on each of {cores} host threads for 6 s; "
+                     f"single_thread_value from {reps1} utterances on one thread",
+           "note": "kind 'port': the reference's own vocoder (xiph/LPCNet, Keras) is absent from the reference tree "
+                   "and cannot be timed anywhere; the reference's Python ENCODER measured in the build container "
+                   "(8-core Xeon 2.1 GHz, BASELINE.md section 2) needs 17.0 s per 3 s utterance (0.176x real time)"}
+    out["encode"] = cpu_baseline_encode(cores)
+    return out
 
 
-def e2e_config5(voc, torch, synth, B=128, L=300):
-    """BASELINE config 5, one GPU's share: encode (GRU predictor + thresholds + scalar/2-stage VQ) ->
-    x24.1 -> ceps2lpc -> LPCNet decode for B utterances; bitrate from codebook-usage entropies
-    (src/generate_qtz_features.py:94-101,202)."""
+def cpu_baseline_encode(cores, frames=100):
+    """encode side of the hot path on the host: the oracle's closed-loop encoder (GRU predictor, thresholds,
+    scalar + 2-stage M-best VQ) and ceps2lpc, one utterance at a time per host thread"""
+    import concurrent.futures as cf
+    import fpcodec_amd
+    from oracle import oracle as O
+    synth = fpcodec_amd.synth
+    pred = O.Predictor(synth.predictor_state_dict())
+    cbs = synth.codebooks()
+    cb = O.Codebooks(cbs["vq_hi"], cbs["scl_hi"], cbs["vq_lo"], cbs["scl_lo"])
+    feat = synth.predictor_features(1, frames, utt0=7000)
+
+    def one():
+        enc = pred.encode(feat, cb, 0.09, 0.28, qtz=True)
+        O.ceps2lpc(np.ascontiguousarray(enc[0].reshape(-1, 20) * np.float32(24.1)))
+
+    t0, n1 = time.time(), 0
+    while time.time() - t0 < 3.0:
+        one()
+        n1 += 1
+    single = n1 * frames / (time.time() - t0)
+
+    def worker(k):
+        n, t1 = 0, time.time()
+        while time.time() - t1 < 5.0:
+            one()
+            n += 1
+        return n
+
+    t0 = time.time()
+    with cf.ThreadPoolExecutor(cores) as ex:
+        done = sum(ex.map(worker, range(cores)))
+    dt = time.time() - t0
+    return {"value": done * frames / dt, "unit": "frames/s", "cores": cores, "kind": "port",
+            "single_thread_value": single, "rtf": done * frames / dt / 100.0,
+            "sample": f"{done} x one {frames}-frame utterance through oracle/fpc_oracle.c (orc_encode + orc_ceps2lpc) "
+                      f"on {cores} host threads for 5 s; single_thread_value from {n1} utterances on one thread",
+            "reference_python_s_per_3s_utterance": 17.0}
+
+
+def e2e_config5(voc, torch, synth, parallel, rank, world, L=300):
+    """BASELINE config 5, this rank's share of the global utterance list: encode (GRU predictor + thresholds +
+    scalar/2-stage VQ) -> x24.1 -> ceps2lpc -> LPCNet decode; the codebook-usage histograms and the frame /
+    sample counts of all ranks are summed (parallel.gather_report) before the entropies are taken, as
+    src/generate_qtz_features.py:184,202 sums cb_tot over utterances."""
     import tempfile
+    from fpcodec_amd import bitstream
     from fpcodec_amd.synthesis_qtz import encode_features
-    from fpcodec_amd.vq_func import cal_entropy
+    from fpcodec_amd.vq_func import cal_entropy, load_codebooks
     from fpcodec_amd.wavernn import Wavernn
     d = tempfile.mkdtemp()
     paths = {}
@@ -90,19 +149,18 @@ def e2e_config5(voc, torch, synth, B=128, L=300):
                bl_cb_path=paths["vq_lo"], l1=0.09, l2=0.28, qtz=True)
     model = Wavernn(in_features=20, gru_units1=384, gru_units2=128, fc_units=18)
     model.load_state_dict(synth.predictor_state_dict())
-    nu = 8
+    total = E2E_PER_GPU * world
+    lo, hi = parallel.shard_range(total, rank, world)
+    B = hi - lo
+    nu = 8  # distinct synthetic utterances per rank, tiled (host-side generation is slow; device work is unchanged)
     nm = np.zeros((B, L, 36), np.float32)
-    nm[:, :, :20] = np.tile(synth.predictor_features(nu, L, utt0=5000), (B // nu + 1, 1, 1))[:B]
+    nm[:, :, :20] = np.tile(synth.predictor_features(nu, L, utt0=5000 + lo), (B // nu + 1, 1, 1))[:B]
     nm_d = torch.from_numpy(nm).cuda()
-    seeds = torch.from_numpy(synth.seeds(B, utt0=5000).astype(np.int64)).cuda()
+    seeds = torch.from_numpy(synth.seeds(B, utt0=5000 + lo).astype(np.int64)).cuda()
     pcm = torch.empty(B, L * 160, dtype=torch.int16, device="cuda")
 
-    def run():
-        feats, r, i1, i2, cb_tot = encode_features(model, cfg, nm_d)
-        voc.synthesize(feats, seeds, out=pcm)
-        return i1, i2, cb_tot
-
-    run()
+    feats, r, i1, i2, cb_tot = encode_features(model, cfg, nm_d)  # warm-up
+    voc.synthesize(feats, seeds, out=pcm)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     feats, r, i1, i2, cb_tot = encode_features(model, cfg, nm_d)
@@ -112,8 +170,6 @@ def e2e_config5(voc, torch, synth, B=128, L=300):
     torch.cuda.synchronize()
     t2 = time.perf_counter()
     # receiver side: the same utterances rebuilt from the symbols alone
-    from fpcodec_amd import bitstream
-    from fpcodec_amd.vq_func import load_codebooks
     enc = model.encoder(cfg, nm_d[:, :, :20], None, cfg["l1"], cfg["l2"], qtz=True, return_indices=True)
     idx = enc[7]
     torch.cuda.synchronize()
@@ -123,22 +179,46 @@ def e2e_config5(voc, torch, synth, B=128, L=300):
     t4 = time.perf_counter()
     assert torch.equal(rec, enc[0]), "decoder output differs from the encoder's reconstruction"
     sizes = load_codebooks(cfg["cb_path"], cfg["scl_cb_path"], cfg["bl_cb_path"], cfg["bl_scl_cb_path"]).sizes
-    fixed_bits = bitstream.bits_per_frame(idx.cpu().numpy(), sizes)
-    idx_h = idx.cpu().numpy()
-    models = bitstream.Models(sizes, cb_tot, (float(i1.mean()), float(i2.mean())))
-    nsub = min(B, 8)  # the arithmetic coder is plain Python: a sample of the utterances
-    coded_bits = sum(bitstream.entropy_pack(idx_h[k], models)[1] for k in range(nsub)) / (nsub * L)
-    assert all(np.array_equal(bitstream.entropy_unpack(bitstream.entropy_pack(idx_h[k], models)[0], L, models), idx_h[k])
-               for k in range(2))
-    n = B * L
-    ent = [cal_entropy(h) if np.sum(h) > 0 else 0.0 for h in cb_tot]
-    bits_frame = sum(e * float(np.sum(h)) for e, h in zip(ent, cb_tot)) / n + 2.0  # + the two threshold flags
-    return {"utterances": B, "encode_ms": (t1 - t0) * 1e3, "decode_ms": (t2 - t1) * 1e3,
-            "rtf_aggregate": B * 3.0 / (t2 - t0), "keep_rates": [float(i1.mean()), float(i2.mean())],
-            "entropy_bits_per_symbol": ent, "bits_per_frame": bits_frame, "bitrate_bps": bits_frame * 100.0,
-            "fixed_length_bits_per_frame": fixed_bits, "fixed_length_bitrate_bps": fixed_bits * 100.0,
-            "arithmetic_coded_bits_per_frame": coded_bits, "arithmetic_coded_bitrate_bps": coded_bits * 100.0,
-            "decode_features_ms": (t4 - t3) * 1e3}
+    # ---- the cross-rank record: max elapsed, total samples, summed histograms (+ flag and frame counts) ----
+    flat = np.concatenate([np.asarray(h, np.float64).ravel() for h in cb_tot] +
+                          [[float(i1.sum()), float(i2.sum()), float(B * L)]]).astype(np.int64)
+    rep = parallel.gather_report(t2 - t0, B * (L * 160 - 17), flat)
+    g = rep["hist"]
+    offs = np.cumsum([0] + [int(np.asarray(h).size) for h in cb_tot])
+    cb_glob = [g[offs[k]:offs[k + 1]].astype(np.float64) for k in range(len(cb_tot))]
+    n_frames = float(g[-1])
+    keep = [float(g[-3]) / n_frames, float(g[-2]) / n_frames]
+    ent = [cal_entropy(h.copy()) if np.sum(h) > 0 else 0.0 for h in cb_glob]
+    bits_frame = sum(e * float(np.sum(h)) for e, h in zip(ent, cb_glob)) / n_frames + 2.0  # + the two threshold flags
+    out = {"utterances": int(n_frames) // L, "utterances_this_rank": B, "ranks": world,
+           "encode_ms": (t1 - t0) * 1e3, "decode_ms": (t2 - t1) * 1e3,
+           "rtf_aggregate": rep["samples"] / rep["elapsed_s"] / 16000.0, "keep_rates": keep,
+           "entropy_bits_per_symbol": ent, "bits_per_frame": bits_frame, "bitrate_bps": bits_frame * 100.0,
+           "decode_features_ms": (t4 - t3) * 1e3}
+    if rank == 0:  # framing figures on rank 0's share (the arithmetic coder is plain Python: a sample of it)
+        idx_h = idx.cpu().numpy()
+        fixed_bits = bitstream.bits_per_frame(idx_h, sizes)
+        models = bitstream.Models(sizes, cb_glob, tuple(keep))
+        nsub = min(B, 4)
+        packed = [bitstream.entropy_pack(idx_h[k], models) for k in range(nsub)]
+        assert all(np.array_equal(bitstream.entropy_unpack(packed[k][0], L, models), idx_h[k]) for k in range(2))
+        coded_bits = sum(p[1] for p in packed) / (nsub * L)
+        out.update({"fixed_length_bits_per_frame": fixed_bits, "fixed_length_bitrate_bps": fixed_bits * 100.0,
+                    "arithmetic_coded_bits_per_frame": coded_bits, "arithmetic_coded_bitrate_bps": coded_bits * 100.0})
+    return out
+
+
+def _spawn(args):
+    """`python bench.py --gpus N` outside a launcher: start one rank per GPU as a child process group and relay
+    its output (nothing in this process has touched the GPU yet)."""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd)
 
 
 def main():
@@ -149,18 +229,24 @@ def main():
     ap.add_argument("--streams", type=int, default=256, help="utterances per GPU per step")
     ap.add_argument("--secs", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--e2e", action="store_true",
-                    help="also time BASELINE config 5 per GPU (predictor + residual VQ encode -> ceps2lpc -> decode, "
-                         "128 utterances) and report bitrate; extra key 'e2e', outside the timed region")
+    ap.add_argument("--no-e2e", action="store_true", help="skip BASELINE config 5 (extra key 'e2e', outside the timed region)")
+    ap.add_argument("--e2e", action="store_true", help="(default; kept for older command lines)")
+    ap.add_argument("--dump-pcm", default=None, help="directory: every rank saves its PCM block and shard range (tests)")
     args = ap.parse_args()
+
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(_spawn(args))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with "
+                 f"`python bench.py --gpus N` or torch.distributed.run --nproc-per-node N ... --gpus N")
 
     import torch
     import fpcodec_amd
-    from fpcodec_amd import _lib
+    from fpcodec_amd import _lib, parallel
     from fpcodec_amd.ceps2lpc import ceps2lpc_v
     from fpcodec_amd.lpcnet import LPCNet
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     ndev = max(1, torch.cuda.device_count())
@@ -177,15 +263,19 @@ def main():
             dist.init_process_group(backend)
 
     synth = fpcodec_amd.synth
-    B, T = args.streams, args.secs * 100
-    # synthetic features: distinct utterances per rank; a few distinct ones tiled to B keep
-    # host-side generation short without changing the device work (every stream has its own seed)
+    T = args.secs * 100
+    # the global utterance list (streams x world) is split in contiguous blocks, one per rank
+    lo, hi = parallel.shard_range(args.streams * world, rank, world)
+    B = hi - lo
+    # synthetic features: a few distinct utterances tiled to B keep host-side generation short without
+    # changing the device work (every stream has its own seed = its global utterance number)
     nuniq = min(B, 16)
-    base = synth.vocoder_features_raw(nuniq, T, utt0=rank * 100000)
-    feats = torch.from_numpy(np.tile(base, ((B + nuniq - 1) // nuniq, 1, 1))[:B].copy()).cuda()
+    base = synth.vocoder_features_raw(nuniq, T, utt0=0)
+    feats = torch.from_numpy(np.stack([base[(lo + k) % nuniq] for k in range(B)])).cuda()
     lpc = ceps2lpc_v(feats.reshape(-1, 36)[:, :20].contiguous())[1]
     feats[:, :, 20:] = lpc.reshape(B, T, 16)
-    seeds = torch.from_numpy(synth.seeds(B, utt0=rank * 100000).astype(np.int64)).cuda()
+    seeds = torch.from_numpy(synth.seeds(B, utt0=lo).astype(np.int64)).cuda()
+    voiced_fraction = float((1.5 * feats[:, :, 19] - 0.5 > 0).float().mean().item())
     voc = LPCNet(synth.lpcnet_weights())
     pcm = torch.empty(B, T * 160, dtype=torch.int16, device="cuda")
 
@@ -207,45 +297,56 @@ def main():
     if dist:
         dist.barrier()
     torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    if dist:
-        tt = torch.tensor([dt], device="cuda" if dist.get_backend() == "nccl" else "cpu", dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
-
+    dt_local = time.perf_counter() - t0
     samples_step = B * (T * 160 - 17)
-    total = samples_step * args.steps * world
+    rep = parallel.gather_report(dt_local, samples_step * args.steps)  # MAX elapsed, SUM samples over ranks
+    dt, total = rep["elapsed_s"], rep["samples"]
     value = total / dt
     dec_s = float(np.mean(dec_ms)) / 1e3
     dec_rate = samples_step / dec_s  # per GPU, decode kernel only
 
+    if args.dump_pcm:
+        os.makedirs(args.dump_pcm, exist_ok=True)
+        np.savez(os.path.join(args.dump_pcm, f"rank{rank}.npz"), pcm=pcm.cpu().numpy(), lo=lo, hi=hi)
+
     traffic = None  # HBM bytes per k_decode launch from the committed PMC passes (same workload only)
-    try:
-        tj = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
-        if B == 256 and T == 300:
-            traffic = tj["hbm_bytes_per_launch"]
-    except Exception:
-        pass
+    traffic_src = None
+    for name in ("r02_traffic.json", "r01_traffic.json"):
+        try:
+            tj = json.load(open(os.path.join(ROOT, "profiles", name)))
+            if B == 256 and T == 300:
+                traffic, traffic_src = tj["hbm_bytes_per_launch"], name
+            break
+        except Exception:
+            continue
     out = {
         "metric": "LPCNet synthesis samples/sec (16 kHz RTF) per GPU; 1/2/4/8-GPU throughput",
         "value": value, "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": f"BASELINE config 3/4: {B} independent {args.secs} s utterances per GPU "
+        "config": {"workload": f"BASELINE config 3/4: {args.streams} independent {args.secs} s utterances per GPU "
                                f"(T={T} frames, {T * 160} samples each), GRU_A=384 block-sparse, fixed Philox RNG",
-                   "streams_per_gpu": B, "frames": T},
+                   "streams_per_gpu": args.streams, "frames": T, "voiced_fraction": voiced_fraction,
+                   "voiced_note": "fraction of frames with pdf sharpening (1.5*pitch_corr-0.5 > 0); SURVEY 8(d) "
+                                  "specifies pitch-corr U(-.4,.4); voiced frames cost more: see voiced_50"},
         "rtf_aggregate": value / 16000.0,
         "rtf_per_stream": dec_rate / B / 16000.0,
         "roofline": {
-            "bound": "mfma", "note": "f32 VALU sparse mat-vec; f32 vector peak == f32 MFMA dense peak (157.3 TF)",
+            "bound": "valu_f32",
+            "note": "per-stream latency-bound recurrence; ceiling = FP32 vector rate (157.3 TF = f32 MFMA dense peak); "
+                    "not HBM, not MFMA (SURVEY 8d)",
             "kernel": "k_decode", "achieved": dec_rate * FLOP_PER_SAMPLE / 1e12, "peak": PEAK_F32_TFLOPS,
             "unit": "TFLOP/s", "frac": dec_rate * FLOP_PER_SAMPLE / 1e12 / PEAK_F32_TFLOPS,
-            "traffic": traffic, "traffic_unit": "bytes/launch (rocprofv3 PMC FETCH_SIZE+WRITE_SIZE, profiles/r01_traffic.json)",
-            "launch_ms": dec_s * 1e3,
+            "traffic": traffic,
+            "traffic_unit": f"bytes/launch (rocprofv3 PMC FETCH_SIZE+WRITE_SIZE, profiles/{traffic_src})",
+            "launch_ms": dec_s * 1e3, "cycles_per_sample_at_2p4GHz": dec_s * 2.4e9 / (T * 160 - 17),
             "hbm": {"achieved": dec_rate * HBM_BYTES_PER_SAMPLE / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                     "frac": dec_rate * HBM_BYTES_PER_SAMPLE / 1e9 / PEAK_HBM_GBS},
         },
     }
+    e2e = None
+    if not args.no_e2e:
+        e2e = e2e_config5(voc, torch, synth, parallel, rank, world)  # every rank: holds the report's collectives
     if rank == 0:
         # single-stream latency view (BASELINE config 2), outside the timed region
         one = torch.empty(1, T * 160, dtype=torch.int16, device="cuda")
@@ -255,8 +356,18 @@ def main():
         ms1 = voc.last_decode_ms()
         out["single_stream"] = {"decode_ms": ms1, "samples_per_s": (T * 160 - 17) / (ms1 / 1e3),
                                 "rtf": (T * 160 - 17) / (ms1 / 1e3) / 16000.0}
-        if args.e2e:
-            out["e2e"] = e2e_config5(voc, torch, synth)
+        # the same batch with every second frame voiced (pdf sharpening + fifth barrier)
+        fv = feats.clone()
+        fv[:, 0::2, 19] = 0.9
+        voc.synthesize(fv, seeds, out=pcm)
+        torch.cuda.synchronize()
+        voc.synthesize(fv, seeds, out=pcm)
+        msv = voc.last_decode_ms()
+        out["voiced_50"] = {"voiced_fraction": float((1.5 * fv[:, :, 19] - 0.5 > 0).float().mean().item()),
+                            "decode_ms": msv, "samples_per_s": samples_step / (msv / 1e3),
+                            "rtf_per_stream": samples_step / (msv / 1e3) / B / 16000.0}
+        if e2e is not None:
+            out["e2e"] = e2e
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)

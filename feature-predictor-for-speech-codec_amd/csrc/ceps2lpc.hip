@@ -117,7 +117,9 @@ struct Tables {
     fpc::DevBuf dct, cosT;
     bool ready = false;
 };
-Tables g_tab[16];
+// heap-allocated and never freed: a static DevBuf's destructor would call hipFree during static destruction,
+// after the HIP runtime may already be gone; a few KB per device live until the process ends
+Tables* g_tab = nullptr;
 std::mutex g_mu;
 
 }  // namespace
@@ -136,6 +138,7 @@ extern "C" int fpc_ceps2lpc(const float* ceps_dev, int N, int stride, float* lpc
     FPC_REQUIRE(dev < 16, "fpc_ceps2lpc: device index %d unsupported", dev);
     {
         std::lock_guard<std::mutex> lk(g_mu);
+        if (!g_tab) g_tab = new Tables[16];
         Tables& t = g_tab[dev];
         if (!t.ready) {  // same table formulas as the oracle (ceps2lpc_vct.py:27-32)
             std::vector<float> dct(NB * NB);

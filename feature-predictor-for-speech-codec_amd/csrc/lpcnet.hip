@@ -18,6 +18,7 @@
 //                    for the per-frame conditioning vectors, the embedding-table rows and the PCM output.
 #include "fpc_common.h"
 #include <algorithm>
+#include <memory>
 
 namespace {
 
@@ -145,6 +146,8 @@ extern "C" long long fpc_lpcnet_workspace_bytes(const fpc_lpcnet* m, int B, int 
     return (long long)B * T * (long long)ws_floats_per_frame() * 4 + 256;
 }
 
+extern "C" void fpc_lpcnet_destroy(fpc_lpcnet* m);
+
 extern "C" int fpc_lpcnet_create(const fpc_lpcnet_weights* w, fpc_lpcnet** out) {
     FPC_REQUIRE(w && out, "fpc_lpcnet_create: null argument");
     if (!fpc::have_device()) {
@@ -154,7 +157,12 @@ extern "C" int fpc_lpcnet_create(const fpc_lpcnet_weights* w, fpc_lpcnet** out) 
     const float* const* ptrs = reinterpret_cast<const float* const*>(w);
     for (size_t i = 0; i < sizeof(*w) / sizeof(float*); ++i)
         FPC_REQUIRE(ptrs[i], "fpc_lpcnet_create: weight pointer %zu is null", i);
-    fpc_lpcnet* m = new fpc_lpcnet();
+    // owned until the last step succeeds: every early return below frees the buffers and events
+    struct Del {
+        void operator()(fpc_lpcnet* x) const { fpc_lpcnet_destroy(x); }
+    };
+    std::unique_ptr<fpc_lpcnet, Del> own(new fpc_lpcnet());
+    fpc_lpcnet* m = own.get();
     FPC_HIP(hipGetDevice(&m->device));
 
     auto up = [&](fpc::DevBuf& d, const float* src, size_t n) -> hipError_t {
@@ -242,7 +250,6 @@ extern "C" int fpc_lpcnet_create(const fpc_lpcnet_weights* w, fpc_lpcnet** out) 
                 "fpc_lpcnet_create: recurrent matrix too dense for the register-resident layout "
                 "(%d blocks of 8x4, row group %d needs %d lanes; capacity %d blocks, 64 per row group)",
                 m->nblocks, g, Q, 4 * NMAT);
-            delete m;
             return FPC_ERR_CAPACITY;
         }
         const int gate = g / (RNN_A / 8), rb = g % (RNN_A / 8);
@@ -309,7 +316,7 @@ extern "C" int fpc_lpcnet_create(const fpc_lpcnet_weights* w, fpc_lpcnet** out) 
     FPC_HIP(hipDeviceSynchronize());
     FPC_HIP(hipEventCreate(&m->ev0));
     FPC_HIP(hipEventCreate(&m->ev1));
-    *out = m;
+    *out = own.release();
     return FPC_OK;
 }
 

@@ -82,7 +82,7 @@ struct __attribute__((aligned(16))) DecodeLds {
     // control block written by the winning lane / the LPC chain lane
     unsigned o_sig, o_pred, o_exc;  // float offsets of the three table rows to gather next
     float pred;                     // prediction of the next sample
-    float q[256];
+    float4 qq[128];  // node n's branch factors as the pair (1 - q[n], q[n]) at floats 2n, 2n+1 (16-byte aligned rows)
     float p[256];
     float4 cand[256];  // per leaf, if it wins the draw: (pcm, next prediction, bits of o_sig, bits of o_pred)
     float ulaw_thr[64];  // fpc_lin2ulaw_tab table
@@ -389,6 +389,7 @@ __global__ __launch_bounds__(NTHREADS) void k_decode(const DecodeParams P) {
         fcw[16] = mk2(P.lane_fc[32 * NSAMP + sl], P.lane_fc[33 * NSAMP + sl]);
         fcw[17] = mk2(P.lane_fc[34 * NSAMP + sl], P.lane_fc[35 * NSAMP + sl]);
         float mem = 0.0f;     // de-emphasis state (tracked by every lane of the drawing wave)
+        float pcm_new = 0.0f; // the sample just drawn (drawing wave)
         float s2_own = 0.0f;  // state of unit u, replicated over the 16 lanes of its row
 
         for (int fr = 0; fr < T; ++fr) {
@@ -478,45 +479,43 @@ __global__ __launch_bounds__(NTHREADS) void k_decode(const DecodeParams P) {
                     a01 = a01 + b01;
                     const float t0 = lut_tanh(L.tt, a01.x), t1 = lut_tanh(L.tt, a01.y);
                     const float v = fmaf(fcw[17].y, t1, fcw[17].x * t0);
-                    L.q[slv] = lut_sigmoid(L.tt, v);
+                    const float qv = lut_sigmoid(L.tt, v);
+                    // both branch factors of the node: a leaf reads the one its bit selects, no select on the draw's chain
+                    reinterpret_cast<float2*>(L.qq)[slv] = make_float2(1.0f - qv, qv);
                 }
+                const float uf = L.uframe[i];  // this sample's uniform: fetched under the FC phase, not behind the scan
                 FPC_BARRIER(2)  // Z2
                 float4 p4;  // wave 0: probabilities of leaves 4*lane .. 4*lane+3
+                // branch factor j (root = 0) of a leaf is float 2*(2^j + (leaf >> (8-j))) + bit_(7-j)(leaf)
+                //                                            = 2*2^j + (leaf >> (7-j)) of qq
+                const float* qf = reinterpret_cast<const float*>(L.qq);
                 if (shape_e > 0.0f) {
                     // ---- voiced frame, Z2..Z3: leaf probability + sharpening, 256 lanes ----
                     {
                         const unsigned slv = opaque((unsigned)sl);  // (recomputed per sample: no registers to spare)
                         float f[8];
 #pragma unroll
-                        for (int j = 0; j < 8; ++j) {
-                            const float qq = L.q[(1u << j) + (slv >> (8 - j))];
-                            f[j] = ((slv >> (7 - j)) & 1u) ? qq : 1.0f - qq;
-                        }
+                        for (int j = 0; j < 8; ++j) f[j] = qf[(2u << j) + (slv >> (7 - j))];
                         const float p = ((((f[0] * f[1]) * (f[2] * f[3])) * (f[4] * f[5])) * f[6]) * f[7];
                         L.p[slv] = fpc_shape_pow(p, shape_e);
                     }
                     FPC_BARRIER(3)  // Z3
                     if (wave == 0) p4 = *reinterpret_cast<const float4*>(&L.p[4 * lane]);
                 } else if (wave == 0) {
-                    // ---- unvoiced frame: the drawing wave builds its 4 leaves per lane straight from
-                    //      q (same product order per leaf); no separate leaf phase, no barrier ----
-                    // (node addresses and branch predicates are lane constants: left to the compiler to keep in
-                    //  registers / lane masks, so that the LDS reads issue right behind the barrier)
-                    const unsigned lv = (unsigned)lane;
+                    // ---- unvoiced frame: the drawing wave builds its 4 leaves per lane straight from the
+                    //      factor pairs (same product order per leaf); no separate leaf phase, no barrier ----
+                    const unsigned lv = (unsigned)lane;  // leaves 4*lv .. 4*lv+3: factors 0..5 shared
                     float f[6];
 #pragma unroll
-                    for (int j = 0; j < 6; ++j) {
-                        const float qq = L.q[(1u << j) + (lv >> (6 - j))];
-                        f[j] = ((lv >> (5 - j)) & 1u) ? qq : 1.0f - qq;
-                    }
+                    for (int j = 0; j < 6; ++j) f[j] = qf[(2u << j) + (lv >> (5 - j))];
+                    const float2 q6 = *reinterpret_cast<const float2*>(&qf[128u + 2u * lv]);   // node 64 + lv
+                    const float4 q7 = *reinterpret_cast<const float4*>(&qf[256u + 4u * lv]);   // nodes 128 + 2 lv, + 1
                     const float pre = ((f[0] * f[1]) * (f[2] * f[3])) * (f[4] * f[5]);
-                    const float q6 = L.q[64u + lv];
-                    const float2 q7 = *reinterpret_cast<const float2*>(&L.q[128u + 2u * lv]);
-                    const float lo = pre * (1.0f - q6), hi = pre * q6;
-                    p4.x = lo * (1.0f - q7.x);
-                    p4.y = lo * q7.x;
-                    p4.z = hi * (1.0f - q7.y);
-                    p4.w = hi * q7.y;
+                    const float lo = pre * q6.x, hi = pre * q6.y;
+                    p4.x = lo * q7.x;
+                    p4.y = lo * q7.y;
+                    p4.z = hi * q7.z;
+                    p4.w = hi * q7.w;
                 }
                 // ---- (wave 0): normaliser, tail cut, scan, draw, publish ----
                 if (wave == 0) {
@@ -532,38 +531,42 @@ __global__ __launch_bounds__(NTHREADS) void k_decode(const DecodeParams P) {
                     c1 = c1 > 0.0f ? c1 : 0.0f;
                     c2 = c2 > 0.0f ? c2 : 0.0f;
                     c3 = c3 > 0.0f ? c3 : 0.0f;
-                    c1 = c0 + c1;  // sequential prefix inside the lane's 4 leaves
-                    c2 = c1 + c2;
-                    c3 = c2 + c3;
-                    float I = c3;  // Kogge-Stone inside each row of 16 lanes
+                    // prefixes inside the lane's 4 leaves, two levels deep: c0 | c0+c1 | (c0+c1)+c2 | (c0+c1)+(c2+c3)
+                    const float P1 = c0 + c1, s23 = c2 + c3;
+                    const float P2 = P1 + c2, P3 = P1 + s23;
+                    float I = P3;  // Kogge-Stone inside each row of 16 lanes
                     I = I + dpp_f<DPP_ROW_SHR + 1>(I);
                     I = I + dpp_f<DPP_ROW_SHR + 2>(I);
                     I = I + dpp_f<DPP_ROW_SHR + 4>(I);
                     I = I + dpp_f<DPP_ROW_SHR + 8>(I);
                     I = add_bcast<DPP_BCAST15, 0xa>(I);  // block offsets by row broadcasts
                     I = add_bcast<DPP_BCAST31, 0xc>(I);
-                    const float S2 = lane_val(I, 63);
-                    const float rthr = L.uframe[i] * S2;
-                    // winning lane = number of the first 63 lanes whose inclusive prefix is <= the draw (v_cmp -> s_bcnt1)
-                    const int lw = __popcll(__builtin_amdgcn_fcmpf(I, rthr, 5 /* FCMP_OLE */) & 0x7fffffffffffffffull);
-                    const float Iprev = dpp_f<DPP_WAVE_SHR1>(I);
-                    const float O = lane > 0 ? Iprev : 0.0f;
-                    int cnt = ((O + c0) <= rthr) + ((O + c1) <= rthr) + ((O + c2) <= rthr) + ((O + c3) <= rthr);
-                    cnt = cnt > 3 ? 3 : cnt;
-                    // the winning lane's result, made wave-uniform
-                    const int exc = __builtin_amdgcn_readlane(4 * lane + cnt, lw);
+                    const float rthr = uf * lane_val(I, 63);
+                    // the draw = number of leaves whose inclusive prefix is <= the threshold: four compares to lane
+                    // masks, four s_bcnt1 (the last leaf of a lane carries the scan value I itself)
+                    const float O = dpp_f<DPP_WAVE_SHR1>(I);  // exclusive offset of the lane (lane 0: +0)
+                    const unsigned long long m0 = __builtin_amdgcn_fcmpf(O + c0, rthr, 5 /* FCMP_OLE */);
+                    const unsigned long long m1 = __builtin_amdgcn_fcmpf(O + P1, rthr, 5);
+                    const unsigned long long m2 = __builtin_amdgcn_fcmpf(O + P2, rthr, 5);
+                    const unsigned long long m3 = __builtin_amdgcn_fcmpf(I, rthr, 5);
+                    int exc = (__popcll(m0) + __popcll(m1)) + (__popcll(m2) + __popcll(m3));
+                    exc = exc > 255 ? 255 : exc;
                     float4 cd = L.cand[exc];  // one broadcast read: what the control block becomes
                     asm volatile("" : "+v"(cd.x), "+v"(cd.y), "+v"(cd.z), "+v"(cd.w));  // (keeps it one ds_read_b128 up here)
-                    mem = fmaf(FPC_PREEMPH, mem, cd.x);
-                    if (lane == lw) {
-                        // control block {o_sig, o_pred, o_exc, pred}: one 16-byte store
+                    if (lane == 0) {
+                        // control block {o_sig, o_pred, o_exc, pred}: one 16-byte store, first thing after the read
                         *reinterpret_cast<float4*>(&L.o_sig) =
                             make_float4(cd.z, cd.w, __uint_as_float((512u + (unsigned)exc) * (unsigned)GA), cd.y);
                         L.hist[t & 15] = cd.x;
-                        out[t] = fpc_pcm16(mem);
                     }
+                    pcm_new = cd.x;
                 }
                 FPC_BARRIER(4)  // X
+                // behind the barrier, off the sample-to-sample chain: de-emphasis and the PCM store
+                if (wave == 0) {
+                    mem = fmaf(FPC_PREEMPH, mem, pcm_new);
+                    if (lane == 0) out[t] = fpc_pcm16(mem);
+                }
             }
         }
         if (STAMP && blockIdx.x == 0 && lane == 0)

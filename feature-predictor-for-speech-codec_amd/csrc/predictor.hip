@@ -16,6 +16,7 @@
 // distances in float64 with numpy's pairwise association, so results match the CPU
 // oracle bit for bit and the reference's indices exactly.
 #include "fpc_common.h"
+#include <memory>
 #include <cmath>
 
 namespace {
@@ -958,7 +959,12 @@ __global__ void k_adam(float* __restrict__ p, float* __restrict__ m, float* __re
 struct fpc_predictor {
     PredDev d;
     fpc::DevBuf buf[10];
+    fpc::DevBuf flag;  // one int: "a symbol lay outside its codebook" (fpc_decode_features), allocated once per handle
+    int refs = 1;  // the creator's handle + one per live fpc_trainer built on it (fpc_predictor_destroy only drops a reference)
 };
+static void predictor_unref(fpc_predictor* p) {
+    if (p && --p->refs <= 0) delete p;
+}
 
 struct fpc_codebooks {
     CbDev d;
@@ -989,7 +995,8 @@ extern "C" int fpc_predictor_create(const fpc_predictor_weights* w, fpc_predicto
                     w->rnn2_weight_ih && w->rnn2_weight_hh && w->rnn2_bias_ih && w->rnn2_bias_hh &&
                     w->fc_weight && w->fc_bias,
                 "fpc_predictor_create: null weight pointer");
-    fpc_predictor* p = new fpc_predictor();
+    std::unique_ptr<fpc_predictor> own(new fpc_predictor());  // freed on every early return below
+    fpc_predictor* p = own.get();
     const int in = w->in_features, h1 = w->gru_units1, h2 = w->gru_units2, fc = w->fc_units;
     p->d.in = in;
     p->d.h1 = h1;
@@ -1011,11 +1018,12 @@ extern "C" int fpc_predictor_create(const fpc_predictor_weights* w, fpc_predicto
     FPC_HIP(upv(p->buf[7], vec(w->rnn2_bias_hh, 3 * h2), &p->d.b2h));
     FPC_HIP(upv(p->buf[8], transpose_f(w->fc_weight, fc, h2), &p->d.fcw));
     FPC_HIP(upv(p->buf[9], vec(w->fc_bias, fc), &p->d.fcb));
-    *out = p;
+    FPC_HIP(p->flag.alloc(sizeof(int)));
+    *out = own.release();
     return FPC_OK;
 }
 
-extern "C" void fpc_predictor_destroy(fpc_predictor* p) { delete p; }
+extern "C" void fpc_predictor_destroy(fpc_predictor* p) { predictor_unref(p); }
 
 extern "C" int fpc_predictor_forward(fpc_predictor* p, const float* x_dev, int B, int L,
                                      float* h1_dev, float* h2_dev, float* y_dev, fpc_stream s) {
@@ -1110,14 +1118,14 @@ extern "C" int fpc_decode_features(fpc_predictor* p, const fpc_codebooks* cb, co
     FPC_REQUIRE(p->d.fc == NDIM + 1, "fpc_decode_features: fc_units must be 18 (c0 + 17-dim VQ), got %d", p->d.fc);
     if (L == 0) return FPC_OK;
     hipStream_t st = static_cast<hipStream_t>(s);
-    fpc::DevBuf bad;
-    FPC_HIP(bad.alloc(sizeof(int)));
-    FPC_HIP(hipMemsetAsync(bad.p, 0, sizeof(int), st));
+    // the flag lives in the handle (no per-call hipMalloc/hipFree: hipFree synchronises the whole device); the
+    // check itself needs this stream's result, so the call still ends with a sync of this one stream
+    FPC_HIP(hipMemsetAsync(p->flag.p, 0, sizeof(int), st));
     hipLaunchKernelGGL(k_decode_feat, dim3(B), dim3(NT), 0, st, p->d, cb->d, pitch_dev, idx_dev, L, c_out_dev,
-                       bad.as<int>());
+                       p->flag.as<int>());
     FPC_HIP(hipGetLastError());
     int h = 0;
-    FPC_HIP(hipMemcpyAsync(&h, bad.p, sizeof(int), hipMemcpyDeviceToHost, st));
+    FPC_HIP(hipMemcpyAsync(&h, p->flag.p, sizeof(int), hipMemcpyDeviceToHost, st));
     FPC_HIP(hipStreamSynchronize(st));
     FPC_REQUIRE(h == 0, "fpc_decode_features: a symbol lies outside its codebook (corrupt stream or wrong codebooks)");
     return FPC_OK;
@@ -1141,7 +1149,8 @@ extern "C" int fpc_trainer_create(fpc_predictor* p, int max_B, int max_L, fpc_tr
     FPC_REQUIRE(p->d.h1 % 4 == 0 && p->d.h2 % 4 == 0, "fpc_trainer_create: gru units must be multiples of 4");
     FPC_REQUIRE((size_t)max_L * p->d.fc * sizeof(float) <= 60 * 1024,
                 "fpc_trainer_create: %d frames x %d outputs do not fit the loss kernel's LDS staging (<= 60 KB)", max_L, p->d.fc);
-    fpc_trainer* t = new fpc_trainer();
+    std::unique_ptr<fpc_trainer> own(new fpc_trainer());  // freed on every early return below
+    fpc_trainer* t = own.get();
     t->p = p;
     t->maxB = max_B;
     t->maxL = max_L;
@@ -1181,11 +1190,16 @@ extern "C" int fpc_trainer_create(fpc_predictor* p, int max_B, int max_L, fpc_tr
     T.th = take(N * F), T.dpre = take(N * F);
     T.dgi1 = take(N * 3 * H1), T.dgh1 = take(N * 3 * H1), T.dgi2 = take(N * 3 * H2), T.dgh2 = take(N * 3 * H2);
     T.lossb = t->lossb.as<double>();
-    *out = t;
+    ++p->refs;  // the trainer keeps its predictor alive: fpc_predictor_destroy before fpc_trainer_destroy is safe
+    *out = own.release();
     return FPC_OK;
 }
 
-extern "C" void fpc_trainer_destroy(fpc_trainer* t) { delete t; }
+extern "C" void fpc_trainer_destroy(fpc_trainer* t) {
+    if (!t) return;
+    predictor_unref(t->p);
+    delete t;
+}
 
 extern "C" int fpc_trainer_step(fpc_trainer* t, const float* feat_dev, int B, int L, double lr, float* loss_host,
                                 fpc_stream s) {

@@ -12,6 +12,7 @@ searched on the device with the same arithmetic.  Dead/broken reference methods
 (mask_enc, decoder, loop_attention: SURVEY.md App. C) are not reproduced.
 """
 import ctypes as C
+import weakref
 from collections import OrderedDict
 
 import numpy as np
@@ -25,6 +26,14 @@ _KEYS = ["rnn1.weight_ih_l0", "rnn1.weight_hh_l0", "rnn1.bias_ih_l0", "rnn1.bias
          "dual_fc.0.weight", "dual_fc.0.bias"]
 
 
+class _ParameterList(list):
+    """what `Wavernn.parameters()` returns: a list of tensors that remembers its model"""
+
+    def __init__(self, model, tensors):
+        super().__init__(tensors)
+        self.model = model
+
+
 class Wavernn:
     def __init__(self, in_features=20, gru_units1=384, gru_units2=16, fc_units=20, attn_units=20,
                  rnn_layers=2, bidirectional=False, packing=False):
@@ -35,6 +44,9 @@ class Wavernn:
         self.scale = 1
         self._sd = None
         self._h = None
+        self._trainer = None   # weakref to the live train_frame.Trainer built on this model's handle, if any
+        self._dirty = False    # the trainer has stepped since state_dict() last matched the device weights
+        self.training = False
         self.device = torch.device("cuda")
 
     # ---- torch.nn.Module-like surface used by synthesis_qtz.py:79-87 ----
@@ -44,11 +56,19 @@ class Wavernn:
                                        (3 * h2, h2), (3 * h2,), (3 * h2,), (f, h2), (f,)]))
 
     def load_state_dict(self, sd, strict=True):
+        """`strict=False` (the transfer load of train_frame.py:244-248) ignores unexpected keys and keeps the
+        current value of a missing one; a model that was never loaded has no current values, so there every key
+        is required."""
         shp = self.shapes()
         missing = [k for k in _KEYS if k not in sd]
         extra = [k for k in sd if k not in shp]
-        if missing or (strict and extra):
+        if (missing and (strict or self._sd is None)) or (strict and extra):
             raise KeyError(f"state_dict mismatch: missing {missing}, unexpected {extra}")
+        if missing:
+            cur = self.state_dict()
+            sd = dict(sd)
+            for k in missing:
+                sd[k] = cur[k]
         arrs = []
         for k in _KEYS:
             v = sd[k]
@@ -61,18 +81,45 @@ class Wavernn:
         return self
 
     def state_dict(self):
+        """host copies in the reference's checkpoint format (utils.py:127-146).  After training steps the device
+        holds newer weights than the host copy: they are pulled first, so a checkpoint never saves stale weights."""
+        if self._sd is None:
+            raise _lib.FpcError("Wavernn: no weights yet (load_state_dict first)")
+        if self._dirty:
+            t = self._trainer() if self._trainer is not None else None
+            if t is None:
+                raise _lib.FpcError("Wavernn.state_dict: the trainer that updated the device weights is gone and "
+                                    "was never synced (call Trainer.sync() before dropping it)")
+            t.sync()
         return OrderedDict((k, torch.from_numpy(v.copy())) for k, v in self._sd.items())
+
+    def parameters(self):
+        """the ten tensors of train_frame.py:250's `optim.Adam(model.parameters(), ...)`: host copies that carry a
+        reference to this model, which `train_frame.Adam` uses to find the device weights"""
+        return _ParameterList(self, [v for _, v in self.named_parameters()])
+
+    def named_parameters(self):
+        return list(self.state_dict().items())
 
     def to(self, device):
         return self
 
-    def eval(self):
+    def cuda(self, device=None):
         return self
+
+    def train(self, mode=True):
+        self.training = bool(mode)
+        return self
+
+    def eval(self):
+        return self.train(False)
 
     def _release(self):
         if self._h is not None:
-            _lib.lib().fpc_predictor_destroy(self._h)
+            _lib.lib().fpc_predictor_destroy(self._h)  # drops one reference; a live trainer keeps its own
             self._h = None
+        self._trainer = None
+        self._dirty = False
 
     def __del__(self):
         try:

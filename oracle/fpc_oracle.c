@@ -914,18 +914,18 @@ EXPORT void orc_lpcnet_synthesize(const orc_lpcnet* m, const float* feat, int T,
                 const float d = p[v] - thr;
                 p[v] = d > 0.0f ? d : 0.0f;
             }
-            /* three-level inclusive scan: sequential prefix inside each aligned group of 4
-             * leaves; Kogge-Stone over the 16 group totals of each aligned block of 64 leaves;
-             * block offsets as below */
+            /* three-level inclusive scan.  Inside each aligned group of 4 leaves the prefixes are two levels
+             * deep: c0 | c0+c1 | (c0+c1)+c2 | (c0+c1)+(c2+c3); Kogge-Stone over the 16 group totals of each
+             * aligned block of 64 leaves; block offsets as below */
             float I64[64];
             for (int g4 = 0; g4 < 64; ++g4) {
-                float run = p[4 * g4];
-                c[4 * g4] = run;
-                for (int j = 1; j < 4; ++j) {
-                    run = run + p[4 * g4 + j];
-                    c[4 * g4 + j] = run;
-                }
-                I64[g4] = run;
+                const float* pg = p + 4 * g4;
+                const float P1 = pg[0] + pg[1], s23 = pg[2] + pg[3];
+                c[4 * g4] = pg[0];
+                c[4 * g4 + 1] = P1;
+                c[4 * g4 + 2] = P1 + pg[2];
+                c[4 * g4 + 3] = P1 + s23;
+                I64[g4] = c[4 * g4 + 3];
             }
             float R4[4], O4[3];
             for (int row = 0; row < 4; ++row) {
@@ -949,15 +949,17 @@ EXPORT void orc_lpcnet_synthesize(const orc_lpcnet* m, const float* feat, int T,
             }
             const float S2 = I64[63];
             const float rthr = fpc_philox_uniform(seed, (uint32_t)t) * S2;
-            int wsel = 0; /* group that holds the draw */
-            for (int g4 = 0; g4 < 63; ++g4)
-                if (I64[g4] <= rthr) ++wsel;
-            const float O = wsel > 0 ? I64[wsel - 1] : 0.0f;
-            int cnt = 0;
-            for (int j = 0; j < 4; ++j)
-                if (O + c[4 * wsel + j] <= rthr) ++cnt;
-            if (cnt > 3) cnt = 3;
-            const int exc = 4 * wsel + cnt;
+            /* the draw = number of leaves whose inclusive prefix is <= the threshold (inverse CDF, one uniform per
+             * sample).  Prefix of leaf 4g+j, j < 3: scan value of group g-1 (0 for g = 0) + the in-group prefix;
+             * the last leaf of a group carries the group's scan value itself */
+            int cntall = 0;
+            for (int g4 = 0; g4 < 64; ++g4) {
+                const float O = g4 > 0 ? I64[g4 - 1] : 0.0f;
+                for (int j = 0; j < 3; ++j)
+                    if (O + c[4 * g4 + j] <= rthr) ++cntall;
+                if (I64[g4] <= rthr) ++cntall;
+            }
+            const int exc = cntall > 255 ? 255 : cntall;
             /* synthesis filter + de-emphasis (wavenet.py:188 coefficient) */
             const float pcm = pred + m->ulaw_tab[exc];
             for (int k = FPC_LPC_ORDER - 1; k > 0; --k) hist[k] = hist[k - 1];
