@@ -301,6 +301,9 @@ __global__ __launch_bounds__(NTHREADS) void k_decode(const DecodeParams P) {
                 __builtin_amdgcn_s_setprio(0);
 #endif
                 FPC_BARRIER(0)  // Y
+#ifdef FPC_SLEEP_Y
+                __builtin_amdgcn_s_sleep(FPC_SLEEP_Y);  // let the sampler waves' reads of s1' reach the LDS first
+#endif
                 // ---- the sparse product of s1' with this lane's 4 blocks (16 columns of 8 rows), sliced under
                 //      the sampler phases: FPC_NA columns under GRU_B, FPC_NB under the dual FC, the rest and the
                 //      store of the partial sums under the draw ----
@@ -526,11 +529,12 @@ __global__ __launch_bounds__(NTHREADS) void k_decode(const DecodeParams P) {
                         rs = add_bcast<DPP_BCAST31, 0xc>(rs);  // row 3 = (r2+r3)+(r0+r1): the balanced total
                         thr = 0.002f * lane_val(rs, 63);
                     }
-                    float c0 = p4.x - thr, c1 = p4.y - thr, c2 = p4.z - thr, c3 = p4.w - thr;
-                    c0 = c0 > 0.0f ? c0 : 0.0f;
-                    c1 = c1 > 0.0f ? c1 : 0.0f;
-                    c2 = c2 > 0.0f ? c2 : 0.0f;
-                    c3 = c3 > 0.0f ? c3 : 0.0f;
+                    // max(p - thr, 0) as one v_sub_f32 with the output clamp (p - thr <= 1 always, so the upper
+                    // clamp never acts; NaN -> 0 on both forms)
+                    const float c0 = __builtin_amdgcn_fmed3f(p4.x - thr, 0.0f, 1.0f);
+                    const float c1 = __builtin_amdgcn_fmed3f(p4.y - thr, 0.0f, 1.0f);
+                    const float c2 = __builtin_amdgcn_fmed3f(p4.z - thr, 0.0f, 1.0f);
+                    const float c3 = __builtin_amdgcn_fmed3f(p4.w - thr, 0.0f, 1.0f);
                     // prefixes inside the lane's 4 leaves, two levels deep: c0 | c0+c1 | (c0+c1)+c2 | (c0+c1)+(c2+c3)
                     const float P1 = c0 + c1, s23 = c2 + c3;
                     const float P2 = P1 + c2, P3 = P1 + s23;
