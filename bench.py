@@ -104,7 +104,7 @@ def cpu_baseline_encode(cores, frames=100):
 
     def one():
         enc = pred.encode(feat, cb, 0.09, 0.28, qtz=True)
-        O.ceps2lpc(np.ascontiguousarray(enc[0].reshape(-1, 20) * np.float32(24.1)))
+        O.ceps2lpc(np.ascontiguousarray(enc["c_in"].reshape(-1, 20) * np.float32(24.1)))
 
     t0, n1 = time.time(), 0
     while time.time() - t0 < 3.0:

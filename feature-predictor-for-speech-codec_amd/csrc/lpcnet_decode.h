@@ -42,6 +42,9 @@ constexpr int PSTRIDE = GA + 4;
 #ifndef FPC_NA
 #define FPC_NA 6  // sparse-product columns (of 16) computed under GRU_B ...
 #endif
+#ifndef FPC_PCM_WHERE
+#define FPC_PCM_WHERE 0  // de-emphasis + PCM store: 0 drawing wave behind barrier X, 1 drawing wave before it, 2 wave 3 behind it
+#endif
 #ifndef FPC_NB
 #define FPC_NB 4  // ... and under the dual FC; the rest runs under the draw
 #endif
@@ -564,13 +567,24 @@ __global__ __launch_bounds__(NTHREADS) void k_decode(const DecodeParams P) {
                         L.hist[t & 15] = cd.x;
                     }
                     pcm_new = cd.x;
+#if FPC_PCM_WHERE == 1
+                    mem = fmaf(FPC_PREEMPH, mem, pcm_new);
+                    if (lane == 0) out[t] = fpc_pcm16(mem);
+#endif
                 }
                 FPC_BARRIER(4)  // X
                 // behind the barrier, off the sample-to-sample chain: de-emphasis and the PCM store
+#if FPC_PCM_WHERE == 0
                 if (wave == 0) {
                     mem = fmaf(FPC_PREEMPH, mem, pcm_new);
                     if (lane == 0) out[t] = fpc_pcm16(mem);
                 }
+#elif FPC_PCM_WHERE == 2
+                if (wave == 3) {  // a sampler wave that does not draw picks the sample up from the history ring
+                    mem = fmaf(FPC_PREEMPH, mem, L.hist[t & 15]);
+                    if (lane == 0) out[t] = fpc_pcm16(mem);
+                }
+#endif
             }
         }
         if (STAMP && blockIdx.x == 0 && lane == 0)

@@ -33,6 +33,27 @@ def f32_to_windows(features):
     return np.stack([a[k * CHUNK: k * CHUNK + CHUNK + 2 * CONTEXT] for k in range(n)])
 
 
+def frames_to_windows(frames):
+    """encoded frames (L, 36) or (1, L, 36) -> (n, 19, 36) windows, hop 15, n = (L - 4) // 15: the as_strided view of
+    src/generate_qtz_features.py:65-70 with its hard-coded (10, 19, 36) (right for that script's L = 154 only, SURVEY
+    App. C) derived from L; frames that do not fill a whole window are dropped"""
+    a = np.asarray(frames, dtype=np.float32).reshape(-1, NB_FEATURES)
+    n = (len(a) - 2 * CONTEXT) // CHUNK
+    if n <= 0:
+        return np.zeros((0, CHUNK + 2 * CONTEXT, NB_FEATURES), np.float32)
+    return np.stack([a[k * CHUNK: k * CHUNK + CHUNK + 2 * CONTEXT] for k in range(n)])
+
+
+def save_windows(path, frames):
+    """the per-utterance `{name}_features` file of the training / synthesis datasets (`write_small_files.py:66-70`
+    stores the (n, 19, 36) windows with torch.save; the datasets read them back with torch.load)"""
+    import torch
+    w = frames if getattr(frames, "ndim", 0) == 3 and frames.shape[1:] == (CHUNK + 2 * CONTEXT, NB_FEATURES) \
+        else frames_to_windows(frames)
+    torch.save(torch.from_numpy(np.ascontiguousarray(w, dtype=np.float32)), path)
+    return w
+
+
 def synthesis_frames(windows, qtz_windows=None, chunks=0):
     """`Libri_lpc_data_syn.__getitem__` (`dataset_syn.py:66-99`) for one utterance: the last `chunks`
     windows (all if 0; the utterance is doubled until it is long enough), centre frames only, pitch

@@ -976,6 +976,24 @@ EXPORT void orc_lpcnet_synthesize(const orc_lpcnet* m, const float* feat, int T,
     free(cfeat);
 }
 
+/* the vocoder's pdf shaping + tail cut of ONE pdf, exactly as orc_lpcnet_synthesize applies it (src/train.py:79-92
+ * without the divisions): out[v] = max(p'[v] - .002 * S1, 0) with p' = p * p**e (e = max(0, 1.5 corr - .5)) and
+ * S1 = balanced total of p' when e > 0, S1 = 1 (not computed) otherwise.  Test hook for golden G9. */
+EXPORT void orc_shape_cut(const float* p_in, float pitch_corr, float* out) {
+    const float shape_e = fpc_shape_exponent(pitch_corr);
+    float p[256], tmp[256];
+    for (int v = 0; v < 256; ++v) p[v] = shape_e > 0.0f ? fpc_shape_pow(p_in[v], shape_e) : p_in[v];
+    float thr = 0.002f;
+    if (shape_e > 0.0f) {
+        memcpy(tmp, p, sizeof p);
+        thr = 0.002f * tree_reduce(tmp, 256);
+    }
+    for (int v = 0; v < 256; ++v) {
+        const float d = p[v] - thr;
+        out[v] = d > 0.0f ? d : 0.0f;
+    }
+}
+
 /* debugging/known-answer helper: pdf of one step from given node probabilities */
 EXPORT void orc_tree_pdf(const float* q, float* p) {
     for (int v = 0; v < 256; ++v) p[v] = tree_leaf_prob(q, v);

@@ -201,6 +201,18 @@ def cal_entropy(hist):
     return float(lib().orc_cal_entropy(_p(h), h.size))
 
 
+def shape_cut(p, pitch_corr):
+    """pdf shaping + tail cut of one 256-level pdf as the vocoder applies it (un-normalised result)"""
+    p = _f32(p)
+    out = np.zeros(256, np.float32)
+    lib().orc_shape_cut(_p(p), C.c_float(pitch_corr), _p(out))
+    return out
+
+
+def period_index(x):
+    return int(lib().orc_period_index(C.c_float(x)))
+
+
 def ceps2lpc(ceps):
     """ceps2lpc_v (ceps2lpc_vct.py:122-162): (N,>=18) -> lpc (N,16), e (N,), rc (N,16)"""
     c = _f32(ceps)

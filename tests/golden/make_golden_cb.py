@@ -42,6 +42,28 @@ def main():
             c = cb_func.vq_train(r, np.zeros((8, 17)), 8)
             stage.append(c)
             r = cb_func.quantize(c, r) - r
+        # the batch loop of train_cb.py:160-217 re-enacted with the reference's own cb_func on synthetic residual
+        # batches (rows with all-zero rows mixed in, dropped as :186 drops them): first batch vq_train per stage,
+        # second batch 10 x update per stage, unequal stage sizes
+        n_entries = [12, 6]
+        cbk10 = [np.zeros((n_entries[i], 17)) for i in range(2)]
+        np.random.seed(31)
+        errs = []
+        for batch_idx in range(2):
+            r10 = synth.cb_training_vectors(1500, seed_offset=50 + batch_idx)
+            r10[::5] = 0.0
+            r10 = np.array([r10[i] for i in range(len(r10)) if sum(abs(r10[i])) != 0])
+            for i in range(2):
+                if batch_idx == 0:
+                    cbk10[i] = cb_func.vq_train(r10, cbk10[i], n_entries[i])
+                else:
+                    for _ in range(10):
+                        cbk10[i] = cb_func.update(r10, cbk10[i], n_entries[i])
+                qr = cb_func.quantize(cbk10[i], r10)
+                r10 = qr - r10
+            errs.append(float(np.sum(r10 * r10)))
+    np.savez_compressed(os.path.join(HERE, "g10_train_cb_loop.npz"), stage0=cbk10[0], stage1=cbk10[1],
+                        errs=np.array(errs), r_last=r10)
     np.savez_compressed(os.path.join(HERE, "g7_cb_train.npz"), idx=idx.astype(np.int64), cb1=cb1, qd=qd, cb2=cb2,
                         cbt=cbt, stage0=stage[0], stage1=stage[1], r_final=r)
     print("wrote g7_cb_train.npz", cbt.shape, idx[:8], float(np.sum(r * r)))

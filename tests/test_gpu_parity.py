@@ -136,7 +136,7 @@ def test_ceps2lpc_vs_golden_and_oracle(torch_cuda, golden, oracle, synth):
     g = golden("g4_ceps2lpc")
     feats = g["feats36"][0]
     e, lpc, rc = ceps2lpc_v(torch.from_numpy(feats[:, :20].copy()))
-    assert np.abs(lpc.cpu().numpy() - g["lpc"]).max() < 2e-4
+    assert np.abs(lpc.cpu().numpy() - g["lpc"]).max() < 2.5e-5  # 10 x the measured 2.4e-6 (FFT vs cosine sum)
     lo, eo, rco = oracle.ceps2lpc(feats[:, :20])
     assert np.array_equal(lpc.cpu().numpy(), lo)
     assert float(e) == float(eo[-1])
@@ -310,7 +310,7 @@ def test_synthesis_qtz_harness_vs_reference_golden(torch_cuda, synth, golden, cb
     g4, g2 = golden("g4_ceps2lpc"), golden("g2_encoder")
     assert feats.shape == (1, 300, 36)
     assert np.abs(feats.cpu().numpy()[..., :20] - g4["feats36"][..., :20]).max() < 1e-4  # 24.1 x 1e-5
-    assert np.abs(feats.cpu().numpy()[..., 20:] - g4["feats36"][..., 20:]).max() < 2e-4
+    assert np.abs(feats.cpu().numpy()[..., 20:] - g4["feats36"][..., 20:]).max() < 2.5e-5
     assert np.abs(r.cpu().numpy() - g2["full_1x300_r"]).max() < 1e-5
     saved = np.load(tmp_path / "samples" / label / "1272-128104-0001_r_t.npy")  # synthesis_qtz.py:166 naming
     assert saved.shape == (1, 300, 18)
@@ -509,3 +509,135 @@ def test_train_converges_at_reference_batch(torch_cuda, synth):
     with pytest.raises(FpcError, match="reloaded"):
         tr.step(feat)
     assert all(np.isfinite(losses)) and all(b < a for a, b in zip(losses, losses[1:])), losses  # lr 1e-4: ~0.3 % a step
+
+
+def test_config5_one_gpu_share_full_size(torch_cuda, model, vocoder, synth, oracle, cb_paths):
+    """BASELINE config 5 at one GPU's full share (128 utterances x 300 frames, all in one launch, more workgroups
+    than a single wave of the encoder fits per XCD): three utterances (c_in, symbols, PCM) bit for bit against
+    the oracle, and the codebook-usage histograms summed over all 128 utterances against the oracle's."""
+    torch = torch_cuda
+    from fpcodec_amd.synthesis_qtz import encode_features
+    voc, w = vocoder
+    B, L, nu = 128, 300, 8
+    f20 = np.tile(synth.predictor_features(nu, L, utt0=5000), (B // nu, 1, 1))
+    nm = np.zeros((B, L, 36), np.float32)
+    nm[:, :, :20] = f20
+    cfg = dict(scl_cb_path=cb_paths["scl_hi"], cb_path=cb_paths["vq_hi"], bl_scl_cb_path=cb_paths["scl_lo"],
+               bl_cb_path=cb_paths["vq_lo"], l1=0.09, l2=0.28, qtz=True)
+    nm_d = torch.from_numpy(nm).cuda()
+    feats, r, ind1, ind2, cb_tot = encode_features(model, cfg, nm_d)
+    enc = model.encoder(cfg, nm_d[:, :, :20], None, 0.09, 0.28, qtz=True, return_indices=True)
+    sd = synth.seeds(B, utt0=5000)
+    pcm = voc.synthesize(feats, sd)
+    c = synth.codebooks()
+    CB = oracle.Codebooks(c["vq_hi"], c["scl_hi"], c["vq_lo"], c["scl_lo"])
+    o = oracle.Predictor(synth.predictor_state_dict()).encode(f20[:nu], CB, 0.09, 0.28, True)  # the 8 distinct ones
+    cin = o["c_in"] * np.float32(synth.MAXI)
+    lpc = oracle.ceps2lpc(cin.reshape(-1, 20))[0].reshape(nu, L, 16)
+    f36 = np.concatenate([cin, lpc], -1)
+    feats_h, idx_h = feats.cpu().numpy(), enc[7].cpu().numpy()
+    for b in (0, 5, 127):  # first workgroup, another utterance, the last workgroup (a replica of utterance 7)
+        assert np.array_equal(feats_h[b], f36[b % nu])
+        assert np.array_equal(idx_h[b], o["idx"][b % nu])
+    assert np.array_equal(feats_h, np.tile(f36, (B // nu, 1, 1)))  # every replica block
+    hs = CB.split_hist(o["hist"] * (B // nu))  # 16 replicas of the 8 utterances
+    for i in range(5):
+        assert np.array_equal(np.atleast_1d(cb_tot[i]), hs[i])
+    orc = oracle.LPCNet(w)
+    pcm_h = pcm.cpu().numpy()
+    for b in (0, 77, 127):
+        assert np.array_equal(pcm_h[b], orc.synthesize(f36[b % nu], int(sd[b])))
+
+
+def test_bench_rank_path_two_ranks_one_gpu(torch_cuda, synth, tmp_path):
+    """bench.py's own multi-rank path, started the way the driver starts it (torch.distributed.run, one process per
+    rank, here 2 ranks on the one GPU with the gloo rehearsal backend): the JSON line reports both ranks, the sample
+    count is the sum of the shards, and each rank's PCM block equals an unsharded decode of the same utterances.
+    (The RCCL branch itself needs 2 GPUs and is only executed by the driver's scaling run.)"""
+    import json
+    import socket
+    import subprocess
+    import sys
+    torch = torch_cuda
+    from fpcodec_amd.ceps2lpc import ceps2lpc_v
+    from fpcodec_amd.lpcnet import LPCNet
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sk = socket.socket()
+    sk.bind(("127.0.0.1", 0))
+    port = sk.getsockname()[1]
+    sk.close()
+    dump = str(tmp_path / "pcm")
+    env = dict(os.environ, FPC_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                        "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"),
+                        "--gpus", "2", "--steps", "1", "--warmup", "1", "--streams", "8", "--secs", "1",
+                        "--no-cpu-baseline", "--dump-pcm", dump],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
+    j = json.loads(line)
+    S, T = 8, 100
+    assert j["n_gpus"] == 2 and j["scaling"] == "weak" and j["config"]["streams_per_gpu"] == S
+    assert abs(j["value"] * j["ms_per_step"] / 1e3 - 2 * S * (T * 160 - 17)) < 1.0  # samples of both ranks
+    assert j["e2e"]["ranks"] == 2 and j["e2e"]["utterances"] == 256 and 5.0 < j["e2e"]["bits_per_frame"] < 30.0
+    # unsharded decode of the same global utterance list
+    nuniq = min(S, 16)
+    base = synth.vocoder_features_raw(nuniq, T, utt0=0)
+    feats = torch.from_numpy(np.stack([base[k % nuniq] for k in range(2 * S)])).cuda()
+    feats[:, :, 20:] = ceps2lpc_v(feats.reshape(-1, 36)[:, :20].contiguous())[1].reshape(2 * S, T, 16)
+    full = LPCNet(synth.lpcnet_weights()).synthesize(feats, synth.seeds(2 * S)).cpu().numpy()
+    for rank in range(2):
+        z = np.load(os.path.join(dump, f"rank{rank}.npz"))
+        assert (int(z["lo"]), int(z["hi"])) == (rank * S, (rank + 1) * S)
+        assert np.array_equal(z["pcm"], full[rank * S:(rank + 1) * S])
+
+
+def test_train_cb_stage_loop_vs_reference_golden(torch_cuda, synth, golden, tmp_path):
+    """G10: the batch loop of src/train_cb.py:160-217 re-enacted with the reference's own cb_func (first batch
+    vq_train per stage, second batch 10 x update per stage, stage sizes 12 and 6) -- the GPU driver reproduces both
+    stages and the final residual bit for bit, and writes a file the repo's vq_quantize loads."""
+    torch = torch_cuda
+    from fpcodec_amd import train_cb, vq_func
+    g = golden("g10_train_cb_loop")
+    n_entries = [12, 6]
+    codebook = [np.zeros((n, 17)) for n in n_entries]
+    np.random.seed(31)
+    errs = []
+    for batch_idx in range(2):
+        r = synth.cb_training_vectors(1500, seed_offset=50 + batch_idx)
+        r[::5] = 0.0
+        rows = torch.from_numpy(r).cuda()
+        rows = rows[rows.abs().sum(1) != 0].contiguous()  # the device-side compaction of train_cb.harvest
+        codebook, res = train_cb.train_stages(codebook, rows, n_entries, batch_idx == 0)
+        errs.append(float(np.sum(res * res)))
+    assert np.array_equal(codebook[0], g["stage0"]) and np.array_equal(codebook[1], g["stage1"])
+    assert np.array_equal(res, g["r_last"]) and np.array_equal(np.array(errs), g["errs"])
+    path = str(tmp_path / "codebooks" / "ceps_vq_codebook_t.npy")
+    train_cb.save_codebook(path, codebook)  # unequal stage sizes -> object array (vq_func.py:141 allow_pickle)
+    x = synth.cb_training_vectors(64, seed_offset=77)
+    qr, hist = vq_func.vq_quantize(x, path)
+    assert qr.shape == (64, 17) and [len(h) for h in hist] == n_entries and sum(h.sum() for h in hist) == 128
+    same = [np.zeros((4, 17)), np.ones((4, 17))]
+    train_cb.save_codebook(str(tmp_path / "same.npy"), same)
+    assert np.load(str(tmp_path / "same.npy")).shape == (2, 4, 17)
+
+
+def test_train_cb_harvest_vs_oracle(torch_cuda, model, synth, oracle, cb_paths):
+    """residual harvest of train_cb.py:165-186 (encoder qtz=False, zero rows dropped, scalar residuals != 0), kept on
+    the device: equal to the oracle encoder's qtz=False outputs compacted on the host the way the reference does"""
+    torch = torch_cuda
+    from fpcodec_amd import train_cb
+    B, L = 5, 60
+    feat = synth.predictor_features(B, L, utt0=900)
+    cfg = dict(scl_cb_path="", cb_path="", bl_scl_cb_path="", bl_cb_path="")
+    o = oracle.Predictor(synth.predictor_state_dict()).encode(feat, None, 0.09, 0.28, qtz=False)
+    for bl in (False, True):
+        rows, scl, scl_bl = train_cb.harvest(model, cfg, torch.from_numpy(feat).cuda(), 0.09, 0.28, train_bl=bl)
+        src = (o["r_under"] if bl else o["r"])[:, :, -17:].reshape(-1, 17)
+        want = np.array([src[i] for i in range(len(src)) if sum(abs(src[i])) != 0])
+        assert rows.is_cuda and np.array_equal(rows.cpu().numpy(), want)
+        assert 0 < len(want) < B * L
+        assert np.array_equal(scl.cpu().numpy(), np.array([k for k in o["r"][:, :, 0].flatten() if k != 0]))
+        assert np.array_equal(scl_bl.cpu().numpy(), np.array([k for k in o["r_under"][:, :, 0].flatten() if k != 0]))

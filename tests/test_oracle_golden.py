@@ -1,7 +1,11 @@
 """Pin the CPU oracle against golden vectors produced by the reference's own Python
 (tests/golden/make_golden.py).  CPU-only."""
+import os
+
 import numpy as np
 import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 @pytest.fixture(scope="module")
@@ -115,11 +119,12 @@ def test_ceps2lpc(oracle, golden):
     g = golden("g4_ceps2lpc")
     feats = g["feats36"][0]
     lpc, e, rc = oracle.ceps2lpc(feats[:, :20])
-    # float path through a 320-point FFT in the reference; direct cosine sum here
-    assert np.abs(lpc - g["lpc"]).max() < 2e-4
-    assert np.abs(lpc - feats[:, 20:]).max() < 2e-4
-    assert abs(e[-1] - g["e_last"]) < 1e-4 * abs(g["e_last"]) + 1e-6
-    assert np.abs(rc[-1] - g["rc_last"]).max() < 2e-4
+    # float path through a 320-point FFT in the reference; direct cosine sum here.  Bounds = 10 x the measured
+    # differences (lpc 2.4e-6, e 6.3e-8 relative, rc 3.7e-8)
+    assert np.abs(lpc - g["lpc"]).max() < 2.5e-5
+    assert np.abs(lpc - feats[:, 20:]).max() < 2.5e-5
+    assert abs(e[-1] - g["e_last"]) < 1e-6 * abs(g["e_last"])
+    assert np.abs(rc[-1] - g["rc_last"]).max() < 5e-7
 
 
 def test_ceps2lpc_early_exit_rows(oracle, golden):
@@ -130,16 +135,19 @@ def test_ceps2lpc_early_exit_rows(oracle, golden):
     # rows that stop early have trailing zeros in the same places as the reference
     assert np.array_equal(lpc == 0, ref == 0)
     assert (ref == 0).any()
+    # these rows sit at the edge of the recursion's early exit (ill-conditioned on purpose): measured 2.9e-3 on
+    # coefficients up to 1.96, bound 1.35 x that
     assert np.abs(lpc - ref).max() < 2e-3 * max(1.0, np.abs(ref).max())
 
 
 # ---- G5: mu-law and LPC predictor restatements (src/utils.py:16-31,91-114) ----
 def test_ulaw_and_lpc_pred(oracle, golden):
     g = golden("g5_ulaw_lpc")
-    assert np.abs(oracle.l2u_ref(g["x"]) - g["l2u"]).max() < 1e-3
-    assert np.abs(oracle.u2l_ref(g["u"]) - g["u2l"]).max() < 1e-2 * 1.0 + 1e-5 * np.abs(g["u2l"]).max()
+    # bounds = 10 x measured (l2u 3.1e-5; u2l identical; lpc_pred 4.9e-4 on values up to 3 882)
+    assert np.abs(oracle.l2u_ref(g["x"]) - g["l2u"]).max() < 3e-4
+    assert np.abs(oracle.u2l_ref(g["u"]) - g["u2l"]).max() <= 4e-3  # one float32 ulp of the largest level (32 768)
     pred = oracle.lpc_pred_ref(g["sig"], g["lpc"])
-    assert np.abs(pred - g["pred"][:, 0]).max() < 1e-3 * np.abs(g["pred"]).max()
+    assert np.abs(pred - g["pred"][:, 0]).max() < 1.3e-6 * np.abs(g["pred"]).max()
 
 
 def test_canonical_ulaw_matches_reference_formula(oracle, golden):
@@ -151,7 +159,7 @@ def test_canonical_ulaw_matches_reference_formula(oracle, golden):
         if abs((u % 1.0) - 0.5) > 1e-3:
             assert L.orc_lin2ulaw(float(x)) == int(np.clip(np.rint(u), 0, 255))
     tab = np.array([L.orc_ulaw2lin(i) for i in range(256)], np.float32)
-    assert np.abs(tab - g["u2l"]).max() < 1e-5 * np.abs(g["u2l"]).max() + 1e-4
+    assert np.abs(tab - g["u2l"]).max() < 2e-2  # measured 2.0e-3 = half an ulp at 32 768
     assert all(L.orc_lin2ulaw(float(tab[i])) == i for i in range(256))
 
 
@@ -223,3 +231,38 @@ def test_train_step_vs_torch(oracle, synth, golden):
     l1 = tr.step(feat)
     check_train_against_golden(g, (l0, l1), grads1, tr.p)
     assert l1 < l0  # the step goes downhill
+
+
+def test_pdf_shaping_and_period_index_vs_reference_golden(oracle, golden):
+    """G9: the reference's own `sample_mu_prob` (src/train.py:79-92) and period-index line (src/synthesis.py:103) on
+    10 240 seeded pdfs x pitch correlations: the oracle's shaping + tail cut (no divisions; S1 = 1 without
+    sharpening) normalises to the same pdf within 1e-6 and has the same arg-max."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("mgs", os.path.join(ROOT, "tests", "golden", "make_golden_shaping.py"))
+    mgs = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mgs)
+    g = golden("g9_shaping")
+    p, feat = mgs.shaping_inputs()
+    n_voiced = n_knee = 0
+    worst = 0.0
+    for k in range(p.shape[1]):
+        corr = float(feat[0, 19, k // 160])
+        c = oracle.shape_cut(p[:, k], corr).astype(np.float64)
+        n_voiced += 1.5 * corr - 0.5 > 0
+        n_knee += abs(1.5 * corr - 0.5) < 1e-6
+        tot = c.sum()
+        assert tot > 0
+        top2 = np.sort(c)[-2:]
+        if top2[1] - top2[0] > 1e-6 * top2[1]:  # a unique maximum: the arg-max is the reference's
+            assert int(np.argmax(c)) == int(g["exc"][k]), k
+        if k % 16 == 0:
+            ref = g["pn_sub"][:, k // 16]
+            worst = max(worst, float(np.abs(c / tot - ref).max()))
+            assert np.array_equal(c > 0, ref > 0) or np.abs(p[:, k].astype(np.float64) - 0.002).min() < 1e-6
+    assert worst < 1e-6, worst
+    assert n_voiced > 2000 and n_knee > 500 and p.shape[1] - n_voiced > 2000  # all three regimes are in the sample
+    c = mgs.period_inputs()
+    want = g["periods"]
+    got = np.array([[oracle.period_index(float(c[b, t, 18])) for t in range(2, 17)] for b in range(2)])
+    # the reference line has no clamp; the embedding has 256 rows, the oracle clamps to them (synthetic P is 40..255)
+    assert np.array_equal(got[:, :, None], np.clip(want, 0, 255))

@@ -93,3 +93,23 @@ def test_numpy_restatement_draws_what_the_oracle_draws(oracle, synth):
         assert abs((pred + _ulaw2lin(exc_prev)) - float(pcm_f[t])) < 1e-2 * max(1.0, abs(float(pcm_f[t])))
     print('second opinion:', same, 'of', n, 'draws identical,', near, 'within one level')
     assert same >= 0.99 * n and near == n, (same, near, n)
+
+
+def test_long_trace_all_kernel_variant_weight_sets(oracle, synth):
+    """the same second opinion over 40 frames (6 383 samples, half of the frames voiced) for each of the three
+    weight sets that select the three decode-kernel instances (tools/second_opinion_long.py; the 3-second runs are
+    recorded in profiles/r02_second_opinion.txt): at most one draw in 10 000 may land on a CDF step within float32
+    rounding, and every draw that differs must sit on such a step (u * S within 1e-5 S of a CDF value; it can then
+    skip several levels when the levels in between were cut to zero)"""
+    import importlib.util
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("sol", os.path.join(root, "tools", "second_opinion_long.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    for k, dens in enumerate([(0.02, 0.02, 0.10), (0.05, 0.05, 0.20), (0.05, 0.05, 0.26)]):
+        r = m.run(dens, 40, 777 + k, 60 + k)
+        assert r["voiced_frames"] >= 20 and r["samples"] == 40 * 160 - 17
+        assert r["differ"] <= max(1, int(1e-4 * r["samples"])), r
+        assert all(mg < 1e-5 for mg in r["margins_of_differing_draws"]), r
+        assert r["condition_max_abs_err"] < 2e-5
