@@ -25,6 +25,10 @@ constexpr int NT = 576;  // 9 wave64; 2 x 576 = 1152 gate rows of GRU1
 constexpr int NW = NT / 64;
 constexpr int MAX_H1 = 512, MAX_H2 = 256, MAX_IN = 64, MAX_FC = 32;
 constexpr int NDIM = 17, SURV = 5;
+constexpr int MAXN = 1024;
+#ifndef FPC_VQ_ABL
+#define FPC_VQ_ABL 0  // timing-only ablations of the search (wrong results, never shipped): 1 no arg-min rounds, 2 no per-lane scan, 4 no distance arithmetic
+#endif  // largest codebook stage the one-pass search holds in LDS (larger stages: strided search)
 
 struct PredDev {
     int in, h1, h2, fc;
@@ -60,7 +64,16 @@ struct __attribute__((aligned(16))) PredLds {
     int res_i[4];
     double qv[NDIM];
     double qs;
+#ifdef FPC_VQ_PROF
+    long long prof[16];  // diagnostic builds only: cycle stamps of the search phases
+#endif
 };
+#ifdef FPC_VQ_PROF
+#define VQ_STAMP(k) \
+    if (tid == 0) L.prof[k] = clock64();
+#else
+#define VQ_STAMP(k)
+#endif
 
 // k-ordered fmaf chains of one row over v[0..K) with weights wT[k][R]: 16 loads in flight per block
 __device__ __forceinline__ float chain1(const float* __restrict__ wT, const float* v, int K, int R, int r, float a) {
@@ -218,45 +231,52 @@ __device__ __forceinline__ void dpp_pair(double d, int i, double& od, int& oi) {
     oi = __builtin_amdgcn_update_dpp(0, i, CTRL, 0xf, 0xf, true);
 }
 __device__ __forceinline__ void take_min(double& d, int& i, double od, int oi) {
-    if (od < d || (od == d && oi < i)) {
-        d = od;
-        i = oi;
-    }
+    // branch-free (three compares, two scalar mask ops, three selects): no exec-mask juggling per exchange step
+    const bool take = (od < d) | ((od == d) & (oi < i));
+    d = take ? od : d;
+    i = take ? oi : i;
 }
+template <int CTRL, int ROWMASK, bool BOUND>
+__device__ __forceinline__ double dpp_mov_f64(double v) {
+    const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+    const int lo = __builtin_amdgcn_update_dpp((int)(unsigned)b, (int)(unsigned)b, CTRL, ROWMASK, 0xf, BOUND);
+    const int hi = __builtin_amdgcn_update_dpp((int)(unsigned)(b >> 32), (int)(unsigned)(b >> 32), CTRL, ROWMASK, 0xf, BOUND);
+    return __longlong_as_double((long long)(((unsigned long long)(unsigned)hi << 32) | (unsigned)lo));
+}
+template <int CTRL, int ROWMASK>
+__device__ __forceinline__ int dpp_mov_i32(int v) {
+    return __builtin_amdgcn_update_dpp(v, v, CTRL, ROWMASK, 0xf, false);
+}
+__device__ __forceinline__ double min_f64(double a, double b) {  // distances are never NaN: plain v_min_f64
+    double r;
+    asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+// (distance, index) minimum over the wave, ties to the lower index; every lane gets the result.  Two passes of
+// cheap exchanges instead of one pass of compound compares: the smallest distance (v_min_f64; four steps inside the
+// 16-lane rows, two row broadcasts, lane 63 holds the wave's), then the smallest index among the lanes that hold
+// exactly that distance (v_min_i32, DPP-fused).  The result does not depend on the pairing order (a minimum of a set).
 __device__ __forceinline__ void wave_argmin(double& d, int& i) {
-    double od;
-    int oi;
-    dpp_pair<0xB1>(d, i, od, oi);  // quad_perm [1,0,3,2]
-    take_min(d, i, od, oi);
-    dpp_pair<0x4E>(d, i, od, oi);  // quad_perm [2,3,0,1]
-    take_min(d, i, od, oi);
-    dpp_pair<0x141>(d, i, od, oi);  // row_half_mirror
-    take_min(d, i, od, oi);
-    dpp_pair<0x140>(d, i, od, oi);  // row_mirror
-    take_min(d, i, od, oi);
-    // across rows: rows 1,3 take the minimum of row 0,2 (row_bcast:15), rows 2,3 that of rows 0-1 (row_bcast:31);
-    // lane 63 then holds the wave's minimum, handed to every lane through SGPRs
-    {
-        const unsigned long long b = (unsigned long long)__double_as_longlong(d);
-        const int lo = __builtin_amdgcn_update_dpp((int)(unsigned)b, (int)(unsigned)b, 0x142, 0xa, 0xf, false);
-        const int hi = __builtin_amdgcn_update_dpp((int)(unsigned)(b >> 32), (int)(unsigned)(b >> 32), 0x142, 0xa, 0xf, false);
-        oi = __builtin_amdgcn_update_dpp(i, i, 0x142, 0xa, 0xf, false);
-        od = __longlong_as_double((long long)(((unsigned long long)(unsigned)hi << 32) | (unsigned)lo));
-        take_min(d, i, od, oi);
-    }
-    {
-        const unsigned long long b = (unsigned long long)__double_as_longlong(d);
-        const int lo = __builtin_amdgcn_update_dpp((int)(unsigned)b, (int)(unsigned)b, 0x143, 0xc, 0xf, false);
-        const int hi = __builtin_amdgcn_update_dpp((int)(unsigned)(b >> 32), (int)(unsigned)(b >> 32), 0x143, 0xc, 0xf, false);
-        oi = __builtin_amdgcn_update_dpp(i, i, 0x143, 0xc, 0xf, false);
-        od = __longlong_as_double((long long)(((unsigned long long)(unsigned)hi << 32) | (unsigned)lo));
-        take_min(d, i, od, oi);
-    }
-    const unsigned long long b = (unsigned long long)__double_as_longlong(d);
+    double m = d;
+    m = min_f64(m, dpp_mov_f64<0xB1, 0xf, false>(m));   // quad_perm [1,0,3,2]
+    m = min_f64(m, dpp_mov_f64<0x4E, 0xf, false>(m));   // quad_perm [2,3,0,1]
+    m = min_f64(m, dpp_mov_f64<0x141, 0xf, false>(m));  // row_half_mirror
+    m = min_f64(m, dpp_mov_f64<0x140, 0xf, false>(m));  // row_mirror
+    m = min_f64(m, dpp_mov_f64<0x142, 0xa, false>(m));  // row_bcast:15 -> rows 1,3
+    m = min_f64(m, dpp_mov_f64<0x143, 0xc, false>(m));  // row_bcast:31 -> rows 2,3
+    const unsigned long long b = (unsigned long long)__double_as_longlong(m);
     const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)b, 63);
     const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(b >> 32), 63);
-    d = __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
-    i = __builtin_amdgcn_readlane(i, 63);
+    const double dmin = __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+    int c = d == dmin ? i : 0x7fffffff;
+    c = min(c, dpp_mov_i32<0xB1, 0xf>(c));
+    c = min(c, dpp_mov_i32<0x4E, 0xf>(c));
+    c = min(c, dpp_mov_i32<0x141, 0xf>(c));
+    c = min(c, dpp_mov_i32<0x140, 0xf>(c));
+    c = min(c, dpp_mov_i32<0x142, 0xa>(c));
+    c = min(c, dpp_mov_i32<0x143, 0xc>(c));
+    d = dmin;
+    i = __builtin_amdgcn_readlane(c, 63);
 }
 
 // per-wave M-best (5 smallest by (distance, index)) of search `srch` -> L.wd/L.wi
@@ -284,6 +304,7 @@ __device__ void wave_mbest(PredLds& L, int srch, const double* __restrict__ cbT,
             }
         }
     }
+#pragma unroll 1
     for (int rnd = 0; rnd < SURV; ++rnd) {
         double d = d5[0];
         int ix = i5[0];
@@ -312,6 +333,7 @@ __device__ void merge_mbest(PredLds& L, int srch, int lane) {
         d = L.wd[srch][lane / SURV][lane % SURV];
         ix = L.wi[srch][lane / SURV][lane % SURV];
     }
+#pragma unroll 1
     for (int rnd = 0; rnd < SURV; ++rnd) {
         double md = d;
         int mi = ix;
@@ -327,16 +349,157 @@ __device__ void merge_mbest(PredLds& L, int srch, int lane) {
     }
 }
 
+// Running (distance, index) minimum of T targets over this thread's entries (e = tid, tid + NT, ...: ascending, so
+// strict < keeps the lower index), the entry's coordinates loaded once for all targets; then the minimum of the
+// workgroup: per-wave exchange, one LDS hop, NW candidates per target.  Only the BEST entry per target is needed
+// where the reference's M-best list is never read past its head: in 1-stage searches (vq_func.py:93-95) and in
+// stage 2, whose merge-insert (:110-125) only ever returns the path at position 0 = the smallest total error,
+// earlier survivors winning ties (strict <).
+template <int T>
+__device__ __forceinline__ void block_argmin(PredLds& L, const double* __restrict__ cbT, int N, int tid) {
+    // N <= 2 * NT: a thread owns entries tid and tid + NT; their coordinates stay in registers across the targets
+    const int wave = tid >> 6, lane = tid & 63;
+    const int e0 = tid, e1 = tid + NT;
+    const bool has0 = e0 < N, has1 = e1 < N;
+    double c0[NDIM], c1[NDIM];
+#pragma unroll
+    for (int j = 0; j < NDIM; ++j) {
+        c0[j] = has0 ? cbT[(size_t)j * N + e0] : 0.0;
+        c1[j] = has1 ? cbT[(size_t)j * N + e1] : 0.0;
+    }
+    auto dist = [](const double* x, const double* c) {
+        double r[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const double d = x[j] - c[j];
+            r[j] = d * d;
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const double d = x[8 + j] - c[8 + j];
+            const double dd = d * d;
+            r[j] = r[j] + dd;
+        }
+        double res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+        const double d = x[16] - c[16];
+        const double dd = d * d;
+        res = res + dd;
+        return res;
+    };
+#pragma unroll 1
+    for (int k = 0; k < T; ++k) {  // (not unrolled: one target's 17 coordinates live at a time, one exchange network)
+        double x[NDIM];
+#pragma unroll
+        for (int j = 0; j < NDIM; ++j) x[j] = L.xq[k][j];
+        double d = INFINITY;
+        int ix = 0x7fffffff;
+        if (has0) {
+            d = dist(x, c0);
+            ix = e0;
+        }
+        if (has1) {  // ascending entries: strict < keeps the lower index
+            const double d1 = dist(x, c1);
+            if (d1 < d) {
+                d = d1;
+                ix = e1;
+            }
+        }
+        wave_argmin(d, ix);
+        if (lane == 0) {
+            L.wd[k][wave][0] = d;
+            L.wi[k][wave][0] = ix;
+        }
+    }
+    __syncthreads();
+    if (tid < T) {
+        double d = L.wd[tid][0][0];
+        int ix = L.wi[tid][0][0];
+        for (int w = 1; w < NW; ++w) take_min(d, ix, L.wd[tid][w][0], L.wi[tid][w][0]);
+        L.od[tid][0] = d;
+        L.oi[tid][0] = ix;
+    }
+}
+
+// stage-1 M-best of a stage of <= 2 * NT entries: a thread owns entries tid and tid + NT (coordinates loaded
+// together), its sorted pair feeds the per-wave rounds -> L.wd/L.wi[0]; merge_mbest(L, 0, .) finishes
+__device__ __forceinline__ void wave_mbest2(PredLds& L, const double* __restrict__ cbT, int N, int tid) {
+    const int wave = tid >> 6, lane = tid & 63;
+    const int e0 = tid, e1 = tid + NT;
+    const bool has0 = e0 < N, has1 = e1 < N;
+    double c0[NDIM], c1[NDIM], x[NDIM];
+#pragma unroll
+    for (int j = 0; j < NDIM; ++j) {
+        c0[j] = has0 ? cbT[(size_t)j * N + e0] : 0.0;
+        c1[j] = has1 ? cbT[(size_t)j * N + e1] : 0.0;
+        x[j] = L.xq[0][j];
+    }
+    auto dist = [](const double* xx, const double* c) {
+        double r[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const double d = xx[j] - c[j];
+            r[j] = d * d;
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const double d = xx[8 + j] - c[8 + j];
+            const double dd = d * d;
+            r[j] = r[j] + dd;
+        }
+        double res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+        const double d = xx[16] - c[16];
+        const double dd = d * d;
+        res = res + dd;
+        return res;
+    };
+    double da = has0 ? dist(x, c0) : INFINITY, db = has1 ? dist(x, c1) : INFINITY;
+    int ia = has0 ? e0 : 0x7fffffff, ib = has1 ? e1 : 0x7fffffff;
+    if (db < da) {  // sorted pair; equal distances keep the lower index (e0 < e1) first
+        const double t = da;
+        da = db;
+        db = t;
+        const int u = ia;
+        ia = ib;
+        ib = u;
+    }
+#pragma unroll 1
+    for (int rnd = 0; rnd < SURV; ++rnd) {
+        double d = da;
+        int ix = ia;
+        wave_argmin(d, ix);
+        if (ia == ix && ix != 0x7fffffff) {  // this lane's head won: pop it
+            da = db;
+            ia = ib;
+            db = INFINITY;
+            ib = 0x7fffffff;
+        }
+        if (lane == 0) {
+            L.wd[0][wave][rnd] = d;
+            L.wi[0][wave][rnd] = ix;
+        }
+    }
+}
+
 // quantize_mstage (vq_func.py:82-131) on L.rs[1..17]; result in L.qv, L.res_i[0..1].
 // Block-uniform control flow; ends with a barrier.
-__device__ void vq_mstage(PredLds& L, int S, const double* cb0T, const double* cb0R, int N0,
+__device__ __forceinline__ void vq_mstage(PredLds& L, int S, const double* cb0T, const double* cb0R, int N0,
                           const double* cb1T, const double* cb1R, int N1, int tid) {
     const int wave = tid >> 6, lane = tid & 63;
+    VQ_STAMP(0)
     if (tid < NDIM) L.xq[0][tid] = (double)L.rs[1 + tid];
     __syncthreads();
-    wave_mbest(L, 0, cb0T, N0, tid);
-    __syncthreads();
-    if (wave == 0) merge_mbest(L, 0, lane);
+    if (S == 1 && N0 <= 2 * NT) {  // the nearest entry is all a 1-stage search returns
+        block_argmin<1>(L, cb0T, N0, tid);
+    } else if (N0 <= 2 * NT) {  // per-wave M-best of the threads' entry pairs, merged by one wave
+        wave_mbest2(L, cb0T, N0, tid);
+        __syncthreads();
+        VQ_STAMP(1)
+        if (wave == 0) merge_mbest(L, 0, lane);
+    } else {
+        wave_mbest(L, 0, cb0T, N0, tid);
+        __syncthreads();
+        if (wave == 0) merge_mbest(L, 0, lane);
+    }
     __syncthreads();
     if (S == 1) {
         if (tid < NDIM) L.qv[tid] = cb0R[(size_t)L.oi[0][0] * NDIM + tid];
@@ -347,6 +510,7 @@ __device__ void vq_mstage(PredLds& L, int S, const double* cb0T, const double* c
         __syncthreads();
         return;
     }
+    VQ_STAMP(2)
     // stage 2: residual of every survivor, searched concurrently
     int s1[SURV];
 #pragma unroll
@@ -357,43 +521,35 @@ __device__ void vq_mstage(PredLds& L, int S, const double* cb0T, const double* c
         L.xq[k][d] = (double)L.rs[1 + d] - cb0R[(size_t)s1[k] * NDIM + d];
     }
     __syncthreads();
-    for (int k = 0; k < SURV; ++k) wave_mbest(L, k, cb1T, N1, tid);
-    __syncthreads();
-    if (wave < SURV) merge_mbest(L, wave, lane);
-    __syncthreads();
-    if (tid == 0) {  // merge-insert of candidate paths (vq_func.py:110-125)
-        int b0[SURV], b1[SURV];
-        double glob[SURV];
-        for (int m = 0; m < SURV; ++m) {
-            b0[m] = s1[0];
-            b1[m] = L.oi[0][m];
-            glob[m] = L.od[0][m];
-        }
-        for (int k = 1; k < SURV; ++k) {
-            if (L.od[k][0] < glob[SURV - 1]) {
-                int m = 0;
-                for (int p = 0; p < SURV; ++p) {
-                    if (L.od[k][m] < glob[p]) {
-                        for (int j = SURV - 1; j > p; --j) {
-                            glob[j] = glob[j - 1];
-                            b0[j] = b0[j - 1];
-                            b1[j] = b1[j - 1];
-                        }
-                        glob[p] = L.od[k][m];
-                        b0[p] = s1[k];
-                        b1[p] = L.oi[k][m];
-                        ++m;
-                    }
-                }
-            }
-        }
-        L.res_i[0] = b0[0];
-        L.res_i[1] = b1[0];
+    VQ_STAMP(3)
+    if (N1 <= 2 * NT) {
+        block_argmin<SURV>(L, cb1T, N1, tid);  // the five searches share one pass over the entries
+    } else {  // larger stages: strided M-best search per survivor (only the heads are used below)
+        for (int k = 0; k < SURV; ++k) wave_mbest(L, k, cb1T, N1, tid);
+        __syncthreads();
+        if (wave < SURV) merge_mbest(L, wave, lane);
     }
     __syncthreads();
+    VQ_STAMP(5)
+    if (tid == 0) {
+        // head of the merge-insert of candidate paths (vq_func.py:110-125): survivor k's best stage-2 entry replaces
+        // the running best only if its total error is strictly smaller (earlier survivors win ties)
+        int bk = 0;
+        double g = L.od[0][0];
+        for (int k = 1; k < SURV; ++k)
+            if (L.od[k][0] < g) {
+                g = L.od[k][0];
+                bk = k;
+            }
+        L.res_i[0] = s1[bk];
+        L.res_i[1] = L.oi[bk][0];
+    }
+    __syncthreads();
+    VQ_STAMP(6)
     if (tid < NDIM)
         L.qv[tid] = cb0R[(size_t)L.res_i[0] * NDIM + tid] + cb1R[(size_t)L.res_i[1] * NDIM + tid];
     __syncthreads();
+    VQ_STAMP(7)
 }
 
 // scl_quantize (vq_func.py:167-185): first arg-min of (x-c)^2 in float64 -> L.qs, L.res_i[2]
@@ -402,6 +558,25 @@ __device__ void scl_search(PredLds& L, float xv, const double* __restrict__ code
     double bd = INFINITY;
     int bi = 0x7fffffff;
     const double v = (double)xv;
+    if (n <= 256) {  // small codebooks: one wave, no cross-wave round
+        if (wave == 0) {
+            for (int c = lane; c < n; c += 64) {
+                const double df = v - codes[c];
+                const double d = df * df;
+                if (d < bd) {
+                    bd = d;
+                    bi = c;
+                }
+            }
+            wave_argmin(bd, bi);
+            if (lane == 0) {
+                L.res_i[2] = bi;
+                L.qs = codes[bi];
+            }
+        }
+        __syncthreads();
+        return;
+    }
     for (int c = tid; c < n; c += NT) {
         const double df = v - codes[c];
         const double d = df * df;
@@ -488,23 +663,24 @@ __global__ __launch_bounds__(NT) void k_encode(const PredDev P, const CbDev C, c
                     if (A.hist) atomicAdd(&A.hist[(i1 ? 0 : off_sl) + L.res_i[2]], 1ull);
                 }
             }
-            if (i2) {  // :229-234
-                vq_mstage(L, C.S_hi, C.vq_hi0, C.vq_hi0_r, C.N_hi0, C.vq_hi1, C.vq_hi1_r, C.N_hi1, tid);
+            if (i2 || C.vq_lo) {  // :229-240: above the threshold the 1- or 2-stage book, below it the 1-stage one
+                // (one call site: the search is one copy of code, inlined with global pointers)
+                vq_mstage(L, i2 ? C.S_hi : 1, i2 ? C.vq_hi0 : C.vq_lo, i2 ? C.vq_hi0_r : C.vq_lo_r,
+                          i2 ? C.N_hi0 : C.N_lo, i2 ? C.vq_hi1 : nullptr, i2 ? C.vq_hi1_r : nullptr,
+                          i2 ? C.N_hi1 : 0, tid);
                 if (tid >= 1 && tid < F) rq = (float)L.qv[tid - 1];
                 if (tid == 0) {
-                    ix1 = L.res_i[0];
-                    ix2 = L.res_i[1];
-                    if (A.hist) {
-                        atomicAdd(&A.hist[off_v0 + ix1], 1ull);
-                        if (C.S_hi == 2) atomicAdd(&A.hist[off_v1 + ix2], 1ull);
+                    if (i2) {
+                        ix1 = L.res_i[0];
+                        ix2 = L.res_i[1];
+                        if (A.hist) {
+                            atomicAdd(&A.hist[off_v0 + ix1], 1ull);
+                            if (C.S_hi == 2) atomicAdd(&A.hist[off_v1 + ix2], 1ull);
+                        }
+                    } else {
+                        ix3 = L.res_i[0];
+                        if (A.hist) atomicAdd(&A.hist[off_vl + ix3], 1ull);
                     }
-                }
-            } else if (C.vq_lo) {  // :235-240
-                vq_mstage(L, 1, C.vq_lo, C.vq_lo_r, C.N_lo, nullptr, nullptr, 0, tid);
-                if (tid >= 1 && tid < F) rq = (float)L.qv[tid - 1];
-                if (tid == 0) {
-                    ix3 = L.res_i[0];
-                    if (A.hist) atomicAdd(&A.hist[off_vl + ix3], 1ull);
                 }
             }
         }
@@ -609,11 +785,14 @@ __global__ __launch_bounds__(NT) void k_vq(const CbDev C, int which, const float
     const int n = blockIdx.x, tid = threadIdx.x;
     if (tid < NDIM) L.rs[1 + tid] = r[(size_t)n * NDIM + tid];
     __syncthreads();
-    if (which == 0)
-        vq_mstage(L, C.S_hi, C.vq_hi0, C.vq_hi0_r, C.N_hi0, C.vq_hi1, C.vq_hi1_r, C.N_hi1, tid);
-    else
-        vq_mstage(L, 1, C.vq_lo, C.vq_lo_r, C.N_lo, nullptr, nullptr, 0, tid);
+    const bool hi = which == 0;
+    vq_mstage(L, hi ? C.S_hi : 1, hi ? C.vq_hi0 : C.vq_lo, hi ? C.vq_hi0_r : C.vq_lo_r, hi ? C.N_hi0 : C.N_lo,
+              hi ? C.vq_hi1 : nullptr, hi ? C.vq_hi1_r : nullptr, hi ? C.N_hi1 : 0, tid);
     if (tid < NDIM) qr[(size_t)n * NDIM + tid] = L.qv[tid];
+#ifdef FPC_VQ_PROF
+    __syncthreads();
+    if (tid < 8) qr[(size_t)n * NDIM + tid] = (double)(L.prof[tid] - L.prof[0]);
+#endif
     if (tid < 2 && idx) idx[n * 2 + tid] = L.res_i[tid];
 }
 
