@@ -25,10 +25,63 @@ constexpr int NT = 576;  // 9 wave64; 2 x 576 = 1152 gate rows of GRU1
 constexpr int NW = NT / 64;
 constexpr int MAX_H1 = 512, MAX_H2 = 256, MAX_IN = 64, MAX_FC = 32;
 constexpr int NDIM = 17, SURV = 5;
-constexpr int MAXN = 1024;
-#ifndef FPC_VQ_ABL
-#define FPC_VQ_ABL 0  // timing-only ablations of the search (wrong results, never shipped): 1 no arg-min rounds, 2 no per-lane scan, 4 no distance arithmetic
-#endif  // largest codebook stage the one-pass search holds in LDS (larger stages: strided search)
+
+// ---- row split: one utterance on NSPLIT workgroups (SURVEY 2.1 "row-sliced weights-stationary across CUs") ----
+// Every frame streams the whole 2.67 MB weight set through ONE CU's L2 port (25 us at ~108 GB/s), 300 frames in
+// sequence: the port, not the arithmetic, sets the time.  With the utterance on two workgroups, each evaluates the
+// gate rows of half of the units of both GRUs (half of the bytes through its port) and the halves of the new state
+// are exchanged after each GRU as 8-byte {epoch, value} granules: one write-through (sc1) store per value, polled
+// by the partner with sc1 loads until the tag matches -- no fence, no flag (cdna_hip_programming.md G16, form R2).
+// The output layer, thresholds and searches run redundantly on both (same inputs, same code: same bits); half 0
+// writes the outputs.  Granules are zeroed before every launch, epochs count 1.. within it; a spin that does not
+// see its tag in ~2 s gives up and poisons the outputs (never hangs).  Placement-independent: nothing assumes
+// which CUs or XCDs the two workgroups land on, only that both get dispatched (in-order dispatch, grid <= CUs).
+typedef __attribute__((address_space(1))) unsigned long long gu64;
+struct SplitCtx {
+    int n = 1, half = 0;            // workgroups per utterance, this workgroup's slice
+    unsigned long long* g1 = nullptr;  // [H1] granules of the new GRU1 state of this utterance
+    unsigned long long* g2 = nullptr;  // [H2]
+    unsigned* err = nullptr;        // set on spin timeout
+    unsigned epoch = 0;             // last epoch used
+    bool dead = false;              // a spin gave up: no further waiting in this workgroup
+};
+__device__ __forceinline__ void store_granule(unsigned long long* g, unsigned epoch, float v) {
+    __hip_atomic_store((gu64*)g, ((unsigned long long)epoch << 32) | (unsigned long long)__float_as_uint(v),
+                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// publish this half of h[0..H) and pick the other half up (h in LDS; ends with a barrier)
+__device__ __forceinline__ void exchange_halves(float* h, int H, SplitCtx& X, unsigned long long* g, int tid) {
+    const int Hs = H / X.n, mine = X.half * Hs;  // this workgroup's slice of the units; every other slice is read
+    const unsigned epoch = ++X.epoch;
+    for (int i = tid; i < Hs; i += NT) store_granule(&g[mine + i], epoch, h[mine + i]);
+    bool gave_up = false;
+    for (int ii = tid; ii < H - Hs; ii += NT) {
+        const int i = ii < mine ? ii : ii + Hs;
+        unsigned long long x = 0x7fc00000ull;  // NaN unless the partner's value arrives: poisons everything downstream
+        unsigned spins = 0;
+        while (!X.dead) {
+            const unsigned long long v = __hip_atomic_load((gu64*)&g[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if ((unsigned)(v >> 32) == epoch) {
+                x = v;
+                break;
+            }
+            ++spins;
+            // the partner never came (~1 s), or another workgroup already gave up: stop waiting, here and from now on --
+            // the launch must end quickly and loudly, never hang the GPU
+            if (spins > (1u << 20) || ((spins & 1023u) == 0 &&
+                                       __hip_atomic_load((__attribute__((address_space(1))) unsigned*)X.err,
+                                                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)) {
+                __hip_atomic_store((__attribute__((address_space(1))) unsigned*)X.err, 1u, __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
+                gave_up = true;
+                break;
+            }
+            __builtin_amdgcn_s_sleep(1);
+        }
+        h[i] = __uint_as_float((unsigned)x);
+    }
+    if (__syncthreads_or(gave_up)) X.dead = true;
+}
 
 struct PredDev {
     int in, h1, h2, fc;
@@ -141,15 +194,18 @@ __device__ __forceinline__ float seg_tree(const float (*p)[3 * MAX_H1], int S, i
 // ---- GRU layer: both mat-vecs in one pass over (matrix, row quad, segment) work items ----
 __device__ void gru_rows(const float* __restrict__ wiT, const float* __restrict__ whT,
                          const float* __restrict__ bi, const float* __restrict__ bh,
-                         const float* x, int K, const float* h, int H, PredLds& L, int tid) {
-    const int R = 3 * H, Q = R / 4;
+                         const float* x, int K, const float* h, int H, PredLds& L, int tid, int nsplit = 1, int half = 0) {
+    const int R = 3 * H;
+    const int Qg = H / 4 / nsplit;  // row quads per gate in this workgroup's slice of the units (H % (4 nsplit) == 0)
+    const int Q = 3 * Qg;
     const int Si = segments(K), Sh = segments(H);
     const int n_h = Q * Sh, n_all = n_h + Q * Si;
     for (int it = tid; it < n_all; it += NT) {
         const bool is_h = it < n_h;
         const int j = is_h ? it : it - n_h;
         const int q = j % Q, sg = j / Q;  // consecutive threads -> adjacent row quads: coalesced 16-byte loads
-        const int len = (is_h ? H : K) / (is_h ? Sh : Si), k0 = sg * len, r = 4 * q;
+        const int gate = q / Qg, qq = q - gate * Qg;
+        const int len = (is_h ? H : K) / (is_h ? Sh : Si), k0 = sg * len, r = gate * H + 4 * (half * Qg + qq);
         float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
         if (sg == 0) a = *reinterpret_cast<const float4*>(&(is_h ? bh : bi)[r]);
         chain4((is_h ? whT : wiT) + (size_t)k0 * R, (is_h ? h : x) + k0, len, R, r, a);
@@ -160,10 +216,12 @@ __device__ void gru_rows(const float* __restrict__ wiT, const float* __restrict_
 
 __device__ void gru_layer(const float* __restrict__ wiT, const float* __restrict__ whT,
                           const float* __restrict__ bi, const float* __restrict__ bh,
-                          const float* x, int K, float* h, int H, PredLds& L, int tid) {
-    gru_rows(wiT, whT, bi, bh, x, K, h, H, L, tid);
+                          const float* x, int K, float* h, int H, PredLds& L, int tid, int nsplit = 1, int half = 0) {
+    gru_rows(wiT, whT, bi, bh, x, K, h, H, L, tid, nsplit, half);
     const int Si = segments(K), Sh = segments(H);
-    for (int i = tid; i < H; i += NT) {  // torch.nn.GRU gate rows [r; z; n]
+    const int Hh = H / nsplit;
+    for (int ii = tid; ii < Hh; ii += NT) {  // torch.nn.GRU gate rows [r; z; n]
+        const int i = half * Hh + ii;
         const float gir = seg_tree(L.pi, Si, i), giz = seg_tree(L.pi, Si, H + i), gin = seg_tree(L.pi, Si, 2 * H + i);
         const float ghr = seg_tree(L.ph, Sh, i), ghz = seg_tree(L.ph, Sh, H + i), ghn = seg_tree(L.ph, Sh, 2 * H + i);
         const float r = fpc_sigmoidf(gir + ghr);
@@ -175,9 +233,16 @@ __device__ void gru_layer(const float* __restrict__ wiT, const float* __restrict
 }
 
 // one frame of Wavernn.forward: L.x -> L.fo, states in L.h1/L.h2
-__device__ void pred_step(const PredDev& P, PredLds& L, int tid) {
-    gru_layer(P.w1i, P.w1h, P.b1i, P.b1h, L.x, P.in, L.h1, P.h1, L, tid);
-    gru_layer(P.w2i, P.w2h, P.b2i, P.b2h, L.h1, P.h1, L.h2, P.h2, L, tid);
+__device__ void pred_step(const PredDev& P, PredLds& L, int tid, SplitCtx* X = nullptr) {
+    if (X && X->n > 1) {  // this workgroup's slice of the units of each GRU, then the slices change hands
+        gru_layer(P.w1i, P.w1h, P.b1i, P.b1h, L.x, P.in, L.h1, P.h1, L, tid, X->n, X->half);
+        exchange_halves(L.h1, P.h1, *X, X->g1, tid);
+        gru_layer(P.w2i, P.w2h, P.b2i, P.b2h, L.h1, P.h1, L.h2, P.h2, L, tid, X->n, X->half);
+        exchange_halves(L.h2, P.h2, *X, X->g2, tid);
+    } else {
+        gru_layer(P.w1i, P.w1h, P.b1i, P.b1h, L.x, P.in, L.h1, P.h1, L, tid);
+        gru_layer(P.w2i, P.w2h, P.b2i, P.b2h, L.h1, P.h1, L.h2, P.h2, L, tid);
+    }
     for (int i = tid; i < P.h2; i += NT) L.relu[i] = L.h2[i] > 0.0f ? L.h2[i] : 0.0f;
     __syncthreads();
     const int Sf = (P.h2 % 8 == 0 && P.h2 >= 64) ? 8 : 1;  // the few output rows: 8 segments each
@@ -604,22 +669,44 @@ __device__ void scl_search(PredLds& L, float xv, const double* __restrict__ code
 }
 
 // ---------------------------------------------------------------------------------
+struct SplitArgs {
+    int n;                    // workgroups per utterance (1, 2, 4 or 8)
+    unsigned long long* g;    // [B][h1 + h2] exchange granules, zeroed before the launch (n > 1)
+    unsigned* err;            // spin-timeout flag
+};
+__device__ __forceinline__ SplitCtx split_ctx(const SplitArgs& S, const PredDev& P, int b, int half) {
+    SplitCtx X;
+    X.n = S.n;
+    X.half = half;
+    if (S.n > 1) {
+        X.g1 = S.g + (size_t)b * (P.h1 + P.h2);
+        X.g2 = X.g1 + P.h1;
+        X.err = S.err;
+    }
+    return X;
+}
+
 __global__ __launch_bounds__(NT) void k_forward(const PredDev P, const float* __restrict__ x, int Lf,
-                                                float* h1, float* h2, float* __restrict__ y) {
+                                                float* h1, float* h2, float* __restrict__ y, const SplitArgs S) {
     __shared__ PredLds L;
-    const int b = blockIdx.x, tid = threadIdx.x;
+    const int b = blockIdx.x / S.n, half = blockIdx.x % S.n, tid = threadIdx.x;
+    SplitCtx X = split_ctx(S, P, b, half);
+    const bool writer = half == 0;  // both halves compute the same outputs; one stores them
     for (int i = tid; i < P.h1; i += NT) L.h1[i] = h1[(size_t)b * P.h1 + i];
     for (int i = tid; i < P.h2; i += NT) L.h2[i] = h2[(size_t)b * P.h2 + i];
     __syncthreads();
     for (int t = 0; t < Lf; ++t) {
         if (tid < P.in) L.x[tid] = x[((size_t)b * Lf + t) * P.in + tid];
         __syncthreads();
-        pred_step(P, L, tid);
-        if (tid < P.fc) y[((size_t)b * Lf + t) * P.fc + tid] = L.fo[tid];
+        pred_step(P, L, tid, &X);
+        if (writer && tid < P.fc) y[((size_t)b * Lf + t) * P.fc + tid] = L.fo[tid];
     }
     __syncthreads();
-    for (int i = tid; i < P.h1; i += NT) h1[(size_t)b * P.h1 + i] = L.h1[i];
-    for (int i = tid; i < P.h2; i += NT) h2[(size_t)b * P.h2 + i] = L.h2[i];
+    // (the partner read the incoming states before its first publish, which this half has waited for: safe to overwrite)
+    if (writer) {
+        for (int i = tid; i < P.h1; i += NT) h1[(size_t)b * P.h1 + i] = L.h1[i];
+        for (int i = tid; i < P.h2; i += NT) h2[(size_t)b * P.h2 + i] = L.h2[i];
+    }
 }
 
 struct EncArgs {
@@ -632,9 +719,11 @@ struct EncArgs {
     unsigned long long* hist;
 };
 
-__global__ __launch_bounds__(NT) void k_encode(const PredDev P, const CbDev C, const EncArgs A) {
+__global__ __launch_bounds__(NT) void k_encode(const PredDev P, const CbDev C, const EncArgs A, const SplitArgs S) {
     __shared__ PredLds L;
-    const int b = blockIdx.x, tid = threadIdx.x;
+    const int b = blockIdx.x / S.n, half = blockIdx.x % S.n, tid = threadIdx.x;
+    SplitCtx X = split_ctx(S, P, b, half);
+    const bool writer = half == 0;  // both halves run the same closed loop on the same bits; one stores the outputs
     const int Cc = P.in, F = P.fc;
     for (int i = tid; i < P.h1; i += NT) L.h1[i] = 0.0f;  // h=None -> zeros (wavernn.py:182)
     for (int i = tid; i < P.h2; i += NT) L.h2[i] = 0.0f;
@@ -645,7 +734,7 @@ __global__ __launch_bounds__(NT) void k_encode(const PredDev P, const CbDev C, c
     for (int i = 0; i < A.Lf; ++i) {
         const size_t fi = (size_t)b * A.Lf + i;
         const float* f = A.feat + fi * Cc;
-        pred_step(P, L, tid);  // wavernn.py:194-195
+        pred_step(P, L, tid, &X);  // wavernn.py:194-195
         if (tid < F) L.rs[tid] = f[tid] - L.fo[tid];  // :196
         __syncthreads();
         float sabs = 0.0f;
@@ -660,7 +749,7 @@ __global__ __launch_bounds__(NT) void k_encode(const PredDev P, const CbDev C, c
                 if (tid == 0) {
                     rq = (float)L.qs;
                     ix0 = L.res_i[2] + (i1 ? 0 : C.n_hi);
-                    if (A.hist) atomicAdd(&A.hist[(i1 ? 0 : off_sl) + L.res_i[2]], 1ull);
+                    if (A.hist && writer) atomicAdd(&A.hist[(i1 ? 0 : off_sl) + L.res_i[2]], 1ull);
                 }
             }
             if (i2 || C.vq_lo) {  // :229-240: above the threshold the 1- or 2-stage book, below it the 1-stage one
@@ -673,13 +762,13 @@ __global__ __launch_bounds__(NT) void k_encode(const PredDev P, const CbDev C, c
                     if (i2) {
                         ix1 = L.res_i[0];
                         ix2 = L.res_i[1];
-                        if (A.hist) {
+                        if (A.hist && writer) {
                             atomicAdd(&A.hist[off_v0 + ix1], 1ull);
                             if (C.S_hi == 2) atomicAdd(&A.hist[off_v1 + ix2], 1ull);
                         }
                     } else {
                         ix3 = L.res_i[0];
-                        if (A.hist) atomicAdd(&A.hist[off_vl + ix3], 1ull);
+                        if (A.hist && writer) atomicAdd(&A.hist[off_vl + ix3], 1ull);
                     }
                 }
             }
@@ -697,17 +786,19 @@ __global__ __launch_bounds__(NT) void k_encode(const PredDev P, const CbDev C, c
                 rv = rs * (float)ind;
                 cn = L.fo[tid] + rv;
             }
-            A.r[fi * F + tid] = rv;
-            A.r_qtz[fi * F + tid] = rq;
-            A.r_under[fi * F + tid] = ru;
-            A.c_in[fi * Cc + tid] = cn;
+            if (writer) {
+                A.r[fi * F + tid] = rv;
+                A.r_qtz[fi * F + tid] = rq;
+                A.r_under[fi * F + tid] = ru;
+                A.c_in[fi * Cc + tid] = cn;
+            }
             L.x[tid] = cn;
         } else if (tid < Cc) {  // pitch columns pass through (:178)
             const float v = f[tid];
-            A.c_in[fi * Cc + tid] = v;
+            if (writer) A.c_in[fi * Cc + tid] = v;
             L.x[tid] = v;
         }
-        if (tid == 0) {
+        if (tid == 0 && writer) {
             A.ind1[fi] = (float)i1;
             A.ind2[fi] = (float)i2;
             if (A.idx) {
@@ -1139,8 +1230,45 @@ struct fpc_predictor {
     PredDev d;
     fpc::DevBuf buf[10];
     fpc::DevBuf flag;  // one int: "a symbol lay outside its codebook" (fpc_decode_features), allocated once per handle
+    fpc::DevBuf xg;    // row-split exchange granules [B][h1 + h2] x 8 bytes + the timeout word, grown on demand
+    int num_cus = 0;
     int refs = 1;  // the creator's handle + one per live fpc_trainer built on it (fpc_predictor_destroy only drops a reference)
 };
+// Row split (two workgroups per utterance) when the batch leaves at least half of the CUs idle; FPC_PRED_SPLIT=0/1
+// forces it off/on (tests run both forms).  Prepares the zeroed granule block on the stream.
+static int split_args(fpc_predictor* p, int B, hipStream_t st, SplitArgs* out) {
+    out->n = 1;
+    out->g = nullptr;
+    out->err = nullptr;
+    const char* env = getenv("FPC_PRED_SPLIT");  // 0: never; 2/4/8: exactly that many (tests); unset: as many as leave
+    int n = 1;                                    // every workgroup a CU of its own, up to 8
+    for (int c = 2; c <= 8; c *= 2)
+        if (p->d.h1 % (4 * c) == 0 && p->d.h2 % (4 * c) == 0 && c * B <= p->num_cus) n = c;
+    if (env && env[0] >= '0' && env[0] <= '8') {
+        const int f = env[0] - '0';
+        if (f == 0 || f == 1)
+            n = 1;
+        else if ((f == 2 || f == 4 || f == 8) && p->d.h1 % (4 * f) == 0 && p->d.h2 % (4 * f) == 0 && f * B <= 2 * p->num_cus)
+            n = f;  // (forced: at most two workgroups per CU, still all resident)
+    }
+    if (n == 1) return FPC_OK;
+    const size_t gran = (size_t)B * (p->d.h1 + p->d.h2) * sizeof(unsigned long long);
+    const size_t bytes = ((gran + 15) / 16) * 16 + 16;  // granules, then the timeout word (own 16-byte slot)
+    if (p->xg.bytes < bytes) {
+        if (p->xg.p) {
+            FPC_HIP(hipStreamSynchronize(st));  // nothing may still be polling the old block
+            (void)hipFree(p->xg.p);
+            p->xg.p = nullptr;
+        }
+        FPC_HIP(p->xg.alloc(bytes));
+    }
+    FPC_HIP(hipMemsetAsync(p->xg.p, 0, bytes, st));  // tags start at 0; epochs count from 1 within the launch
+    out->n = n;
+    out->g = p->xg.as<unsigned long long>();
+    out->err = reinterpret_cast<unsigned*>(static_cast<char*>(p->xg.p) + ((gran + 15) / 16) * 16);
+    return FPC_OK;
+}
+
 static void predictor_unref(fpc_predictor* p) {
     if (p && --p->refs <= 0) delete p;
 }
@@ -1198,6 +1326,11 @@ extern "C" int fpc_predictor_create(const fpc_predictor_weights* w, fpc_predicto
     FPC_HIP(upv(p->buf[8], transpose_f(w->fc_weight, fc, h2), &p->d.fcw));
     FPC_HIP(upv(p->buf[9], vec(w->fc_bias, fc), &p->d.fcb));
     FPC_HIP(p->flag.alloc(sizeof(int)));
+    {
+        int dev = 0;
+        FPC_HIP(hipGetDevice(&dev));
+        FPC_HIP(hipDeviceGetAttribute(&p->num_cus, hipDeviceAttributeMultiprocessorCount, dev));
+    }
     *out = own.release();
     return FPC_OK;
 }
@@ -1208,8 +1341,11 @@ extern "C" int fpc_predictor_forward(fpc_predictor* p, const float* x_dev, int B
                                      float* h1_dev, float* h2_dev, float* y_dev, fpc_stream s) {
     FPC_REQUIRE(p && x_dev && h1_dev && h2_dev && y_dev, "fpc_predictor_forward: null argument");
     FPC_REQUIRE(B > 0 && L >= 0, "fpc_predictor_forward: bad shape B=%d L=%d", B, L);
-    hipLaunchKernelGGL(k_forward, dim3(B), dim3(NT), 0, static_cast<hipStream_t>(s), p->d, x_dev, L,
-                       h1_dev, h2_dev, y_dev);
+    SplitArgs sp;
+    const int rc = split_args(p, B, static_cast<hipStream_t>(s), &sp);
+    if (rc != FPC_OK) return rc;
+    hipLaunchKernelGGL(k_forward, dim3(B * sp.n), dim3(NT), 0, static_cast<hipStream_t>(s), p->d, x_dev, L,
+                       h1_dev, h2_dev, y_dev, sp);
     FPC_HIP(hipGetLastError());
     return FPC_OK;
 }
@@ -1285,7 +1421,10 @@ extern "C" int fpc_encode(fpc_predictor* p, const fpc_codebooks* cb, const float
     if (cb) cd = cb->d;
     EncArgs a{feat_dev, L,  l1, l2, qtz ? 1 : 0, c_in_dev, r_dev, r_qtz_dev, r_under_dev, ind1_dev, ind2_dev,
               idx_dev,  hist_dev};
-    hipLaunchKernelGGL(k_encode, dim3(B), dim3(NT), 0, static_cast<hipStream_t>(s), p->d, cd, a);
+    SplitArgs sp;
+    const int rc = split_args(p, B, static_cast<hipStream_t>(s), &sp);
+    if (rc != FPC_OK) return rc;
+    hipLaunchKernelGGL(k_encode, dim3(B * sp.n), dim3(NT), 0, static_cast<hipStream_t>(s), p->d, cd, a, sp);
     FPC_HIP(hipGetLastError());
     return FPC_OK;
 }

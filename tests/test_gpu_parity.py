@@ -641,3 +641,28 @@ def test_train_cb_harvest_vs_oracle(torch_cuda, model, synth, oracle, cb_paths):
         assert 0 < len(want) < B * L
         assert np.array_equal(scl.cpu().numpy(), np.array([k for k in o["r"][:, :, 0].flatten() if k != 0]))
         assert np.array_equal(scl_bl.cpu().numpy(), np.array([k for k in o["r_under"][:, :, 0].flatten() if k != 0]))
+
+
+def test_predictor_row_split_equals_single_workgroup_form(torch_cuda, model, synth, cb_paths, monkeypatch):
+    """the predictor on 2, 4 or 8 workgroups per utterance (row split, slices of the new states exchanged as tagged
+    granules; taken automatically while the batch leaves CUs idle) and on one workgroup per utterance give the same
+    bits: forward incl. carried states, and the closed-loop encoder incl. symbols and histograms -- at 1, 7 and 128
+    utterances (up to 512 co-resident workgroups) and over 300 frames (600 exchanges per group)"""
+    torch = torch_cuda
+    cfg = dict(scl_cb_path=cb_paths["scl_hi"], cb_path=cb_paths["vq_hi"], bl_scl_cb_path=cb_paths["scl_lo"],
+               bl_cb_path=cb_paths["vq_lo"])
+    for B, L, modes in ((1, 300, ("0", "2", "4", "8")), (7, 50, ("0", "2", "8")), (128, 60, ("0", "2", "4"))):
+        feat = torch.from_numpy(np.tile(synth.predictor_features(min(B, 8), L, utt0=1200), (B // 8 + 1, 1, 1))[:B].copy()).cuda()
+        out = {}
+        for mode in modes:
+            monkeypatch.setenv("FPC_PRED_SPLIT", mode)
+            y, h1, h2 = model.forward(feat)
+            y2, h1b, h2b = model.forward(feat[:, :5], h1, h2)  # carried states
+            enc = model.encoder(cfg, feat, None, 0.09, 0.28, qtz=True, return_indices=True)
+            torch.cuda.synchronize()
+            out[mode] = [t.cpu().numpy() for t in (y, h1, h2, y2, h1b, h2b)] + [t.cpu().numpy() for t in enc[:6]] + \
+                list(enc[6]) + [enc[7].cpu().numpy()]
+        for mode in modes[1:]:
+            assert not any(np.isnan(a).any() for a in out[mode] if a.dtype.kind == "f")  # no spin gave up
+            for a, b in zip(out["0"], out[mode]):
+                assert np.array_equal(a, b), (B, L, mode)

@@ -18,3 +18,8 @@ print("encode qtz=False %.2f ms"%tm(lambda: m.encoder(cfg,f,None,0.09,0.28,qtz=F
 print("encode l1=l2=0 (all frames coded) %.2f ms"%tm(lambda: m.encoder(cfg,f,None,0.0,0.0)))
 print("encode l=inf (none above) %.2f ms"%tm(lambda: m.encoder(cfg,f,None,1e9,1e9)))
 print("forward          %.2f ms"%tm(lambda: m.forward(f)))
+f1=f[:1].contiguous()
+for n in ("0","2","4","8"):
+    os.environ["FPC_PRED_SPLIT"]=n
+    print("single utterance, %s workgroups: encode %.2f ms  forward %.2f ms"%(n if n!="0" else "1", tm(lambda: m.encoder(cfg,f1,None,0.09,0.28)), tm(lambda: m.forward(f1))))
+os.environ.pop("FPC_PRED_SPLIT")
