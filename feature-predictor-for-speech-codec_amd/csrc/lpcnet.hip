@@ -440,6 +440,11 @@ extern "C" int fpc_lpcnet_synthesize(fpc_lpcnet* m, const float* features_dev, i
         else                                                                                      \
             hipLaunchKernelGGL((k_decode<false, QZR, QN>), dim3(B), dim3(NTHREADS), 0, st, P);    \
     } while (0)
+#ifdef FPC_ABL_Q11  // timing-only experiment: gate lanes read one partial-sum plane per row (wrong output)
+    if (variant >= 0)
+        FPC_LAUNCH(1, 1);
+    else
+#endif
     if (variant == 208)
         FPC_LAUNCH(2, 8);
     else if (variant == 408)

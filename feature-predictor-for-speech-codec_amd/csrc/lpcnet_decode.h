@@ -153,8 +153,12 @@ __device__ __forceinline__ unsigned opaque(unsigned v) {
 __device__ __forceinline__ float lut_scaled(const float2* T2, float x, float scale) {
     const float u = fminf(fabsf(x) * scale, 4095.99976f);
     const float f = __builtin_amdgcn_fractf(u);
+#ifdef FPC_ABL_LUT  // timing-only experiment (wrong output): activation without the table read
+    return copysignf(fmaf(f, 0.001f, u * 0.0001f), x);
+#else
     const float2 td = T2[(uint32_t)u];
     return copysignf(fmaf(f, td.y, td.x), x);
+#endif
 }
 __device__ __forceinline__ float lut_tanh(const float2* T2, float x) { return lut_scaled(T2, x, 512.0f); }
 __device__ __forceinline__ float lut_sigmoid(const float2* T2, float x) {
@@ -215,6 +219,9 @@ __global__ __launch_bounds__(NTHREADS) void k_decode(const DecodeParams P) {
         L.s2[tid] = 0.0f;
         L.hist[tid] = 0.0f;
     }
+#ifdef FPC_ABL_WINDOW  // timing-only experiment (wrong output): no per-sample window work; records stay valid constants
+    if (tid < 256) L.cand[tid] = make_float4(0.0f, 0.0f, __uint_as_float(128u * GA), __uint_as_float(384u * GA));
+#endif
     if (tid == 0) {
         L.o_sig = 128u * GA;
         L.o_pred = (256u + 128u) * GA;
@@ -279,9 +286,15 @@ __global__ __launch_bounds__(NTHREADS) void k_decode(const DecodeParams P) {
                     }
                     // uniform base + 32-bit byte offset (the global_load saddr form: no 64-bit VALU address math)
                     const char* tabc = reinterpret_cast<const char*>(P.tab);
+#ifdef FPC_ABL_GATHER  // timing-only experiment (wrong output): no embedding-row gather
+                    (void)tabc;
+                    const F3 ta = {__uint_as_float(oa) * 1e-30f, 0.0f, 0.0f}, tb = {__uint_as_float(ob) * 1e-30f, 0.0f, 0.0f},
+                             tc = {__uint_as_float(oc) * 1e-30f, 0.0f, 0.0f};
+#else
                     const F3 ta = *reinterpret_cast<const F3*>(tabc + (size_t)((oa + 3u * ml) * 4u));
                     const F3 tb = *reinterpret_cast<const F3*>(tabc + (size_t)((ob + 3u * ml) * 4u));
                     const F3 tc = *reinterpret_cast<const F3*>(tabc + (size_t)((oc + 3u * ml) * 4u));
+#endif
                     // while the gather is in flight: recurrent terms of the three rows of unit ml =
                     // diagonal + tree over the row group's partial sums (written before barrier X)
                     const float h_own = L.s1[ml];
@@ -416,10 +429,15 @@ __global__ __launch_bounds__(NTHREADS) void k_decode(const DecodeParams P) {
 #endif
                 // ---- X..Y (the mat-vec waves gather + gate): everything that only needs the
                 //      previous draw: GRU_B recurrent part, LPC history chain, leaf candidates ----
+#ifdef FPC_ABL_WINDOW
+                float ub_z = ub0, ub_r = ub1, ub_n = ub2;
+                if (false) {
+#else
                 const float s2k = L.s2[kl];
                 float ub_z = ub0 * s2k, ub_r = ub1 * s2k, ub_n = ub2 * s2k;
                 row_bfly16x3(ub_z, ub_r, ub_n);
                 {
+#endif
                     // prediction of the NEXT sample: taps 2..16 as a balanced tree over the 16 lanes of
                     // the row (lane kl holds tap kl+1, lane 0 contributes 0), the newest tap by one fma
                     const bool lastsmp = i == FPC_FRAME_SIZE - 1;  // next sample belongs to the next frame
