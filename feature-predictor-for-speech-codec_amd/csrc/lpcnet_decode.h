@@ -186,9 +186,14 @@ __device__ __forceinline__ float part_tree(const float* p0) {
         st_acc[k] += now_ - st_last;                                  \
         st_last = now_;                                               \
     }
+#ifdef FPC_ABL_BARE_BARRIER  // timing-only experiment (NOT a valid program: LDS writes are not waited for)
+#define FPC_SYNC() asm volatile("s_barrier" ::: "memory")
+#else
+#define FPC_SYNC() __syncthreads()
+#endif
 #define FPC_BARRIER(k)   \
     FPC_STAMP(2 * (k))   \
-    __syncthreads();     \
+    FPC_SYNC();          \
     FPC_STAMP(2 * (k) + 1)
 
 // QZR / QN: partial-sum planes read per update/reset-gate row and per candidate-gate row (powers of two

@@ -817,9 +817,11 @@ __global__ __launch_bounds__(NT) void k_encode(const PredDev P, const CbDev C, c
 // A symbol outside its codebook sets *bad and decodes as "not coded".
 __global__ __launch_bounds__(NT) void k_decode_feat(const PredDev P, const CbDev C, const float* __restrict__ pitch,
                                                     const int* __restrict__ idx, int Lf, float* __restrict__ c_out,
-                                                    int* bad) {
+                                                    int* bad, const SplitArgs S) {
     __shared__ PredLds L;
-    const int b = blockIdx.x, tid = threadIdx.x;
+    const int b = blockIdx.x / S.n, half = blockIdx.x % S.n, tid = threadIdx.x;
+    SplitCtx X = split_ctx(S, P, b, half);
+    const bool writer = half == 0;
     const int Cc = P.in, F = P.fc;
     for (int i = tid; i < P.h1; i += NT) L.h1[i] = 0.0f;
     for (int i = tid; i < P.h2; i += NT) L.h2[i] = 0.0f;
@@ -827,7 +829,7 @@ __global__ __launch_bounds__(NT) void k_decode_feat(const PredDev P, const CbDev
     __syncthreads();
     for (int i = 0; i < Lf; ++i) {
         const size_t fi = (size_t)b * Lf + i;
-        pred_step(P, L, tid);
+        pred_step(P, L, tid, &X);
         if (tid < F) {
             const int* ix = idx + fi * 4;
             float rq = 0.0f;
@@ -839,30 +841,30 @@ __global__ __launch_bounds__(NT) void k_decode_feat(const PredDev P, const CbDev
                     else if (C.scl_lo && k - C.n_hi < C.n_lo)
                         rq = (float)C.scl_lo[k - C.n_hi];
                     else
-                        atomicOr(bad, 1);
+                        { if (writer) atomicOr(bad, 1); }
                 }
             } else {
                 const int d = tid - 1, k1 = ix[1], k2 = ix[2], k3 = ix[3];
                 if (k1 >= 0) {
                     if (k1 >= C.N_hi0 || (C.S_hi == 2 && (k2 < 0 || k2 >= C.N_hi1))) {
-                        atomicOr(bad, 1);
+                        { if (writer) atomicOr(bad, 1); }
                     } else {
                         const double e0 = C.vq_hi0_r[(size_t)k1 * NDIM + d];
                         rq = (float)(C.S_hi == 2 ? e0 + C.vq_hi1_r[(size_t)k2 * NDIM + d] : e0);
                     }
                 } else if (k3 >= 0) {
                     if (!C.vq_lo_r || k3 >= C.N_lo)
-                        atomicOr(bad, 1);
+                        { if (writer) atomicOr(bad, 1); }
                     else
                         rq = (float)C.vq_lo_r[(size_t)k3 * NDIM + d];
                 }
             }
             const float cn = L.fo[tid] + rq;
-            c_out[fi * Cc + tid] = cn;
+            if (writer) c_out[fi * Cc + tid] = cn;
             L.x[tid] = cn;
         } else if (tid < Cc) {
             const float v = pitch[fi * (Cc - F) + (tid - F)];
-            c_out[fi * Cc + tid] = v;
+            if (writer) c_out[fi * Cc + tid] = v;
             L.x[tid] = v;
         }
         __syncthreads();
@@ -1439,8 +1441,11 @@ extern "C" int fpc_decode_features(fpc_predictor* p, const fpc_codebooks* cb, co
     // the flag lives in the handle (no per-call hipMalloc/hipFree: hipFree synchronises the whole device); the
     // check itself needs this stream's result, so the call still ends with a sync of this one stream
     FPC_HIP(hipMemsetAsync(p->flag.p, 0, sizeof(int), st));
-    hipLaunchKernelGGL(k_decode_feat, dim3(B), dim3(NT), 0, st, p->d, cb->d, pitch_dev, idx_dev, L, c_out_dev,
-                       p->flag.as<int>());
+    SplitArgs sp;
+    const int rc = split_args(p, B, st, &sp);
+    if (rc != FPC_OK) return rc;
+    hipLaunchKernelGGL(k_decode_feat, dim3(B * sp.n), dim3(NT), 0, st, p->d, cb->d, pitch_dev, idx_dev, L, c_out_dev,
+                       p->flag.as<int>(), sp);
     FPC_HIP(hipGetLastError());
     int h = 0;
     FPC_HIP(hipMemcpyAsync(&h, p->flag.p, sizeof(int), hipMemcpyDeviceToHost, st));
