@@ -49,11 +49,16 @@ __device__ __forceinline__ void store_granule(unsigned long long* g, unsigned ep
     __hip_atomic_store((gu64*)g, ((unsigned long long)epoch << 32) | (unsigned long long)__float_as_uint(v),
                        __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-// publish this half of h[0..H) and pick the other half up (h in LDS; ends with a barrier)
-__device__ __forceinline__ void exchange_halves(float* h, int H, SplitCtx& X, unsigned long long* g, int tid) {
-    const int Hs = H / X.n, mine = X.half * Hs;  // this workgroup's slice of the units; every other slice is read
+// publish this workgroup's slice of h[0..H) (h in LDS) under a new epoch ...
+__device__ __forceinline__ void publish_slice(const float* h, int H, SplitCtx& X, unsigned long long* g, int tid) {
+    const int Hs = H / X.n, mine = X.half * Hs;
     const unsigned epoch = ++X.epoch;
     for (int i = tid; i < Hs; i += NT) store_granule(&g[mine + i], epoch, h[mine + i]);
+}
+// ... and pick every other slice of that epoch up (ends with a barrier); independent work may sit between the two
+__device__ __forceinline__ void consume_slices(float* h, int H, SplitCtx& X, unsigned long long* g, int tid) {
+    const int Hs = H / X.n, mine = X.half * Hs;  // this workgroup's slice of the units; every other slice is read
+    const unsigned epoch = X.epoch;
     bool gave_up = false;
     for (int ii = tid; ii < H - Hs; ii += NT) {
         const int i = ii < mine ? ii : ii + Hs;
@@ -76,11 +81,17 @@ __device__ __forceinline__ void exchange_halves(float* h, int H, SplitCtx& X, un
                 gave_up = true;
                 break;
             }
+#ifndef FPC_XCHG_NOSLEEP
             __builtin_amdgcn_s_sleep(1);
+#endif
         }
         h[i] = __uint_as_float((unsigned)x);
     }
     if (__syncthreads_or(gave_up)) X.dead = true;
+}
+__device__ __forceinline__ void exchange_halves(float* h, int H, SplitCtx& X, unsigned long long* g, int tid) {
+    publish_slice(h, H, X, g, tid);
+    consume_slices(h, H, X, g, tid);
 }
 
 struct PredDev {
@@ -194,13 +205,15 @@ __device__ __forceinline__ float seg_tree(const float (*p)[3 * MAX_H1], int S, i
 // ---- GRU layer: both mat-vecs in one pass over (matrix, row quad, segment) work items ----
 __device__ void gru_rows(const float* __restrict__ wiT, const float* __restrict__ whT,
                          const float* __restrict__ bi, const float* __restrict__ bh,
-                         const float* x, int K, const float* h, int H, PredLds& L, int tid, int nsplit = 1, int half = 0) {
+                         const float* x, int K, const float* h, int H, PredLds& L, int tid, int nsplit = 1, int half = 0,
+                         int part = 0 /* 0: both mat-vecs, 1: recurrent only, 2: input only */) {
     const int R = 3 * H;
     const int Qg = H / 4 / nsplit;  // row quads per gate in this workgroup's slice of the units (H % (4 nsplit) == 0)
     const int Q = 3 * Qg;
     const int Si = segments(K), Sh = segments(H);
     const int n_h = Q * Sh, n_all = n_h + Q * Si;
-    for (int it = tid; it < n_all; it += NT) {
+    const int it0 = part == 2 ? n_h : 0, it1 = part == 1 ? n_h : n_all;
+    for (int it = it0 + tid; it < it1; it += NT) {
         const bool is_h = it < n_h;
         const int j = is_h ? it : it - n_h;
         const int q = j % Q, sg = j / Q;  // consecutive threads -> adjacent row quads: coalesced 16-byte loads
@@ -214,10 +227,14 @@ __device__ void gru_rows(const float* __restrict__ wiT, const float* __restrict_
     __syncthreads();
 }
 
+__device__ void gru_gates(int K, float* h, int H, PredLds& L, int tid, int nsplit, int half);
 __device__ void gru_layer(const float* __restrict__ wiT, const float* __restrict__ whT,
                           const float* __restrict__ bi, const float* __restrict__ bh,
                           const float* x, int K, float* h, int H, PredLds& L, int tid, int nsplit = 1, int half = 0) {
     gru_rows(wiT, whT, bi, bh, x, K, h, H, L, tid, nsplit, half);
+    gru_gates(K, h, H, L, tid, nsplit, half);
+}
+__device__ void gru_gates(int K, float* h, int H, PredLds& L, int tid, int nsplit, int half) {
     const int Si = segments(K), Sh = segments(H);
     const int Hh = H / nsplit;
     for (int ii = tid; ii < Hh; ii += NT) {  // torch.nn.GRU gate rows [r; z; n]
@@ -235,6 +252,8 @@ __device__ void gru_layer(const float* __restrict__ wiT, const float* __restrict
 // one frame of Wavernn.forward: L.x -> L.fo, states in L.h1/L.h2
 __device__ void pred_step(const PredDev& P, PredLds& L, int tid, SplitCtx* X = nullptr) {
     if (X && X->n > 1) {  // this workgroup's slice of the units of each GRU, then the slices change hands
+        // (GRU2's recurrent product under the first exchange -- two passes of 96 + 288 work items instead of one of 384 on
+        //  576 threads -- was measured 5 % slower: the passes stay whole)
         gru_layer(P.w1i, P.w1h, P.b1i, P.b1h, L.x, P.in, L.h1, P.h1, L, tid, X->n, X->half);
         exchange_halves(L.h1, P.h1, *X, X->g1, tid);
         gru_layer(P.w2i, P.w2h, P.b2i, P.b2h, L.h1, P.h1, L.h2, P.h2, L, tid, X->n, X->half);
