@@ -666,3 +666,36 @@ def test_predictor_row_split_equals_single_workgroup_form(torch_cuda, model, syn
             assert not any(np.isnan(a).any() for a in out[mode] if a.dtype.kind == "f")  # no spin gave up
             for a, b in zip(out["0"], out[mode]):
                 assert np.array_equal(a, b), (B, L, mode)
+
+
+def test_predictor_row_split_under_uneven_load(torch_cuda, model, vocoder, synth, oracle, cb_paths):
+    """the row-split exchange with the chip busy and the workgroups of a group NOT starting together: a 256-workgroup
+    vocoder launch (one per CU, too much LDS to share a CU) is queued on a side stream right before the split encoder,
+    so the encoder's workgroups trickle onto CUs as the decoder's finish and spin for partners that are dispatched
+    later; repeated with the launch order swapped.  Every output must equal the quiet run's (and no spin may give up)."""
+    torch = torch_cuda
+    voc, w = vocoder
+    cfg = dict(scl_cb_path=cb_paths["scl_hi"], cb_path=cb_paths["vq_hi"], bl_scl_cb_path=cb_paths["scl_lo"],
+               bl_cb_path=cb_paths["vq_lo"])
+    B, L = 128, 40
+    feat = torch.from_numpy(np.tile(synth.predictor_features(8, L, utt0=1700), (B // 8, 1, 1)).copy()).cuda()
+    quiet = model.encoder(cfg, feat, None, 0.09, 0.28, qtz=True, return_indices=True)
+    torch.cuda.synchronize()
+    vf = torch.from_numpy(np.tile(_voc_features(synth, oracle, 4, 10), (64, 1, 1)).copy()).cuda()
+    sd = torch.from_numpy(synth.seeds(256).astype(np.int64)).cuda()
+    pcm = torch.empty(256, 1600, dtype=torch.int16, device="cuda")
+    side = torch.cuda.Stream()
+    for order in (0, 1):
+        if order == 0:
+            with torch.cuda.stream(side):
+                voc.synthesize(vf, sd, out=pcm)
+            busy = model.encoder(cfg, feat, None, 0.09, 0.28, qtz=True, return_indices=True)
+        else:
+            busy = model.encoder(cfg, feat, None, 0.09, 0.28, qtz=True, return_indices=True)
+            with torch.cuda.stream(side):
+                voc.synthesize(vf, sd, out=pcm)
+        torch.cuda.synchronize()
+        for a, b in zip(quiet[:6] + (quiet[7],), busy[:6] + (busy[7],)):
+            assert torch.equal(a, b), order
+        for a, b in zip(quiet[6], busy[6]):
+            assert np.array_equal(a, b)
