@@ -212,6 +212,23 @@ def test_lpcnet_too_dense_is_refused(torch_cuda, synth):
     from fpcodec_amd.lpcnet import LPCNet
     with pytest.raises(FpcError, match="too dense"):
         LPCNet(synth.lpcnet_weights(density=(0.3, 0.3, 0.5)))
+    # the same refusal at the end of the `[Saved_Model]` route: Keras-named weights -> tools/h5_to_npz mapping -> .npz -> load
+    import importlib.util
+    import tempfile
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("h5_to_npz", os.path.join(root, "tools", "h5_to_npz.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    for density, ok in (((0.05, 0.05, 0.2), True), ((0.3, 0.3, 0.5), False)):
+        w = synth.lpcnet_weights(density=density)
+        named = {f"model_weights/{layer}/{layer}/{weight}:0": w[key] for key, layer, weight, shape in m.MAPPING}
+        path = os.path.join(tempfile.mkdtemp(), "m.npz")
+        np.savez(path, **m.from_keras_named(named))
+        if ok:
+            assert LPCNet.load(path).kernel_variant() == 408
+        else:
+            with pytest.raises(FpcError, match="too dense"):
+                LPCNet.load(path)
 
 
 def test_lpcnet_config2_single_stream_3s(torch_cuda, vocoder, synth, oracle):
