@@ -41,6 +41,8 @@ struct SplitCtx {
     int n = 1, half = 0;            // workgroups per utterance, this workgroup's slice
     unsigned long long* g1 = nullptr;  // [H1] granules of the new GRU1 state of this utterance
     unsigned long long* g2 = nullptr;  // [H2]
+    unsigned long long* g3 = nullptr;  // [H1], g4: [H2]: second set (the training backward has ONE hop per frame and
+    unsigned long long* g4 = nullptr;  // alternates between the sets, so a set is rewritten only two hops later)
     unsigned* err = nullptr;        // set on spin timeout
     unsigned epoch = 0;             // last epoch used
     bool dead = false;              // a spin gave up: no further waiting in this workgroup
@@ -50,9 +52,11 @@ __device__ __forceinline__ void store_granule(unsigned long long* g, unsigned ep
                        __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 // publish this workgroup's slice of h[0..H) (h in LDS) under a new epoch ...
-__device__ __forceinline__ void publish_slice(const float* h, int H, SplitCtx& X, unsigned long long* g, int tid) {
+__device__ __forceinline__ void publish_slice(const float* h, int H, SplitCtx& X, unsigned long long* g, int tid,
+                                              bool new_epoch = true) {
     const int Hs = H / X.n, mine = X.half * Hs;
-    const unsigned epoch = ++X.epoch;
+    if (new_epoch) ++X.epoch;  // (false: a second array handed over in the same hop)
+    const unsigned epoch = X.epoch;
     for (int i = tid; i < Hs; i += NT) store_granule(&g[mine + i], epoch, h[mine + i]);
 }
 // ... and pick every other slice of that epoch up (ends with a barrier); independent work may sit between the two
@@ -690,7 +694,7 @@ __device__ void scl_search(PredLds& L, float xv, const double* __restrict__ code
 // ---------------------------------------------------------------------------------
 struct SplitArgs {
     int n;                    // workgroups per utterance (1, 2, 4 or 8)
-    unsigned long long* g;    // [B][h1 + h2] exchange granules, zeroed before the launch (n > 1)
+    unsigned long long* g;    // [B][2][h1 + h2] exchange granules, zeroed before the launch (n > 1)
     unsigned* err;            // spin-timeout flag
 };
 __device__ __forceinline__ SplitCtx split_ctx(const SplitArgs& S, const PredDev& P, int b, int half) {
@@ -698,8 +702,10 @@ __device__ __forceinline__ SplitCtx split_ctx(const SplitArgs& S, const PredDev&
     X.n = S.n;
     X.half = half;
     if (S.n > 1) {
-        X.g1 = S.g + (size_t)b * (P.h1 + P.h2);
+        X.g1 = S.g + (size_t)b * 2 * (P.h1 + P.h2);
         X.g2 = X.g1 + P.h1;
+        X.g3 = X.g2 + P.h2;
+        X.g4 = X.g3 + P.h1;
         X.err = S.err;
     }
     return X;
@@ -936,9 +942,11 @@ struct TrainBufs {              // per sample n = b*L + t
 };
 
 __device__ void gates_save(const float* h_prev_lds, float* h_lds, int K, int H, PredLds& L, size_t n, float* r_, float* z_,
-                           float* n_, float* hn_, float* hout, int tid) {
+                           float* n_, float* hn_, float* hout, int tid, int nsplit = 1, int half = 0) {
     const int Si = segments(K), Sh = segments(H);
-    for (int i = tid; i < H; i += NT) {
+    const int Hs = H / nsplit;
+    for (int ii = tid; ii < Hs; ii += NT) {
+        const int i = half * Hs + ii;
         const float gir = seg_tree(L.pi, Si, i), giz = seg_tree(L.pi, Si, H + i), gin = seg_tree(L.pi, Si, 2 * H + i);
         const float ghr = seg_tree(L.ph, Sh, i), ghz = seg_tree(L.ph, Sh, H + i), ghn = seg_tree(L.ph, Sh, 2 * H + i);
         const float r = fpc_sigmoidf(gir + ghr);
@@ -956,26 +964,32 @@ __device__ void gates_save(const float* h_prev_lds, float* h_lds, int K, int H, 
 }
 
 __global__ __launch_bounds__(NT) void k_train_fwd(const PredDev P, const float* __restrict__ feat, int Lf,
-                                                  const TrainBufs T) {
+                                                  const TrainBufs T, const SplitArgs S) {
     __shared__ PredLds L;
-    const int b = blockIdx.x, tid = threadIdx.x;
+    const int b = blockIdx.x / S.n, half = blockIdx.x % S.n, tid = threadIdx.x;
+    SplitCtx X = split_ctx(S, P, b, half);
+    const bool writer = half == 0;  // kept activations: every slice stores its own units, the rest by slice 0
     for (int i = tid; i < P.h1; i += NT) L.h1[i] = 0.0f;
     for (int i = tid; i < P.h2; i += NT) L.h2[i] = 0.0f;
     __syncthreads();
     for (int t = 0; t < Lf; ++t) {
         const size_t n = (size_t)b * Lf + t;
         if (tid < P.in) L.x[tid] = feat[n * P.in + tid];
-        for (int i = tid; i < P.h1; i += NT) T.h1p[n * P.h1 + i] = L.h1[i];
-        for (int i = tid; i < P.h2; i += NT) T.h2p[n * P.h2 + i] = L.h2[i];
+        if (writer) {
+            for (int i = tid; i < P.h1; i += NT) T.h1p[n * P.h1 + i] = L.h1[i];
+            for (int i = tid; i < P.h2; i += NT) T.h2p[n * P.h2 + i] = L.h2[i];
+        }
         __syncthreads();
-        gru_rows(P.w1i, P.w1h, P.b1i, P.b1h, L.x, P.in, L.h1, P.h1, L, tid);
-        gates_save(L.h1, L.h1, P.in, P.h1, L, n, T.r1, T.z1, T.n1, T.hn1, T.h1, tid);
-        gru_rows(P.w2i, P.w2h, P.b2i, P.b2h, L.h1, P.h1, L.h2, P.h2, L, tid);
-        gates_save(L.h2, L.h2, P.h1, P.h2, L, n, T.r2, T.z2, T.n2, T.hn2, T.h2, tid);
+        gru_rows(P.w1i, P.w1h, P.b1i, P.b1h, L.x, P.in, L.h1, P.h1, L, tid, X.n, X.half);
+        gates_save(L.h1, L.h1, P.in, P.h1, L, n, T.r1, T.z1, T.n1, T.hn1, T.h1, tid, X.n, X.half);
+        if (X.n > 1) exchange_halves(L.h1, P.h1, X, X.g1, tid);
+        gru_rows(P.w2i, P.w2h, P.b2i, P.b2h, L.h1, P.h1, L.h2, P.h2, L, tid, X.n, X.half);
+        gates_save(L.h2, L.h2, P.h1, P.h2, L, n, T.r2, T.z2, T.n2, T.hn2, T.h2, tid, X.n, X.half);
+        if (X.n > 1) exchange_halves(L.h2, P.h2, X, X.g2, tid);
         for (int i = tid; i < P.h2; i += NT) {
             const float v = L.h2[i] > 0.0f ? L.h2[i] : 0.0f;
             L.relu[i] = v;
-            T.relu[n * P.h2 + i] = v;
+            if (writer) T.relu[n * P.h2 + i] = v;
         }
         __syncthreads();
         const int Sf = (P.h2 % 8 == 0 && P.h2 >= 64) ? 8 : 1, lenf = P.h2 / Sf;
@@ -989,7 +1003,7 @@ __global__ __launch_bounds__(NT) void k_train_fwd(const PredDev P, const float* 
             if (Sf == 8)
                 acc = ((L.pf[0][tid] + L.pf[1][tid]) + (L.pf[2][tid] + L.pf[3][tid])) +
                       ((L.pf[4][tid] + L.pf[5][tid]) + (L.pf[6][tid] + L.pf[7][tid]));
-            T.th[n * P.fc + tid] = fpc_tanhf(acc);
+            if (writer) T.th[n * P.fc + tid] = fpc_tanhf(acc);
         }
         __syncthreads();
     }
@@ -1040,9 +1054,10 @@ struct BwdW {
 // all (4 adjacent k, row segment) work items of one transposed product: part[sg][k] = chain over the rows
 // of segment sg of W[r][k] d[r] from 0
 __device__ __forceinline__ void tprod_items(const float* __restrict__ W, const float* d, int rows, int cols,
-                                            float (*part)[MAX_H1], int item, int tid_unused) {
-    const int Q = cols / 4, S = segments(rows), len = rows / S;
-    const int q = item % Q, sg = item / Q;
+                                            float (*part)[MAX_H1], int item, int nsplit, int half) {
+    // (row split: this workgroup's slice of the output columns k; every chain is the one of the unsplit form)
+    const int Qs = cols / 4 / nsplit, S = segments(rows), len = rows / S;
+    const int q = half * Qs + item % Qs, sg = item / Qs;
     float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
     chain4(W + (size_t)sg * len * cols, d + sg * len, len, cols, 4 * q, a);
     *reinterpret_cast<float4*>(&part[sg][4 * q]) = a;
@@ -1070,9 +1085,13 @@ __device__ __forceinline__ void gate_grads(float dh, float r, float z, float nn,
 
 // back-propagation through time of one utterance; the transposed products W^T d run on torch-layout copies
 // of the matrices as coalesced, row-segmented chains
-__global__ __launch_bounds__(NT) void k_train_bwd(const PredDev P, const BwdW W, int Lf, const TrainBufs T) {
+__global__ __launch_bounds__(NT) void k_train_bwd(const PredDev P, const BwdW W, int Lf, const TrainBufs T,
+                                                  const SplitArgs Sp) {
     __shared__ BwdLds S;
-    const int b = blockIdx.x, tid = threadIdx.x;
+    const int b = blockIdx.x / Sp.n, half = blockIdx.x % Sp.n, tid = threadIdx.x;
+    SplitCtx X = split_ctx(Sp, P, b, half);
+    const bool writer = half == 0;
+    const int ns = X.n;  // row split: each workgroup owns a slice of the columns k of the three transposed products
     const int H1 = P.h1, H2 = P.h2, F = P.fc;
     for (int i = tid; i < H1; i += NT) S.dh1n[i] = 0.0f;
     for (int i = tid; i < H2; i += NT) S.dh2n[i] = 0.0f;
@@ -1090,44 +1109,61 @@ __global__ __launch_bounds__(NT) void k_train_bwd(const PredDev P, const BwdW W,
                        S.g2i, S.g2h, H2, i);
         }
         __syncthreads();
-        for (int i = tid; i < 3 * H2; i += NT) {
-            T.dgi2[n * 3 * H2 + i] = S.g2i[i];
-            T.dgh2[n * 3 * H2 + i] = S.g2h[i];
-        }
+        if (writer)
+            for (int i = tid; i < 3 * H2; i += NT) {
+                T.dgi2[n * 3 * H2 + i] = S.g2i[i];
+                T.dgh2[n * 3 * H2 + i] = S.g2h[i];
+            }
         {  // W_ih2^T dgi2 -> dh1 (part), W_hh2^T dgh2 -> dh2 of frame t-1: (4 adjacent k, row segment) items
-            const int S2 = segments(3 * H2), na = (H1 / 4) * S2, nb = (H2 / 4) * S2;
+            const int S2 = segments(3 * H2), na = (H1 / 4 / ns) * S2, nb = (H2 / 4 / ns) * S2;
             for (int it = tid; it < na + nb; it += NT) {
                 if (it < na)
-                    tprod_items(W.w2i, S.g2i, 3 * H2, H1, S.pa, it, tid);
+                    tprod_items(W.w2i, S.g2i, 3 * H2, H1, S.pa, it, ns, half);
                 else
-                    tprod_items(W.w2h, S.g2h, 3 * H2, H2, S.pb, it - na, tid);
+                    tprod_items(W.w2h, S.g2h, 3 * H2, H2, S.pb, it - na, ns, half);
             }
             __syncthreads();
-            for (int w = tid; w < H1 + H2; w += NT) {
-                if (w < H1)
+            const int H1s = H1 / ns, H2s = H2 / ns;
+            for (int ww = tid; ww < H1s + H2s; ww += NT) {
+                if (ww < H1s) {
+                    const int w = half * H1s + ww;
                     S.dh1[w] = tree4(S.pa, S2, w) + S.dh1n[w];
-                else {
-                    const int k = w - H1;
+                } else {
+                    const int k = half * H2s + (ww - H1s);
                     S.dh2n[k] = fmaf(S.dh2[k], T.z2[n * H2 + k], tree4(S.pb, S2, k));
                 }
             }
         }
         __syncthreads();
+        if (ns > 1) {
+            // both vectors change hands in ONE hop per frame, through the granule set of the frame's parity: a set is
+            // rewritten two hops later, after the partners' intervening publish proves they have read it
+            unsigned long long* ga = (t & 1) ? X.g3 : X.g1;
+            unsigned long long* gb = (t & 1) ? X.g4 : X.g2;
+            publish_slice(S.dh1, H1, X, ga, tid);
+            publish_slice(S.dh2n, H2, X, gb, tid, false);
+            consume_slices(S.dh1, H1, X, ga, tid);
+            consume_slices(S.dh2n, H2, X, gb, tid);
+        }
         for (int i = tid; i < H1; i += NT)
             gate_grads(S.dh1[i], T.r1[n * H1 + i], T.z1[n * H1 + i], T.n1[n * H1 + i], T.hn1[n * H1 + i],
                        T.h1p[n * H1 + i], S.g1i, S.g1h, H1, i);
         __syncthreads();
-        for (int i = tid; i < 3 * H1; i += NT) {
-            T.dgi1[n * 3 * H1 + i] = S.g1i[i];
-            T.dgh1[n * 3 * H1 + i] = S.g1h[i];
-        }
+        if (writer)
+            for (int i = tid; i < 3 * H1; i += NT) {
+                T.dgi1[n * 3 * H1 + i] = S.g1i[i];
+                T.dgh1[n * 3 * H1 + i] = S.g1h[i];
+            }
         {
-            const int S1 = segments(3 * H1), n1 = (H1 / 4) * S1;
-            for (int it = tid; it < n1; it += NT) tprod_items(W.w1h, S.g1h, 3 * H1, H1, S.pa, it, tid);
+            const int S1 = segments(3 * H1), n1 = (H1 / 4 / ns) * S1, H1s = H1 / ns;
+            for (int it = tid; it < n1; it += NT) tprod_items(W.w1h, S.g1h, 3 * H1, H1, S.pa, it, ns, half);
             __syncthreads();
-            for (int k = tid; k < H1; k += NT) S.dh1n[k] = fmaf(S.dh1[k], T.z1[n * H1 + k], tree4(S.pa, S1, k));
+            for (int kk = tid; kk < H1s; kk += NT) {
+                const int k = half * H1s + kk;
+                S.dh1n[k] = fmaf(S.dh1[k], T.z1[n * H1 + k], tree4(S.pa, S1, k));
+            }
         }
-        __syncthreads();
+        __syncthreads();  // (dh1n is only ever read at this workgroup's own columns: it stays local)
     }
 }
 
@@ -1251,7 +1287,7 @@ struct fpc_predictor {
     PredDev d;
     fpc::DevBuf buf[10];
     fpc::DevBuf flag;  // one int: "a symbol lay outside its codebook" (fpc_decode_features), allocated once per handle
-    fpc::DevBuf xg;    // row-split exchange granules [B][h1 + h2] x 8 bytes + the timeout word, grown on demand
+    fpc::DevBuf xg;    // row-split exchange granules [B][2][h1 + h2] x 8 bytes + the timeout word, grown on demand
     int num_cus = 0;
     int refs = 1;  // the creator's handle + one per live fpc_trainer built on it (fpc_predictor_destroy only drops a reference)
 };
@@ -1273,7 +1309,7 @@ static int split_args(fpc_predictor* p, int B, hipStream_t st, SplitArgs* out) {
             n = f;  // (forced: at most two workgroups per CU, still all resident)
     }
     if (n == 1) return FPC_OK;
-    const size_t gran = (size_t)B * (p->d.h1 + p->d.h2) * sizeof(unsigned long long);
+    const size_t gran = (size_t)B * 2 * (p->d.h1 + p->d.h2) * sizeof(unsigned long long);
     const size_t bytes = ((gran + 15) / 16) * 16 + 16;  // granules, then the timeout word (own 16-byte slot)
     if (p->xg.bytes < bytes) {
         if (p->xg.p) {
@@ -1564,12 +1600,21 @@ extern "C" int fpc_trainer_step(fpc_trainer* t, const float* feat_dev, int B, in
         refresh();
         t->step = 0;
     }
-    hipLaunchKernelGGL(k_train_fwd, dim3(B), dim3(NT), 0, st, P, feat_dev, L, T);
+    SplitArgs sp;  // forward and backward each run an utterance on 2-8 workgroups while the batch leaves CUs idle
+    {
+        const int rc = split_args(p, B, st, &sp);
+        if (rc != FPC_OK) return rc;
+    }
+    hipLaunchKernelGGL(k_train_fwd, dim3(B * sp.n), dim3(NT), 0, st, P, feat_dev, L, T, sp);
     const double cnt = (double)B * (L - 1) * F;
     hipLaunchKernelGGL(k_train_loss, dim3(B), dim3(256), sizeof(float) * (size_t)L * F, st, feat_dev, in, F, L,
                        (float)(2.0 / cnt), T);
     const BwdW bw{t->wt[0].as<float>(), t->wt[1].as<float>(), t->wt[2].as<float>()};
-    hipLaunchKernelGGL(k_train_bwd, dim3(B), dim3(NT), 0, st, P, bw, L, T);
+    {
+        const int rc = split_args(p, B, st, &sp);  // fresh granules (zeroed behind the forward launch on the stream)
+        if (rc != FPC_OK) return rc;
+    }
+    hipLaunchKernelGGL(k_train_bwd, dim3(B * sp.n), dim3(NT), 0, st, P, bw, L, T, sp);
     struct G {
         const float* A;
         int K;
