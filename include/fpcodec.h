@@ -69,7 +69,16 @@ typedef struct {
 typedef struct fpc_predictor fpc_predictor;
 
 FPC_API int fpc_predictor_create(const fpc_predictor_weights* w, fpc_predictor** out);
+/* drops the caller's reference; a live fpc_trainer built on the handle keeps the device weights alive */
 FPC_API void fpc_predictor_destroy(fpc_predictor* p);
+
+/* Row split (round 2): fpc_predictor_forward, fpc_encode, fpc_decode_features and fpc_trainer_step run one utterance
+ * on 2, 4 or 8 workgroups (one CU each) while the batch leaves CUs idle (B x n <= number of CUs); the slices of the
+ * recurrent state change hands through a block of tagged 8-byte words that belongs to the predictor handle and is
+ * cleared on the stream before each launch.  Results are bit-identical to the one-workgroup form.  Consequences for the
+ * caller: do not run launches of ONE handle on two streams at the same time; a launch whose workgroups cannot all
+ * become resident within ~1 s of each other gives up and fills its outputs with NaN instead of hanging.
+ * Environment: FPC_PRED_SPLIT=0 keeps one workgroup per utterance, 2|4|8 fixes the count. */
 
 /* Wavernn.forward (wavernn.py:63-102): x [B,L,in] -> y [B,L,fc]; h1 [B,H1],
  * h2 [B,H2] are read as initial state and overwritten with the final state.
