@@ -33,9 +33,6 @@ constexpr int NMW = NMAT / 64;
 // stride between the partial-sum planes of consecutive lanes q of a row group: +4 floats so that the
 // lanes of one group (consecutive lanes of a wave) start their 16-byte stores in different bank groups
 constexpr int PSTRIDE = GA + 4;
-#ifndef FPC_X_RP
-#define FPC_X_RP 4  // (timing experiments only: < 4 drops part of the sparse product)
-#endif
 #ifndef FPC_PRIO
 #define FPC_PRIO 3  // priority of the mat-vec waves while they gather and gate (the sampler waves drop to 0 there)
 #endif
@@ -66,8 +63,7 @@ struct DecodeParams {
     const float* brn_a;      // [384]
     const float* brn_b;      // [16]
     const float* ulaw_tab;   // [256]
-    unsigned long long* stamps;  // diagnostic only
-    int dbg_const_rows;          // diagnostic only (STAMP build): gather fixed table rows
+    unsigned* stamps;  // diagnostic only: [FPC_STAMP_NS][12 waves][8 slots]
 };
 
 __device__ const float k_ulaw_thr[64] = FPC_ULAW_TABLE_INIT;
@@ -153,12 +149,8 @@ __device__ __forceinline__ unsigned opaque(unsigned v) {
 __device__ __forceinline__ float lut_scaled(const float2* T2, float x, float scale) {
     const float u = fminf(fabsf(x) * scale, 4095.99976f);
     const float f = __builtin_amdgcn_fractf(u);
-#ifdef FPC_ABL_LUT  // timing-only experiment (wrong output): activation without the table read
-    return copysignf(fmaf(f, 0.001f, u * 0.0001f), x);
-#else
     const float2 td = T2[(uint32_t)u];
     return copysignf(fmaf(f, td.y, td.x), x);
-#endif
 }
 __device__ __forceinline__ float lut_tanh(const float2* T2, float x) { return lut_scaled(T2, x, 512.0f); }
 __device__ __forceinline__ float lut_sigmoid(const float2* T2, float x) {
@@ -177,32 +169,27 @@ __device__ __forceinline__ float part_tree(const float* p0) {
         for (int k = 0; k < w / 2; ++k) v[k] = v[2 * k] + v[2 * k + 1];
     return v[0];
 }
-// STAMP=true is a diagnostic build (env FPC_DECODE_STAMPS=1): lane 0 of every wave w of block 0
-// (slots 16w..16w+9) accumulates s_memtime deltas: slot 2k = work before barrier k,
-// slot 2k+1 = wait at barrier k (k: 0 Y, 1 Z1, 2 Z2, 3 Z3, 4 X); perturbs the timing, never timed.
-#define FPC_STAMP(k)                                                  \
-    if (STAMP) {                                                      \
-        const unsigned long long now_ = __builtin_readcyclecounter(); \
-        st_acc[k] += now_ - st_last;                                  \
-        st_last = now_;                                               \
+// STAMP=true is a diagnostic build (env FPC_DECODE_STAMPS=1): for samples FPC_STAMP_T0 .. +FPC_STAMP_NS of block 0,
+// lane 0 of every wave stores raw s_memtime values: slot k = arrival at barrier k (0 Y, 1 Z1, 2 Z2, 3 Z3, 4 X; the
+// release is taken as the last wave's arrival).  No registers are held between stamps; perturbs the timing a little
+// (each stamp waits for the wave's LDS operations), never timed.
+#define FPC_STAMP_T0 400
+#define FPC_STAMP_NS 64
+#define FPC_STAMP(k)                                                                                       \
+    if (STAMP && stamp_on) {                                                                               \
+        const unsigned now_ = (unsigned)__builtin_readcyclecounter();                                      \
+        if (lane == 0) P.stamps[((st_t - FPC_STAMP_T0) * (NTHREADS / 64) + wave) * 8 + (k)] = now_;        \
     }
-#ifdef FPC_ABL_BARE_BARRIER  // timing-only experiment (NOT a valid program: LDS writes are not waited for)
-#define FPC_SYNC() asm volatile("s_barrier" ::: "memory")
-#else
 #define FPC_SYNC() __syncthreads()
-#endif
-#define FPC_BARRIER(k)   \
-    FPC_STAMP(2 * (k))   \
-    FPC_SYNC();          \
-    FPC_STAMP(2 * (k) + 1)
+#define FPC_BARRIER(k) \
+    FPC_STAMP(k)       \
+    FPC_SYNC();
 
 // QZR / QN: partial-sum planes read per update/reset-gate row and per candidate-gate row (powers of two
 // >= the widest row group of those gates; planes no lane owns hold +0)
 template <bool STAMP, int QZR, int QN>
 __global__ __launch_bounds__(NTHREADS) void k_decode(const DecodeParams P) {
     __shared__ DecodeLds L;
-    unsigned long long st_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    unsigned long long st_last = STAMP ? __builtin_readcyclecounter() : 0;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int b = blockIdx.x, T = P.T;
 
@@ -224,9 +211,6 @@ __global__ __launch_bounds__(NTHREADS) void k_decode(const DecodeParams P) {
         L.s2[tid] = 0.0f;
         L.hist[tid] = 0.0f;
     }
-#ifdef FPC_ABL_WINDOW  // timing-only experiment (wrong output): no per-sample window work; records stay valid constants
-    if (tid < 256) L.cand[tid] = make_float4(0.0f, 0.0f, __uint_as_float(128u * GA), __uint_as_float(384u * GA));
-#endif
     if (tid == 0) {
         L.o_sig = 128u * GA;
         L.o_pred = (256u + 128u) * GA;
@@ -274,6 +258,8 @@ __global__ __launch_bounds__(NTHREADS) void k_decode(const DecodeParams P) {
                 L.cfa[2 * RNN_A + ml_] = cfa[2 * RNN_A + ml_];
             }
             for (int i = (fr == 0 ? FPC_LPC_ORDER + 1 : 0); i < FPC_FRAME_SIZE; ++i) {
+                const int st_t = fr * FPC_FRAME_SIZE + i;
+                const bool stamp_on = STAMP && blockIdx.x == 0 && st_t >= FPC_STAMP_T0 && st_t < FPC_STAMP_T0 + FPC_STAMP_NS;
                 // ---- X..Y: gather the three embedding-table rows, GRU_A gates ----
 #if FPC_PRIO
                 __builtin_amdgcn_s_setprio(FPC_PRIO);  // the gates are on the sample-to-sample critical path
@@ -284,22 +270,11 @@ __global__ __launch_bounds__(NTHREADS) void k_decode(const DecodeParams P) {
                         float x, y, z;
                     };
                     unsigned oa = L.o_sig, ob = L.o_pred, oc = L.o_exc;
-                    if (STAMP && P.dbg_const_rows) {  // timing experiment (wrong output)
-                        oa = 128u * GA;
-                        ob = 384u * GA;
-                        oc = 640u * GA;
-                    }
                     // uniform base + 32-bit byte offset (the global_load saddr form: no 64-bit VALU address math)
                     const char* tabc = reinterpret_cast<const char*>(P.tab);
-#ifdef FPC_ABL_GATHER  // timing-only experiment (wrong output): no embedding-row gather
-                    (void)tabc;
-                    const F3 ta = {__uint_as_float(oa) * 1e-30f, 0.0f, 0.0f}, tb = {__uint_as_float(ob) * 1e-30f, 0.0f, 0.0f},
-                             tc = {__uint_as_float(oc) * 1e-30f, 0.0f, 0.0f};
-#else
                     const F3 ta = *reinterpret_cast<const F3*>(tabc + (size_t)((oa + 3u * ml) * 4u));
                     const F3 tb = *reinterpret_cast<const F3*>(tabc + (size_t)((ob + 3u * ml) * 4u));
                     const F3 tc = *reinterpret_cast<const F3*>(tabc + (size_t)((oc + 3u * ml) * 4u));
-#endif
                     // while the gather is in flight: recurrent terms of the three rows of unit ml =
                     // diagonal + tree over the row group's partial sums (written before barrier X)
                     const float h_own = L.s1[ml];
@@ -322,9 +297,6 @@ __global__ __launch_bounds__(NTHREADS) void k_decode(const DecodeParams P) {
                 __builtin_amdgcn_s_setprio(0);
 #endif
                 FPC_BARRIER(0)  // Y
-#ifdef FPC_SLEEP_Y
-                __builtin_amdgcn_s_sleep(FPC_SLEEP_Y);  // let the sampler waves' reads of s1' reach the LDS first
-#endif
                 // ---- the sparse product of s1' with this lane's 4 blocks (16 columns of 8 rows), sliced under
                 //      the sampler phases: FPC_NA columns under GRU_B, FPC_NB under the dual FC, the rest and the
                 //      store of the partial sums under the draw ----
@@ -348,7 +320,7 @@ __global__ __launch_bounds__(NTHREADS) void k_decode(const DecodeParams P) {
             hv1[0] = hc.x, hv1[1] = hc.y, hv1[2] = hc.z, hv1[3] = hc.w;                                           \
             hv1[4] = hd.x, hv1[5] = hd.y, hv1[6] = hd.z, hv1[7] = hd.w;                                           \
         }                                                                                                         \
-        _Pragma("unroll") for (int rp = 0; rp < FPC_X_RP; ++rp) {                                                 \
+        _Pragma("unroll") for (int rp = 0; rp < 4; ++rp) {                                                 \
             if (bc < 8)                                                                                           \
                 acc[rp] = fma2(w2[bc * 4 + rp], splat2(hv0[bc]), acc[rp]);                                        \
             else                                                                                                  \
@@ -383,8 +355,6 @@ __global__ __launch_bounds__(NTHREADS) void k_decode(const DecodeParams P) {
                 FPC_BARRIER(4)  // X
             }
         }
-        if (STAMP && blockIdx.x == 0 && lane == 0)
-            for (int k = 0; k < 10; ++k) P.stamps[16 * wave + k] = st_acc[k];
     } else {
         // =========================== sampler role ===========================
         __builtin_amdgcn_s_setprio(3);  // the sample-to-sample critical path lives in these waves
@@ -429,20 +399,17 @@ __global__ __launch_bounds__(NTHREADS) void k_decode(const DecodeParams P) {
 
             for (int i = (fr == 0 ? FPC_LPC_ORDER + 1 : 0); i < FPC_FRAME_SIZE; ++i) {
                 const int t = fr * FPC_FRAME_SIZE + i;
+                const int st_t = t;
+                const bool stamp_on = STAMP && blockIdx.x == 0 && st_t >= FPC_STAMP_T0 && st_t < FPC_STAMP_T0 + FPC_STAMP_NS;
 #if FPC_PRIO
                 __builtin_amdgcn_s_setprio(0);  // window work has slack; the gate waves do not
 #endif
                 // ---- X..Y (the mat-vec waves gather + gate): everything that only needs the
                 //      previous draw: GRU_B recurrent part, LPC history chain, leaf candidates ----
-#ifdef FPC_ABL_WINDOW
-                float ub_z = ub0, ub_r = ub1, ub_n = ub2;
-                if (false) {
-#else
                 const float s2k = L.s2[kl];
                 float ub_z = ub0 * s2k, ub_r = ub1 * s2k, ub_n = ub2 * s2k;
                 row_bfly16x3(ub_z, ub_r, ub_n);
                 {
-#endif
                     // prediction of the NEXT sample: taps 2..16 as a balanced tree over the 16 lanes of
                     // the row (lane kl holds tap kl+1, lane 0 contributes 0), the newest tap by one fma
                     const bool lastsmp = i == FPC_FRAME_SIZE - 1;  // next sample belongs to the next frame
@@ -610,8 +577,6 @@ __global__ __launch_bounds__(NTHREADS) void k_decode(const DecodeParams P) {
 #endif
             }
         }
-        if (STAMP && blockIdx.x == 0 && lane == 0)
-            for (int k = 0; k < 10; ++k) P.stamps[16 * wave + k] = st_acc[k];
     }
 }
 #undef FPC_BARRIER
