@@ -10,7 +10,8 @@ _lib = None
 
 SYMBOLS = [
     "fpc_last_error", "fpc_abi_version", "fpc_device_count",
-    "fpc_predictor_create", "fpc_predictor_destroy", "fpc_predictor_forward",
+    "fpc_predictor_create", "fpc_predictor_destroy", "fpc_predictor_forward", "fpc_predictor_status",
+    "fpc_predictor_set_split",
     "fpc_codebooks_create", "fpc_codebooks_destroy", "fpc_codebooks_hist_size",
     "fpc_encode", "fpc_decode_features", "fpc_vq_quantize", "fpc_scl_quantize", "fpc_ceps2lpc",
     "fpc_lpcnet_create", "fpc_lpcnet_destroy", "fpc_lpcnet_workspace_bytes",
@@ -84,6 +85,8 @@ def lib():
         L.fpc_cb_mean0.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
         L.fpc_predictor_create.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
         L.fpc_predictor_destroy.argtypes = [C.c_void_p]
+        L.fpc_predictor_status.argtypes = [C.c_void_p]
+        L.fpc_predictor_set_split.argtypes = [C.c_void_p, C.c_int]
         L.fpc_predictor_forward.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p,
                                             C.c_void_p, C.c_void_p, C.c_void_p]
         L.fpc_codebooks_create.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int,

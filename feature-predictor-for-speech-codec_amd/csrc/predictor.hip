@@ -16,6 +16,7 @@
 // distances in float64 with numpy's pairwise association, so results match the CPU
 // oracle bit for bit and the reference's indices exactly.
 #include "fpc_common.h"
+#include <atomic>
 #include <memory>
 #include <cmath>
 
@@ -33,9 +34,13 @@ constexpr int NDIM = 17, SURV = 5;
 // are exchanged after each GRU as 8-byte {epoch, value} granules: one write-through (sc1) store per value, polled
 // by the partner with sc1 loads until the tag matches -- no fence, no flag (cdna_hip_programming.md G16, form R2).
 // The output layer, thresholds and searches run redundantly on both (same inputs, same code: same bits); half 0
-// writes the outputs.  Granules are zeroed before every launch, epochs count 1.. within it; a spin that does not
-// see its tag in ~2 s gives up and poisons the outputs (never hangs).  Placement-independent: nothing assumes
-// which CUs or XCDs the two workgroups land on, only that both get dispatched (in-order dispatch, grid <= CUs).
+// writes the outputs.  Granules are zeroed before every launch, epochs count 1.. within it.  A spin that does not
+// see its tag within FPC_SPIN_LIMIT (1 s of wall clock, s_memrealtime) gives up: it sets bit 0 of the handle's
+// STATUS WORD (host-mapped memory, sticky), every workgroup that notices stops waiting, the kernels store NaN / idx -2
+// from that frame on and skip the Adam update, and the host turns the word into FPC_ERR_TIMEOUT (at the next call on
+// the handle, at every call that synchronises anyway, and in fpc_predictor_status) -- a launch can fail, loudly, but
+// never hang.  Placement-independent: nothing assumes which CUs or XCDs the workgroups land on, only that all of a
+// group get dispatched (in-order dispatch, grid <= CUs: the process is assumed to own the GPU, fpcodec.h).
 typedef __attribute__((address_space(1))) unsigned long long gu64;
 struct SplitCtx {
     int n = 1, half = 0;            // workgroups per utterance, this workgroup's slice
@@ -43,10 +48,20 @@ struct SplitCtx {
     unsigned long long* g2 = nullptr;  // [H2]
     unsigned long long* g3 = nullptr;  // [H1], g4: [H2]: second set (the training backward has ONE hop per frame and
     unsigned long long* g4 = nullptr;  // alternates between the sets, so a set is rewritten only two hops later)
-    unsigned* err = nullptr;        // set on spin timeout
+    unsigned* err = nullptr;        // the handle's status word (host-mapped): bit 0 spin timeout, bit 1 non-finite residual
+    unsigned long long limit = 0;   // give-up bound of one spin in s_memrealtime ticks (100 MHz)
     unsigned epoch = 0;             // last epoch used
     bool dead = false;              // a spin gave up: no further waiting in this workgroup
+    bool withhold = false;          // test hook (FPC_TEST_WITHHOLD_PUBLISH=1): this workgroup never publishes
 };
+constexpr unsigned FPC_ST_TIMEOUT = 1u, FPC_ST_NONFINITE = 2u;
+typedef __attribute__((address_space(1))) unsigned gu32;
+__device__ __forceinline__ unsigned status_load(const unsigned* w) {
+    return __hip_atomic_load((gu32*)w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__device__ __forceinline__ void status_or(unsigned* w, unsigned bits) {
+    (void)__hip_atomic_fetch_or((gu32*)w, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
 __device__ __forceinline__ void store_granule(unsigned long long* g, unsigned epoch, float v) {
     __hip_atomic_store((gu64*)g, ((unsigned long long)epoch << 32) | (unsigned long long)__float_as_uint(v),
                        __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -57,6 +72,7 @@ __device__ __forceinline__ void publish_slice(const float* h, int H, SplitCtx& X
     const int Hs = H / X.n, mine = X.half * Hs;
     if (new_epoch) ++X.epoch;  // (false: a second array handed over in the same hop)
     const unsigned epoch = X.epoch;
+    if (X.withhold) return;    // (test hook: the partners' spins must time out)
     for (int i = tid; i < Hs; i += NT) store_granule(&g[mine + i], epoch, h[mine + i]);
 }
 // ... and pick every other slice of that epoch up (ends with a barrier); independent work may sit between the two
@@ -68,22 +84,24 @@ __device__ __forceinline__ void consume_slices(float* h, int H, SplitCtx& X, uns
         const int i = ii < mine ? ii : ii + Hs;
         unsigned long long x = 0x7fc00000ull;  // NaN unless the partner's value arrives: poisons everything downstream
         unsigned spins = 0;
+        unsigned long long t0 = 0;
         while (!X.dead) {
             const unsigned long long v = __hip_atomic_load((gu64*)&g[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if ((unsigned)(v >> 32) == epoch) {
                 x = v;
                 break;
             }
-            ++spins;
-            // the partner never came (~1 s), or another workgroup already gave up: stop waiting, here and from now on --
-            // the launch must end quickly and loudly, never hang the GPU
-            if (spins > (1u << 20) || ((spins & 1023u) == 0 &&
-                                       __hip_atomic_load((__attribute__((address_space(1))) unsigned*)X.err,
-                                                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)) {
-                __hip_atomic_store((__attribute__((address_space(1))) unsigned*)X.err, 1u, __ATOMIC_RELAXED,
-                                   __HIP_MEMORY_SCOPE_AGENT);
-                gave_up = true;
-                break;
+            // every 64 polls (~10-100 us): has the partner been missing for X.limit of wall clock, or has another
+            // workgroup already given up?  Then stop waiting, here and from now on -- the launch must end quickly
+            // and loudly, never hang the GPU
+            if ((++spins & 63u) == 0) {
+                const unsigned long long now = __builtin_amdgcn_s_memrealtime();
+                if (t0 == 0) t0 = now;
+                if (now - t0 > X.limit || (status_load(X.err) & FPC_ST_TIMEOUT) != 0u) {
+                    status_or(X.err, FPC_ST_TIMEOUT);
+                    gave_up = true;
+                    break;
+                }
             }
 #ifndef FPC_XCHG_NOSLEEP
             __builtin_amdgcn_s_sleep(1);
@@ -695,18 +713,25 @@ __device__ void scl_search(PredLds& L, float xv, const double* __restrict__ code
 struct SplitArgs {
     int n;                    // workgroups per utterance (1, 2, 4 or 8)
     unsigned long long* g;    // [B][2][h1 + h2] exchange granules, zeroed before the launch (n > 1)
-    unsigned* err;            // spin-timeout flag
+    unsigned* err;            // the handle's status word (host-mapped, sticky; always valid)
+    unsigned long long limit; // give-up bound of one spin, s_memrealtime ticks
+    int withhold;             // test hook: the last slice of utterance 0 never publishes
 };
 __device__ __forceinline__ SplitCtx split_ctx(const SplitArgs& S, const PredDev& P, int b, int half) {
     SplitCtx X;
     X.n = S.n;
     X.half = half;
+    X.err = S.err;
+    X.limit = S.limit;
+    X.withhold = S.withhold != 0 && b == 0 && half == S.n - 1 && S.n > 1;
+    // a handle whose status word is already set (an earlier launch failed and the host has not cleared it yet)
+    // does not wait for anybody: its outputs are poison anyway
+    X.dead = S.n > 1 && (status_load(S.err) & FPC_ST_TIMEOUT) != 0u;
     if (S.n > 1) {
         X.g1 = S.g + (size_t)b * 2 * (P.h1 + P.h2);
         X.g2 = X.g1 + P.h1;
         X.g3 = X.g2 + P.h2;
         X.g4 = X.g3 + P.h1;
-        X.err = S.err;
     }
     return X;
 }
@@ -720,13 +745,24 @@ __global__ __launch_bounds__(NT) void k_forward(const PredDev P, const float* __
     for (int i = tid; i < P.h1; i += NT) L.h1[i] = h1[(size_t)b * P.h1 + i];
     for (int i = tid; i < P.h2; i += NT) L.h2[i] = h2[(size_t)b * P.h2 + i];
     __syncthreads();
-    for (int t = 0; t < Lf; ++t) {
+    int t = 0;
+    for (; t < Lf; ++t) {
         if (tid < P.in) L.x[tid] = x[((size_t)b * Lf + t) * P.in + tid];
         __syncthreads();
         pred_step(P, L, tid, &X);
+        if (X.dead) break;  // (workgroup-uniform) a spin of the row split gave up
         if (writer && tid < P.fc) y[((size_t)b * Lf + t) * P.fc + tid] = L.fo[tid];
     }
     __syncthreads();
+    if (X.dead) {  // fail loudly: NaN from this frame on, NaN states; the host reports FPC_ERR_TIMEOUT
+        if (writer) {
+            const float qnan = __uint_as_float(0x7fc00000u);
+            for (size_t k = (size_t)t * P.fc + tid; k < (size_t)Lf * P.fc; k += NT) y[(size_t)b * Lf * P.fc + k] = qnan;
+            for (int i = tid; i < P.h1; i += NT) h1[(size_t)b * P.h1 + i] = qnan;
+            for (int i = tid; i < P.h2; i += NT) h2[(size_t)b * P.h2 + i] = qnan;
+        }
+        return;
+    }
     // (the partner read the incoming states before its first publish, which this half has waited for: safe to overwrite)
     if (writer) {
         for (int i = tid; i < P.h1; i += NT) h1[(size_t)b * P.h1 + i] = L.h1[i];
@@ -756,19 +792,27 @@ __global__ __launch_bounds__(NT) void k_encode(const PredDev P, const CbDev C, c
     __syncthreads();
     const int off_sl = C.n_hi, off_v0 = off_sl + C.n_lo, off_v1 = off_v0 + C.N_hi0,
               off_vl = off_v1 + (C.S_hi == 2 ? C.N_hi1 : 0);
-    for (int i = 0; i < A.Lf; ++i) {
+    int i = 0;
+    for (; i < A.Lf; ++i) {
         const size_t fi = (size_t)b * A.Lf + i;
         const float* f = A.feat + fi * Cc;
         pred_step(P, L, tid, &X);  // wavernn.py:194-195
+        if (X.dead) break;         // (workgroup-uniform) a spin of the row split gave up
         if (tid < F) L.rs[tid] = f[tid] - L.fo[tid];  // :196
         __syncthreads();
         float sabs = 0.0f;
         for (int d = 1; d < F; ++d) sabs += fabsf(L.rs[d]);
         const int i1 = fabsf(L.rs[0]) > A.l1;  // :202
         const int i2 = sabs > A.l2;            // :206
+        // a NaN / infinite residual (non-finite features or weights) has no nearest entry: the arg-min would come back
+        // as 0x7fffffff and be used as an address.  Such a frame is not searched: status bit 1, symbols -2
+        // (every thread evaluates the same LDS values: workgroup-uniform without a barrier)
+        const bool nonfinite = !(fabsf(L.rs[0]) <= 3.0e38f) || !(sabs <= 3.0e38f);
+        if (nonfinite && A.qtz && tid == 0 && writer) status_or(S.err, FPC_ST_NONFINITE);
         float rq = 0.0f;                       // this thread's r_qtz[d] (tid < F)
         int ix0 = -1, ix1 = -1, ix2 = -1, ix3 = -1;
-        if (A.qtz) {
+        if (nonfinite) ix0 = ix1 = ix2 = ix3 = -2;
+        if (A.qtz && !nonfinite) {
             if (i1 || C.scl_lo) {  // :218-225
                 scl_search(L, L.rs[0], i1 ? C.scl_hi : C.scl_lo, i1 ? C.n_hi : C.n_lo, tid);
                 if (tid == 0) {
@@ -835,6 +879,23 @@ __global__ __launch_bounds__(NT) void k_encode(const PredDev P, const CbDev C, c
         }
         __syncthreads();
     }
+    if (X.dead && writer) {  // fail loudly: NaN and symbols -2 from this frame on (the histograms are not touched any
+        const float qnan = __uint_as_float(0x7fc00000u);  // more); the host reports FPC_ERR_TIMEOUT
+        for (size_t k = (size_t)i * F + tid; k < (size_t)A.Lf * F; k += NT) {
+            const size_t o = (size_t)b * A.Lf * F + k;
+            A.r[o] = qnan;
+            A.r_qtz[o] = qnan;
+            A.r_under[o] = qnan;
+        }
+        for (size_t k = (size_t)i * Cc + tid; k < (size_t)A.Lf * Cc; k += NT) A.c_in[(size_t)b * A.Lf * Cc + k] = qnan;
+        for (size_t k = (size_t)i + tid; k < (size_t)A.Lf; k += NT) {
+            const size_t o = (size_t)b * A.Lf + k;
+            A.ind1[o] = qnan;
+            A.ind2[o] = qnan;
+            if (A.idx)
+                for (int c = 0; c < 4; ++c) A.idx[o * 4 + c] = -2;
+        }
+    }
 }
 
 // receiver side of k_encode: the same predictor steps, the residual looked up from the transmitted symbols
@@ -852,9 +913,11 @@ __global__ __launch_bounds__(NT) void k_decode_feat(const PredDev P, const CbDev
     for (int i = tid; i < P.h2; i += NT) L.h2[i] = 0.0f;
     if (tid < Cc) L.x[tid] = 0.0f;
     __syncthreads();
-    for (int i = 0; i < Lf; ++i) {
+    int i = 0;
+    for (; i < Lf; ++i) {
         const size_t fi = (size_t)b * Lf + i;
         pred_step(P, L, tid, &X);
+        if (X.dead) break;  // (workgroup-uniform) a spin of the row split gave up
         if (tid < F) {
             const int* ix = idx + fi * 4;
             float rq = 0.0f;
@@ -894,6 +957,10 @@ __global__ __launch_bounds__(NT) void k_decode_feat(const PredDev P, const CbDev
         }
         __syncthreads();
     }
+    if (X.dead && writer) {  // fail loudly: NaN from this frame on; the host reports FPC_ERR_TIMEOUT
+        const float qnan = __uint_as_float(0x7fc00000u);
+        for (size_t k = (size_t)i * Cc + tid; k < (size_t)Lf * Cc; k += NT) c_out[(size_t)b * Lf * Cc + k] = qnan;
+    }
 }
 
 // stand-alone quantizers: one workgroup per input row
@@ -901,8 +968,15 @@ __global__ __launch_bounds__(NT) void k_vq(const CbDev C, int which, const float
                                            int* idx) {
     __shared__ PredLds L;
     const int n = blockIdx.x, tid = threadIdx.x;
-    if (tid < NDIM) L.rs[1 + tid] = r[(size_t)n * NDIM + tid];
-    __syncthreads();
+    float rv = 0.0f;
+    if (tid < NDIM) L.rs[1 + tid] = rv = r[(size_t)n * NDIM + tid];
+    // a NaN / infinite row has no nearest entry (the arg-min would come back as 0x7fffffff and be used as an address):
+    // NaN out, symbols -2
+    if (__syncthreads_or(!(fabsf(rv) <= 3.0e38f))) {
+        if (tid < NDIM) qr[(size_t)n * NDIM + tid] = __longlong_as_double(0x7ff8000000000000ll);
+        if (tid < 2 && idx) idx[n * 2 + tid] = -2;
+        return;
+    }
     const bool hi = which == 0;
     vq_mstage(L, hi ? C.S_hi : 1, hi ? C.vq_hi0 : C.vq_lo, hi ? C.vq_hi0_r : C.vq_lo_r, hi ? C.N_hi0 : C.N_lo,
               hi ? C.vq_hi1 : nullptr, hi ? C.vq_hi1_r : nullptr, hi ? C.N_hi1 : 0, tid);
@@ -918,6 +992,13 @@ __global__ __launch_bounds__(NT) void k_scl(const CbDev C, int which, const floa
                                             int* idx) {
     __shared__ PredLds L;
     const int n = blockIdx.x, tid = threadIdx.x;
+    if (!(fabsf(x[n]) <= 3.0e38f)) {  // (workgroup-uniform) no nearest code of a NaN: NaN out, symbol -2
+        if (tid == 0) {
+            q[n] = __longlong_as_double(0x7ff8000000000000ll);
+            if (idx) idx[n] = -2;
+        }
+        return;
+    }
     scl_search(L, x[n], which == 0 ? C.scl_hi : C.scl_lo, which == 0 ? C.n_hi : C.n_lo, tid);
     if (tid == 0) {
         q[n] = L.qs;
@@ -1265,9 +1346,10 @@ __global__ void k_colsum(const GradJobs J, int N) {
 
 // torch.optim.Adam, single-tensor path (betas 0.9 / 0.999, eps 1e-8, no weight decay)
 __global__ void k_adam(float* __restrict__ p, float* __restrict__ m, float* __restrict__ v, const float* __restrict__ g,
-                       size_t n, float step_size, float bc2_sqrt) {
+                       size_t n, float step_size, float bc2_sqrt, const unsigned* status) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
+    if (status_load(status) != 0u) return;  // the step's forward or backward gave up: the weights stay as they are
     const float gi = g[i];
     const float mi = fmaf(0.1f, gi - m[i], m[i]);
     const float vi = fmaf(0.001f, gi * gi, v[i] * 0.999f);
@@ -1287,33 +1369,83 @@ struct fpc_predictor {
     PredDev d;
     fpc::DevBuf buf[10];
     fpc::DevBuf flag;  // one int: "a symbol lay outside its codebook" (fpc_decode_features), allocated once per handle
-    fpc::DevBuf xg;    // row-split exchange granules [B][2][h1 + h2] x 8 bytes + the timeout word, grown on demand
+    fpc::DevBuf xg;    // row-split exchange granules [B][2][h1 + h2] x 8 bytes, grown on demand
+    // status word: host-mapped pinned memory the kernels OR failure bits into (FPC_ST_*); sticky until
+    // fpc_predictor_status() clears it; read by the host without a synchronisation at the start of every call
+    unsigned* status_host = nullptr;
+    unsigned* status_dev = nullptr;
+    // launches on this handle share its granule block: a call on another stream first waits for the last launch
+    hipEvent_t last_ev = nullptr;
+    hipStream_t last_stream = nullptr;
+    bool launched = false;
+    int forced_split = 0;  // fpc_predictor_set_split: 0 automatic, 1 off, 2/4/8 exactly that many workgroups per utterance
     int num_cus = 0;
-    int refs = 1;  // the creator's handle + one per live fpc_trainer built on it (fpc_predictor_destroy only drops a reference)
+    std::atomic<int> refs{1};  // the creator's handle + one per live fpc_trainer built on it (fpc_predictor_destroy only drops a reference)
+    ~fpc_predictor() {
+        if (last_ev) (void)hipEventDestroy(last_ev);
+        if (status_host) (void)hipHostFree(status_host);
+    }
 };
-// Row split (two workgroups per utterance) when the batch leaves at least half of the CUs idle; FPC_PRED_SPLIT=0/1
-// forces it off/on (tests run both forms).  Prepares the zeroed granule block on the stream.
+// the sticky status word as an error code (no synchronisation: what the device has reported so far)
+static int status_error(const fpc_predictor* p, const char* who) {
+    const unsigned st = p->status_host ? *(volatile unsigned*)p->status_host : 0u;
+    if (st & FPC_ST_TIMEOUT) {
+        fpc::set_error("%s: a row-split exchange timed out (a workgroup of an utterance's group was not dispatched "
+                       "or stalled for > 1 s: is the GPU shared?); the outputs of that launch are NaN / -2; "
+                       "fpc_predictor_status() clears the condition, fpc_predictor_set_split(p, 1) avoids the exchange", who);
+        return FPC_ERR_TIMEOUT;
+    }
+    if (st & FPC_ST_NONFINITE) {
+        fpc::set_error("%s: a non-finite residual reached a quantizer (NaN / infinity in the features or weights); "
+                       "those frames carry the symbols -2; fpc_predictor_status() clears the condition", who);
+        return FPC_ERR_NONFINITE;
+    }
+    return FPC_OK;
+}
+// every launch on the handle goes through these two: cross-stream ordering on the shared granule block
+static int before_launch(fpc_predictor* p, hipStream_t st) {
+    if (p->launched && p->last_stream != st) FPC_HIP(hipStreamWaitEvent(st, p->last_ev, 0));
+    return FPC_OK;
+}
+static int after_launch(fpc_predictor* p, hipStream_t st) {
+    FPC_HIP(hipEventRecord(p->last_ev, st));
+    p->last_stream = st;
+    p->launched = true;
+    return FPC_OK;
+}
+// Row split (2, 4 or 8 workgroups per utterance) while the batch leaves CUs idle; fpc_predictor_set_split or
+// FPC_PRED_SPLIT=0/1/2/4/8 force it off / to a count (tests run every form).  Prepares the zeroed granule block on the
+// stream.  The automatic choice assumes that this process owns the GPU (every workgroup of a group must be resident).
 static int split_args(fpc_predictor* p, int B, hipStream_t st, SplitArgs* out) {
     out->n = 1;
     out->g = nullptr;
-    out->err = nullptr;
+    out->err = p->status_dev;
+    out->limit = 100000000ull;  // 1 s of s_memrealtime (100 MHz)
+    out->withhold = 0;
+    if (const char* lim = getenv("FPC_SPIN_LIMIT_US")) {  // test hook: a shorter give-up bound
+        const long us = atol(lim);
+        if (us > 0) out->limit = (unsigned long long)us * 100ull;
+    }
+    if (const char* wh = getenv("FPC_TEST_WITHHOLD_PUBLISH")) out->withhold = wh[0] == '1';  // test hook
     const char* env = getenv("FPC_PRED_SPLIT");  // 0: never; 2/4/8: exactly that many (tests); unset: as many as leave
     int n = 1;                                    // every workgroup a CU of its own, up to 8
     for (int c = 2; c <= 8; c *= 2)
         if (p->d.h1 % (4 * c) == 0 && p->d.h2 % (4 * c) == 0 && c * B <= p->num_cus) n = c;
-    if (env && env[0] >= '0' && env[0] <= '8') {
-        const int f = env[0] - '0';
-        if (f == 0 || f == 1)
-            n = 1;
-        else if ((f == 2 || f == 4 || f == 8) && p->d.h1 % (4 * f) == 0 && p->d.h2 % (4 * f) == 0 && f * B <= 2 * p->num_cus)
-            n = f;  // (forced: at most two workgroups per CU, still all resident)
+    int f = p->forced_split;
+    if (env && env[0] >= '0' && env[0] <= '8') f = env[0] == '0' ? 1 : env[0] - '0';
+    if (f == 1)
+        n = 1;
+    else if ((f == 2 || f == 4 || f == 8) && p->d.h1 % (4 * f) == 0 && p->d.h2 % (4 * f) == 0 && f * B <= 2 * p->num_cus)
+        n = f;  // (forced: at most two workgroups per CU, still all resident)
+    {
+        const int rc = before_launch(p, st);
+        if (rc != FPC_OK) return rc;
     }
     if (n == 1) return FPC_OK;
-    const size_t gran = (size_t)B * 2 * (p->d.h1 + p->d.h2) * sizeof(unsigned long long);
-    const size_t bytes = ((gran + 15) / 16) * 16 + 16;  // granules, then the timeout word (own 16-byte slot)
+    const size_t bytes = (size_t)B * 2 * (p->d.h1 + p->d.h2) * sizeof(unsigned long long);
     if (p->xg.bytes < bytes) {
         if (p->xg.p) {
-            FPC_HIP(hipStreamSynchronize(st));  // nothing may still be polling the old block
+            FPC_HIP(hipDeviceSynchronize());  // nothing may still be polling the old block (on any stream)
             (void)hipFree(p->xg.p);
             p->xg.p = nullptr;
         }
@@ -1322,12 +1454,11 @@ static int split_args(fpc_predictor* p, int B, hipStream_t st, SplitArgs* out) {
     FPC_HIP(hipMemsetAsync(p->xg.p, 0, bytes, st));  // tags start at 0; epochs count from 1 within the launch
     out->n = n;
     out->g = p->xg.as<unsigned long long>();
-    out->err = reinterpret_cast<unsigned*>(static_cast<char*>(p->xg.p) + ((gran + 15) / 16) * 16);
     return FPC_OK;
 }
 
 static void predictor_unref(fpc_predictor* p) {
-    if (p && --p->refs <= 0) delete p;
+    if (p && p->refs.fetch_sub(1) <= 1) delete p;
 }
 
 struct fpc_codebooks {
@@ -1384,6 +1515,16 @@ extern "C" int fpc_predictor_create(const fpc_predictor_weights* w, fpc_predicto
     FPC_HIP(upv(p->buf[9], vec(w->fc_bias, fc), &p->d.fcb));
     FPC_HIP(p->flag.alloc(sizeof(int)));
     {
+        void* hp = nullptr;
+        FPC_HIP(hipHostMalloc(&hp, 64, hipHostMallocMapped));
+        p->status_host = static_cast<unsigned*>(hp);
+        memset(hp, 0, 64);
+        void* dp = nullptr;
+        FPC_HIP(hipHostGetDevicePointer(&dp, hp, 0));
+        p->status_dev = static_cast<unsigned*>(dp);
+        FPC_HIP(hipEventCreateWithFlags(&p->last_ev, hipEventDisableTiming));
+    }
+    {
         int dev = 0;
         FPC_HIP(hipGetDevice(&dev));
         FPC_HIP(hipDeviceGetAttribute(&p->num_cus, hipDeviceAttributeMultiprocessorCount, dev));
@@ -1398,12 +1539,28 @@ extern "C" int fpc_predictor_forward(fpc_predictor* p, const float* x_dev, int B
                                      float* h1_dev, float* h2_dev, float* y_dev, fpc_stream s) {
     FPC_REQUIRE(p && x_dev && h1_dev && h2_dev && y_dev, "fpc_predictor_forward: null argument");
     FPC_REQUIRE(B > 0 && L >= 0, "fpc_predictor_forward: bad shape B=%d L=%d", B, L);
+    if (const int se = status_error(p, "fpc_predictor_forward")) return se;  // an earlier launch on the handle failed
     SplitArgs sp;
     const int rc = split_args(p, B, static_cast<hipStream_t>(s), &sp);
     if (rc != FPC_OK) return rc;
     hipLaunchKernelGGL(k_forward, dim3(B * sp.n), dim3(NT), 0, static_cast<hipStream_t>(s), p->d, x_dev, L,
                        h1_dev, h2_dev, y_dev, sp);
     FPC_HIP(hipGetLastError());
+    return after_launch(p, static_cast<hipStream_t>(s));
+}
+
+extern "C" int fpc_predictor_status(fpc_predictor* p) {
+    FPC_REQUIRE(p, "fpc_predictor_status: null handle");
+    FPC_HIP(hipDeviceSynchronize());  // everything launched on the handle so far has reported
+    const int rc = status_error(p, "fpc_predictor_status");
+    *(volatile unsigned*)p->status_host = 0u;
+    return rc;
+}
+
+extern "C" int fpc_predictor_set_split(fpc_predictor* p, int n) {
+    FPC_REQUIRE(p, "fpc_predictor_set_split: null handle");
+    FPC_REQUIRE(n == 0 || n == 1 || n == 2 || n == 4 || n == 8, "fpc_predictor_set_split: n = %d (0 automatic, 1 off, 2, 4 or 8)", n);
+    p->forced_split = n;
     return FPC_OK;
 }
 
@@ -1473,6 +1630,7 @@ extern "C" int fpc_encode(fpc_predictor* p, const fpc_codebooks* cb, const float
     FPC_REQUIRE(!qtz || cb, "fpc_encode: qtz=1 needs codebooks");
     FPC_REQUIRE(p->d.fc == NDIM + 1, "fpc_encode: fc_units must be 18 (c0 + 17-dim VQ), got %d", p->d.fc);
     if (L == 0) return FPC_OK;
+    if (const int se = status_error(p, "fpc_encode")) return se;  // an earlier launch on the handle failed
     CbDev cd;
     memset(&cd, 0, sizeof cd);
     if (cb) cd = cb->d;
@@ -1483,7 +1641,7 @@ extern "C" int fpc_encode(fpc_predictor* p, const fpc_codebooks* cb, const float
     if (rc != FPC_OK) return rc;
     hipLaunchKernelGGL(k_encode, dim3(B * sp.n), dim3(NT), 0, static_cast<hipStream_t>(s), p->d, cd, a, sp);
     FPC_HIP(hipGetLastError());
-    return FPC_OK;
+    return after_launch(p, static_cast<hipStream_t>(s));
 }
 
 extern "C" int fpc_decode_features(fpc_predictor* p, const fpc_codebooks* cb, const float* pitch_dev,
@@ -1492,6 +1650,7 @@ extern "C" int fpc_decode_features(fpc_predictor* p, const fpc_codebooks* cb, co
     FPC_REQUIRE(B > 0 && L >= 0, "fpc_decode_features: bad shape B=%d L=%d", B, L);
     FPC_REQUIRE(p->d.fc == NDIM + 1, "fpc_decode_features: fc_units must be 18 (c0 + 17-dim VQ), got %d", p->d.fc);
     if (L == 0) return FPC_OK;
+    if (const int se = status_error(p, "fpc_decode_features")) return se;  // an earlier launch on the handle failed
     hipStream_t st = static_cast<hipStream_t>(s);
     // the flag lives in the handle (no per-call hipMalloc/hipFree: hipFree synchronises the whole device); the
     // check itself needs this stream's result, so the call still ends with a sync of this one stream
@@ -1504,7 +1663,12 @@ extern "C" int fpc_decode_features(fpc_predictor* p, const fpc_codebooks* cb, co
     FPC_HIP(hipGetLastError());
     int h = 0;
     FPC_HIP(hipMemcpyAsync(&h, p->flag.p, sizeof(int), hipMemcpyDeviceToHost, st));
+    {
+        const int rc2 = after_launch(p, st);
+        if (rc2 != FPC_OK) return rc2;
+    }
     FPC_HIP(hipStreamSynchronize(st));
+    if (const int se = status_error(p, "fpc_decode_features")) return se;  // this launch's exchange gave up
     FPC_REQUIRE(h == 0, "fpc_decode_features: a symbol lies outside its codebook (corrupt stream or wrong codebooks)");
     return FPC_OK;
 }
@@ -1568,7 +1732,7 @@ extern "C" int fpc_trainer_create(fpc_predictor* p, int max_B, int max_L, fpc_tr
     T.th = take(N * F), T.dpre = take(N * F);
     T.dgi1 = take(N * 3 * H1), T.dgh1 = take(N * 3 * H1), T.dgi2 = take(N * 3 * H2), T.dgh2 = take(N * 3 * H2);
     T.lossb = t->lossb.as<double>();
-    ++p->refs;  // the trainer keeps its predictor alive: fpc_predictor_destroy before fpc_trainer_destroy is safe
+    p->refs.fetch_add(1);  // the trainer keeps its predictor alive: fpc_predictor_destroy before fpc_trainer_destroy is safe
     *out = own.release();
     return FPC_OK;
 }
@@ -1586,6 +1750,7 @@ extern "C" int fpc_trainer_step(fpc_trainer* t, const float* feat_dev, int B, in
                 B, L, t->maxB, t->maxL);
     hipStream_t st = static_cast<hipStream_t>(s);
     fpc_predictor* p = t->p;
+    if (const int se = status_error(p, "fpc_trainer_step")) return se;  // an earlier launch on the handle failed
     const PredDev& P = p->d;
     const int in = P.in, H1 = P.h1, H2 = P.h2, F = P.fc;
     const int N = B * L;
@@ -1642,13 +1807,19 @@ extern "C" int fpc_trainer_step(fpc_trainer* t, const float* feat_dev, int B, in
     const float step_size = (float)(lr / bc1), bc2_sqrt = (float)sqrt(bc2);
     for (int k = 0; k < 10; ++k)
         hipLaunchKernelGGL(k_adam, dim3((unsigned)((t->sz[k] + 255) / 256)), dim3(256), 0, st, param_ptr(p, k),
-                           t->m[k].as<float>(), t->v[k].as<float>(), t->grad[k].as<float>(), t->sz[k], step_size, bc2_sqrt);
+                           t->m[k].as<float>(), t->v[k].as<float>(), t->grad[k].as<float>(), t->sz[k], step_size, bc2_sqrt,
+                           p->status_dev);
     refresh();
     FPC_HIP(hipGetLastError());
+    {
+        const int rc = after_launch(p, st);
+        if (rc != FPC_OK) return rc;
+    }
     if (loss_host) {
         std::vector<double> lb(B);
         FPC_HIP(hipMemcpyAsync(lb.data(), T.lossb, sizeof(double) * (size_t)B, hipMemcpyDeviceToHost, st));
         FPC_HIP(hipStreamSynchronize(st));
+        if (const int se = status_error(p, "fpc_trainer_step")) return se;  // this step gave up: no Adam update was made
         double loss = 0.0;
         for (int b = 0; b < B; ++b) loss += lb[b];
         *loss_host = (float)(loss / cnt);
@@ -1667,6 +1838,7 @@ extern "C" int fpc_trainer_export(fpc_trainer* t, int what, const fpc_predictor_
     const int rows[10] = {3 * H1, 3 * H1, 0, 0, 3 * H2, 3 * H2, 0, 0, F, 0};   // torch rows of the matrices
     const int cols[10] = {in, H1, 0, 0, H1, H2, 0, 0, H2, 0};
     FPC_HIP(hipDeviceSynchronize());
+    if (const int se = status_error(t->p, "fpc_trainer_export")) return se;  // a step on the handle gave up
     for (int k = 0; k < 10; ++k) {
         FPC_REQUIRE(dst[k], "fpc_trainer_export: null output pointer %d", k);
         std::vector<float> h(t->sz[k]);

@@ -124,7 +124,8 @@ def vq_quantize(r, cb_path, return_indices=False):
     ih = idx.cpu().numpy()
     cb_tot = []
     for s, st in enumerate(cb.vq_hi):
-        cb_tot.append(np.bincount(ih[:, s], minlength=st.shape[0]).astype(np.float64))
+        col = ih[:, s]  # (-2: a non-finite row, not searched -- its qr row is NaN)
+        cb_tot.append(np.bincount(col[col >= 0], minlength=st.shape[0]).astype(np.float64))
     out = (qr.cpu().numpy(), cb_tot)
     return out + (ih,) if return_indices else out
 
@@ -147,7 +148,7 @@ def scl_quantize(data, cb_path, return_indices=False):
     _lib.check(_lib.lib().fpc_scl_quantize(cb.handle, 0, xd.data_ptr(), n, q.data_ptr(), idx.data_ptr(),
                                            _lib.stream_ptr()), "fpc_scl_quantize")
     ih = idx.cpu().numpy()
-    out = (q.cpu().numpy()[:, None], np.bincount(ih, minlength=cb.scl_hi.size).astype(np.float64))
+    out = (q.cpu().numpy()[:, None], np.bincount(ih[ih >= 0], minlength=cb.scl_hi.size).astype(np.float64))
     return out + (ih,) if return_indices else out
 
 

@@ -5,11 +5,14 @@ Same constructor arguments, same state_dict keys/shapes (wavernn.py:24-52), same
 `forward(x, h1, h2) -> (y, h1, h2)` (:63-102) and
 `encoder(cfg, feat, mask, l1, l2, vq_quantize, scl_quantize, qtz)` ->
 `(c_in[:,1:], r, r_qtz, r_under, ind1_mask, ind2_mask, cb_tot)` (:165-256).  The whole
-closed loop of `encoder` runs in one persistent kernel per utterance; the quantizer
-callables are accepted for signature compatibility and are NOT called - the codebooks
-named by cfg['scl_cb_path'] / ['cb_path'] / ['bl_scl_cb_path'] / ['bl_cb_path'] are
-searched on the device with the same arithmetic.  Dead/broken reference methods
-(mask_enc, decoder, loop_attention: SURVEY.md App. C) are not reproduced.
+closed loop of `encoder` runs in one persistent kernel per utterance when the quantizer
+callables are this package's own `vq_func.vq_quantize` / `scl_quantize` (or None): the
+codebooks named by cfg['scl_cb_path'] / ['cb_path'] / ['bl_scl_cb_path'] / ['bl_cb_path']
+are then searched on the device with the same arithmetic.  Any OTHER callable is honoured
+as the reference honours it (wavernn.py:219-240): the loop then runs frame by frame, the
+predictor step on the device, the injected quantizers on the rows the reference hands them.
+Dead/broken reference methods (mask_enc, decoder, loop_attention: SURVEY.md App. C) are not
+reproduced.
 """
 import ctypes as C
 import weakref
@@ -157,11 +160,83 @@ class Wavernn:
 
     __call__ = forward
 
+    def check(self):
+        """synchronise and raise FpcError if a launch on this model's handle failed (a row-split exchange that
+        timed out, a non-finite residual at a quantizer): fpc_predictor_status of include/fpcodec.h"""
+        if self._h is not None:
+            _lib.check(_lib.lib().fpc_predictor_status(self._h), "fpc_predictor_status")
+
+    def set_split(self, n):
+        """workgroups per utterance: 0 automatic (the process owns the GPU), 1 never split (shared GPU), 2 / 4 / 8"""
+        _lib.check(_lib.lib().fpc_predictor_set_split(self._handle(), int(n)), "fpc_predictor_set_split")
+
+    def _encoder_injected(self, cfg, feat, l1, l2, vq_quantize, scl_quantize):
+        """`encoder(..., qtz=True)` with quantizer callables that are not this package's own: the reference's loop
+        (wavernn.py:192-242) frame by frame -- the predictor step on the device, thresholds and the injected
+        callables on the host with exactly the rows, paths and accumulation of wavernn.py:217-240."""
+        dev = self.device
+        B, L, Cc = feat.shape
+        c_in = torch.zeros(B, L + 1, Cc, device=dev)
+        c_in[:, 1:, -2:] = feat[:, :, -2:]
+        r = torch.zeros(B, L, 18, device=dev)
+        r_qtz = torch.zeros(B, L, 18, device=dev)
+        r_under = torch.zeros(B, L, 18, device=dev)
+        ind1_mask = torch.zeros(B, L, 1, device=dev)
+        ind2_mask = torch.zeros(B, L, 1, device=dev)
+        cb_tot = [0, 0, 0, 0, 0]
+        h1 = h2 = None
+        for i in range(L):
+            f_out, h1, h2 = self.forward(c_in[:, i:i + 1, :], h1, h2)
+            f_out = f_out[:, -1, :]
+            r_s = feat[:, i, :-2] - f_out
+            r[:, i, :] = r_s
+            ind1 = (abs(r_s[:, 0]) > l1).to(int).unsqueeze(1)
+            ind1_mask[:, i, :] = ind1
+            ind2 = (torch.sum(abs(r_s[:, 1:]), -1) > l2).to(int).unsqueeze(1)
+            ind2_mask[:, i, :] = ind2
+            r_host = r_s.cpu().numpy()
+            i1, i2 = ind1.cpu().numpy(), ind2.cpu().numpy()
+            for k in range(B):
+                if i1[k, 0]:
+                    rq, cb_t = scl_quantize(r_host[k:k + 1, 0:1], cfg['scl_cb_path'])
+                    r_qtz[k:k + 1, i, 0:1] = torch.as_tensor(np.asarray(rq), dtype=torch.float32).to(dev)
+                    cb_tot[0] = cb_tot[0] + cb_t
+                elif cfg.get('bl_scl_cb_path'):
+                    rq, cb_t = scl_quantize(r_host[k:k + 1, 0:1], cfg['bl_scl_cb_path'])
+                    r_qtz[k:k + 1, i, 0:1] = torch.as_tensor(np.asarray(rq), dtype=torch.float32).to(dev)
+                    cb_tot[1] = cb_tot[1] + cb_t
+            for k in range(B):
+                if i2[k, 0]:
+                    rq, cb_t = vq_quantize(r_host[k:k + 1, 1:], cfg['cb_path'])
+                    r_qtz[k:k + 1, i, 1:] = torch.as_tensor(np.asarray(rq), dtype=torch.float32).to(dev)
+                    cb_tot[2] = cb_tot[2] + cb_t[0]
+                    cb_tot[3] = cb_tot[3] + cb_t[1]
+                elif cfg.get('bl_cb_path'):
+                    rq, cb_t = vq_quantize(r_host[k:k + 1, 1:], cfg['bl_cb_path'])
+                    r_qtz[k:k + 1, i, 1:] = torch.as_tensor(np.asarray(rq), dtype=torch.float32).to(dev)
+                    cb_tot[4] = cb_tot[4] + cb_t[-1]
+            c_in[:, i + 1, :-2] = f_out + r_qtz[:, i, :]
+        self.check()
+        return c_in[:, 1:, :], r, r_qtz, r_under, ind1_mask, ind2_mask, cb_tot
+
     # ---- Wavernn.encoder (wavernn.py:165-256) ----
     def encoder(self, cfg, feat, mask, l1, l2, vq_quantize=None, scl_quantize=None, qtz=True,
                 return_indices=False):
         if mask is not None:
             raise NotImplementedError("only the threshold mode (mask=None) is live in the reference")
+        from . import vq_func as _vq
+        own = (vq_quantize is None or vq_quantize is _vq.vq_quantize) and \
+            (scl_quantize is None or scl_quantize is _vq.scl_quantize)
+        if qtz and not own:
+            # injected quantizers (wavernn.py:165: the reference calls whatever it is handed): honoured, frame by frame
+            if return_indices:
+                raise _lib.FpcError("Wavernn.encoder: return_indices needs the built-in quantizers (an injected "
+                                    "callable returns quantized values, not codebook symbols)")
+            if vq_quantize is None or scl_quantize is None:
+                raise _lib.FpcError("Wavernn.encoder: pass both vq_quantize and scl_quantize or neither "
+                                    "(wavernn.py:219,230 call both)")
+            return self._encoder_injected(cfg, feat.to(self.device, torch.float32).contiguous(), l1, l2,
+                                          vq_quantize, scl_quantize)
         h = self._handle()
         feat = feat.to(self.device, torch.float32).contiguous()
         B, L, Cc = feat.shape
@@ -185,7 +260,8 @@ class Wavernn:
             ind2.data_ptr(), idx.data_ptr(), hist.data_ptr() if hist is not None else None,
             _lib.stream_ptr()), "fpc_encode")
         if qtz:
-            cb_tot = cb.split_hist(hist.cpu().numpy().astype(np.float64))
+            cb_tot = cb.split_hist(hist.cpu().numpy().astype(np.float64))  # (synchronises: the launch has reported)
+            self.check()
         else:
             cb_tot = [0, 0, 0, 0, 0]  # wavernn.py:189
         out = (c_in, r, r_qtz, r_under, ind1, ind2, cb_tot)

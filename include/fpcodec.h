@@ -33,7 +33,9 @@ typedef enum {
     FPC_ERR_INVALID = -1, /* bad argument / shape */
     FPC_ERR_HIP = -2,     /* HIP runtime error (text in fpc_last_error) */
     FPC_ERR_NO_DEVICE = -3,
-    FPC_ERR_CAPACITY = -4 /* model does not fit the on-chip layout */
+    FPC_ERR_CAPACITY = -4, /* model does not fit the on-chip layout */
+    FPC_ERR_TIMEOUT = -5,  /* a row-split exchange of a predictor launch gave up (see fpc_predictor_status) */
+    FPC_ERR_NONFINITE = -6 /* a NaN / infinite residual reached a quantizer (see fpc_predictor_status) */
 } fpc_status;
 
 typedef void* fpc_stream; /* hipStream_t */
@@ -72,13 +74,32 @@ FPC_API int fpc_predictor_create(const fpc_predictor_weights* w, fpc_predictor**
 /* drops the caller's reference; a live fpc_trainer built on the handle keeps the device weights alive */
 FPC_API void fpc_predictor_destroy(fpc_predictor* p);
 
-/* Row split (round 2): fpc_predictor_forward, fpc_encode, fpc_decode_features and fpc_trainer_step run one utterance
- * on 2, 4 or 8 workgroups (one CU each) while the batch leaves CUs idle (B x n <= number of CUs); the slices of the
- * recurrent state change hands through a block of tagged 8-byte words that belongs to the predictor handle and is
- * cleared on the stream before each launch.  Results are bit-identical to the one-workgroup form.  Consequences for the
- * caller: do not run launches of ONE handle on two streams at the same time; a launch whose workgroups cannot all
- * become resident within ~1 s of each other gives up and fills its outputs with NaN instead of hanging.
- * Environment: FPC_PRED_SPLIT=0 keeps one workgroup per utterance, 2|4|8 fixes the count. */
+/* Row split: fpc_predictor_forward, fpc_encode, fpc_decode_features and fpc_trainer_step run one utterance on 2, 4 or
+ * 8 workgroups (one CU each) while the batch leaves CUs idle (B x n <= number of CUs); the slices of the recurrent
+ * state change hands through a block of tagged 8-byte words that belongs to the predictor handle and is cleared on the
+ * stream before each launch.  Results are bit-identical to the one-workgroup form.
+ *  - ASSUMPTION: the process owns the GPU.  The automatic choice of n counts on every workgroup of a group being
+ *    dispatched at once; a co-tenant kernel that occupies CUs for longer than the bound below makes a split launch
+ *    fail.  Shared-GPU deployments pin n = 1 with fpc_predictor_set_split(p, 1) (or FPC_PRED_SPLIT=0).
+ *  - A spin that does not see its partner within 1 s of wall clock gives up, never hangs: the launch stores NaN (floats)
+ *    and -2 (symbols) from that frame on, touches the histograms no further, the training step skips its Adam update,
+ *    and the handle's sticky status word turns every later call on the handle -- and, at once, every call that
+ *    synchronises anyway (fpc_decode_features, fpc_trainer_step with loss_host, fpc_trainer_export) -- into
+ *    FPC_ERR_TIMEOUT with text in fpc_last_error(), until fpc_predictor_status() has reported and cleared it.
+ *    The asynchronous entry points (fpc_predictor_forward, fpc_encode) therefore return FPC_OK for the failing launch
+ *    itself: a caller that consumes their outputs without another call on the handle asks fpc_predictor_status() first.
+ *  - Launches of ONE handle may be issued on different streams: a call on another stream first waits (on the device)
+ *    for the handle's previous launch.  Creating and destroying handles is thread-safe; calls on one handle are not.
+ * Environment: FPC_PRED_SPLIT=0 keeps one workgroup per utterance, 2|4|8 fixes the count (tests);
+ * FPC_SPIN_LIMIT_US / FPC_TEST_WITHHOLD_PUBLISH are test hooks (a shorter bound; the last slice of utterance 0 never
+ * publishes). */
+
+/* Synchronises the device and returns what the launches on the handle have reported: FPC_OK, FPC_ERR_TIMEOUT (a
+ * row-split exchange gave up) or FPC_ERR_NONFINITE (a NaN / infinite residual reached a quantizer in fpc_encode: those
+ * frames carry the symbols -2 and were not searched); clears the condition. */
+FPC_API int fpc_predictor_status(fpc_predictor* p);
+/* workgroups per utterance: 0 automatic (default), 1 never split, 2 / 4 / 8 exactly that many when the shape allows */
+FPC_API int fpc_predictor_set_split(fpc_predictor* p, int n);
 
 /* Wavernn.forward (wavernn.py:63-102): x [B,L,in] -> y [B,L,fc]; h1 [B,H1],
  * h2 [B,H2] are read as initial state and overwritten with the final state.

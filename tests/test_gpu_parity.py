@@ -739,3 +739,171 @@ def test_train_step_row_split_equals_single_workgroup_form(torch_cuda, synth, mo
     for mode in ("2", "4", "8"):
         for a, b in zip(out["0"], out[mode]):
             assert not np.isnan(b).any() and np.array_equal(a, b), mode
+
+
+def test_row_split_timeout_is_an_error_not_garbage(torch_cuda, synth, cb_paths, monkeypatch):
+    """a row-split exchange that gives up must fail loudly at the ABI (round-2 review item 3): with the test hooks
+    (FPC_TEST_WITHHOLD_PUBLISH: the last slice of utterance 0 never publishes; FPC_SPIN_LIMIT_US: 20 ms instead of 1 s)
+    the partner's spin times out ONCE, deterministically.  The asynchronous entry point itself returns FPC_OK; the
+    handle's sticky status word turns the next call on the handle and fpc_predictor_status into FPC_ERR_TIMEOUT; the
+    failing launch's float outputs are NaN and its symbols -2 (never finite-but-wrong); clearing restores the handle."""
+    import ctypes as C
+    from fpcodec_amd import _lib
+    from fpcodec_amd._lib import FpcError
+    from fpcodec_amd.wavernn import Wavernn
+    from fpcodec_amd.vq_func import load_codebooks
+    torch = torch_cuda
+    m = Wavernn(20, 384, 128, 18)
+    m.load_state_dict(synth.predictor_state_dict())
+    cfg = dict(scl_cb_path=cb_paths["scl_hi"], cb_path=cb_paths["vq_hi"], bl_scl_cb_path=cb_paths["scl_lo"],
+               bl_cb_path=cb_paths["vq_lo"])
+    B, L = 2, 30
+    feat = torch.from_numpy(synth.predictor_features(B, L, utt0=5100)).cuda()
+    monkeypatch.setenv("FPC_PRED_SPLIT", "2")
+    good = m.encoder(cfg, feat, None, 0.09, 0.28, qtz=True, return_indices=True)
+    yg, _, _ = m.forward(feat)
+    torch.cuda.synchronize()
+    # --- the raw ABI: the failing launch returns FPC_OK, its outputs are poison, the status call reports and clears ---
+    L_ = _lib.lib()
+    h = m._handle()
+    cb = load_codebooks(cfg["cb_path"], cfg["scl_cb_path"], cfg["bl_cb_path"], cfg["bl_scl_cb_path"])
+    bufs = [torch.zeros(B, L, n, device="cuda") for n in (20, 18, 18, 18, 1, 1)]
+    idx = torch.zeros(B, L, 4, device="cuda", dtype=torch.int32)
+    hist = torch.zeros(cb.hist_size, device="cuda", dtype=torch.int64)
+    monkeypatch.setenv("FPC_TEST_WITHHOLD_PUBLISH", "1")
+    monkeypatch.setenv("FPC_SPIN_LIMIT_US", "20000")
+    rc = L_.fpc_encode(h, cb.handle, feat.data_ptr(), B, L, 0.09, 0.28, 1, *[b.data_ptr() for b in bufs], idx.data_ptr(),
+                       hist.data_ptr(), _lib.stream_ptr())
+    assert rc == 0  # asynchronous: the launch itself is accepted
+    torch.cuda.synchronize()
+    monkeypatch.delenv("FPC_TEST_WITHHOLD_PUBLISH")
+    # utterance 0 gave up in its first frame: NaN floats, symbols -2, never finite-but-wrong values
+    assert torch.isnan(bufs[0][0]).all() and torch.isnan(bufs[1][0]).all() and (idx[0] == -2).all()
+    # the next call on the handle is refused with the timeout code, and keeps being refused until the status is read
+    y = torch.empty(B, L, 18, device="cuda")
+    s1, s2 = torch.zeros(B, 384, device="cuda"), torch.zeros(B, 128, device="cuda")
+    for _ in range(2):
+        rc = L_.fpc_predictor_forward(h, feat.data_ptr(), B, L, s1.data_ptr(), s2.data_ptr(), y.data_ptr(), _lib.stream_ptr())
+        assert rc == -5 and b"timed out" in L_.fpc_last_error()
+    assert L_.fpc_predictor_status(h) == -5
+    assert L_.fpc_predictor_status(h) == 0  # cleared
+    # --- the Python surface raises; afterwards the handle works again, bit for bit ---
+    monkeypatch.setenv("FPC_TEST_WITHHOLD_PUBLISH", "1")
+    with pytest.raises(FpcError, match="timed out"):
+        m.encoder(cfg, feat, None, 0.09, 0.28, qtz=True, return_indices=True)
+    yb, _, _ = m.forward(feat)  # (status already cleared by the raise: this launch is accepted and fails again)
+    with pytest.raises(FpcError, match="timed out"):
+        m.check()
+    assert torch.isnan(yb[0]).all()
+    monkeypatch.delenv("FPC_TEST_WITHHOLD_PUBLISH")
+    monkeypatch.delenv("FPC_SPIN_LIMIT_US")
+    again = m.encoder(cfg, feat, None, 0.09, 0.28, qtz=True, return_indices=True)
+    ya, _, _ = m.forward(feat)
+    m.check()
+    for a, b in zip(good[:6] + (good[7], yg), again[:6] + (again[7], ya)):
+        assert torch.equal(a, b)
+    for a, b in zip(good[6], again[6]):
+        assert np.array_equal(a, b)
+    # --- a pinned split of 1 (shared-GPU deployments) never exchanges: the hook has nothing to withhold ---
+    monkeypatch.delenv("FPC_PRED_SPLIT")
+    monkeypatch.setenv("FPC_TEST_WITHHOLD_PUBLISH", "1")
+    m.set_split(1)
+    one = m.encoder(cfg, feat, None, 0.09, 0.28, qtz=True, return_indices=True)
+    m.set_split(0)
+    monkeypatch.delenv("FPC_TEST_WITHHOLD_PUBLISH")
+    assert torch.equal(one[0], good[0]) and torch.equal(one[7], good[7])
+
+
+def test_nonfinite_residual_is_refused_not_searched(torch_cuda, synth, cb_paths):
+    """a NaN in the features has no nearest codebook entry: the frame is not searched (the arg-min of NaN distances
+    would be used as an address), its symbols are -2 and the call fails with the non-finite code (ADVICE round 2);
+    the stand-alone quantizers answer NaN / -2 for such a row"""
+    from fpcodec_amd._lib import FpcError
+    from fpcodec_amd.wavernn import Wavernn
+    from fpcodec_amd.vq_func import vq_quantize, scl_quantize
+    torch = torch_cuda
+    m = Wavernn(20, 384, 128, 18)
+    m.load_state_dict(synth.predictor_state_dict())
+    cfg = dict(scl_cb_path=cb_paths["scl_hi"], cb_path=cb_paths["vq_hi"], bl_scl_cb_path=cb_paths["scl_lo"],
+               bl_cb_path=cb_paths["vq_lo"])
+    feat = torch.from_numpy(synth.predictor_features(2, 12, utt0=5200)).cuda()
+    feat[1, 5, 3] = float("nan")
+    with pytest.raises(FpcError, match="non-finite"):
+        m.encoder(cfg, feat, None, 0.09, 0.28, qtz=True, return_indices=True)
+    clean = torch.from_numpy(synth.predictor_features(2, 12, utt0=5200)).cuda()
+    out = m.encoder(cfg, clean, None, 0.09, 0.28, qtz=True, return_indices=True)  # the handle is usable again
+    assert not torch.isnan(out[0]).any()
+    r = synth.predictor_features(1, 4, utt0=5300)[0, :, :17].copy()
+    r[2, 7] = np.inf
+    qr, _, ix = vq_quantize(r, cb_paths["vq_hi"], return_indices=True)
+    assert np.isnan(qr[2]).all() and (np.asarray(ix)[2] == -2).all() and np.isfinite(qr[[0, 1, 3]]).all()
+    q, _, ix = scl_quantize(np.array([[0.1], [np.nan]], np.float32), cb_paths["scl_hi"], return_indices=True)
+    assert np.isnan(q[1, 0]) and np.asarray(ix).reshape(-1)[1] == -2 and np.isfinite(q[0, 0])
+
+
+def test_one_handle_on_two_streams(torch_cuda, model, synth, cb_paths, monkeypatch):
+    """launches of ONE predictor handle issued back to back on two streams (they share the handle's granule block):
+    the second waits on the device for the first; both equal the single-stream results"""
+    torch = torch_cuda
+    monkeypatch.setenv("FPC_PRED_SPLIT", "2")
+    cfg = dict(scl_cb_path=cb_paths["scl_hi"], cb_path=cb_paths["vq_hi"], bl_scl_cb_path=cb_paths["scl_lo"],
+               bl_cb_path=cb_paths["vq_lo"])
+    fa = torch.from_numpy(synth.predictor_features(16, 120, utt0=5400)).cuda()
+    fb = torch.from_numpy(synth.predictor_features(16, 120, utt0=5500)).cuda()
+    ya, _, _ = model.forward(fa)
+    yb, _, _ = model.forward(fb)
+    torch.cuda.synchronize()
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    for _ in range(3):
+        with torch.cuda.stream(s1):
+            y1, _, _ = model.forward(fa)
+        with torch.cuda.stream(s2):
+            y2, _, _ = model.forward(fb)
+        torch.cuda.synchronize()
+        model.check()
+        assert torch.equal(y1, ya) and torch.equal(y2, yb)
+
+
+def test_injected_quantizers_are_honoured(torch_cuda, model, synth, cb_paths):
+    """`Wavernn.encoder` calls whatever quantizers it is handed (reference wavernn.py:165,219-240): callables that are
+    not this package's own run frame by frame on the rows the reference hands them.  A pass-through wrapper of the
+    built-in quantizers must reproduce the fused kernel bit for bit; a quantizer of its own (everything -> 0) must
+    show up in r_qtz, c_in and cb_tot; asking for codebook symbols from a foreign quantizer is refused."""
+    from fpcodec_amd import vq_func
+    from fpcodec_amd._lib import FpcError
+    torch = torch_cuda
+    cfg = dict(scl_cb_path=cb_paths["scl_hi"], cb_path=cb_paths["vq_hi"], bl_scl_cb_path=cb_paths["scl_lo"],
+               bl_cb_path=cb_paths["vq_lo"])
+    feat = torch.from_numpy(synth.predictor_features(3, 25, utt0=5600)).cuda()
+    fused = model.encoder(cfg, feat, None, 0.09, 0.28, vq_func.vq_quantize, vq_func.scl_quantize, qtz=True)
+    calls = {"vq": 0, "scl": 0}
+
+    def vq_wrap(r, path):
+        calls["vq"] += 1
+        assert r.shape == (1, 17) and r.dtype == np.float32
+        return vq_func.vq_quantize(r, path)
+
+    def scl_wrap(d, path):
+        calls["scl"] += 1
+        assert d.shape == (1, 1)
+        return vq_func.scl_quantize(d, path)
+
+    slow = model.encoder(cfg, feat, None, 0.09, 0.28, vq_wrap, scl_wrap, qtz=True)
+    assert calls["vq"] == 3 * 25 and calls["scl"] == 3 * 25  # both codebook pairs are set: every row is quantized
+    for a, b in zip(fused[:6], slow[:6]):
+        assert torch.equal(a, b)
+    for a, b in zip(fused[6], slow[6]):
+        assert np.array_equal(np.asarray(a), np.asarray(b))
+
+    def vq_zero(r, path):
+        return np.zeros((1, 17)), [np.ones(3), np.ones(3)]
+
+    def scl_zero(d, path):
+        return np.zeros((1, 1)), np.ones(2)
+
+    z = model.encoder(cfg, feat, None, 0.09, 0.28, vq_zero, scl_zero, qtz=True)
+    assert float(z[2].abs().max()) == 0.0 and not torch.equal(z[0], fused[0])
+    n1, n2 = int(z[4].sum()), int(z[5].sum())
+    assert z[6][0].sum() == 2 * n1 and z[6][1].sum() == 2 * (75 - n1) and z[6][2].sum() == 3 * n2 and z[6][4].sum() == 3 * (75 - n2)
+    with pytest.raises(FpcError, match="return_indices"):
+        model.encoder(cfg, feat, None, 0.09, 0.28, vq_zero, scl_zero, qtz=True, return_indices=True)
