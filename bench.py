@@ -152,9 +152,8 @@ def e2e_config5(voc, torch, synth, parallel, rank, world, L=300):
     total = E2E_PER_GPU * world
     lo, hi = parallel.shard_range(total, rank, world)
     B = hi - lo
-    nu = 8  # distinct synthetic utterances per rank, tiled (host-side generation is slow; device work is unchanged)
-    nm = np.zeros((B, L, 36), np.float32)
-    nm[:, :, :20] = np.tile(synth.predictor_features(nu, L, utt0=5000 + lo), (B // nu + 1, 1, 1))[:B]
+    nm = np.zeros((B, L, 36), np.float32)  # every utterance of the share is its own AR(1) draw: the bitrate and the
+    nm[:, :, :20] = synth.predictor_features(B, L, utt0=5000 + lo)  # keep-rates are statistics of B x L distinct frames
     nm_d = torch.from_numpy(nm).cuda()
     seeds = torch.from_numpy(synth.seeds(B, utt0=5000 + lo).astype(np.int64)).cuda()
     pcm = torch.empty(B, L * 160, dtype=torch.int16, device="cuda")
@@ -190,7 +189,7 @@ def e2e_config5(voc, torch, synth, parallel, rank, world, L=300):
     keep = [float(g[-3]) / n_frames, float(g[-2]) / n_frames]
     ent = [cal_entropy(h.copy()) if np.sum(h) > 0 else 0.0 for h in cb_glob]
     bits_frame = sum(e * float(np.sum(h)) for e, h in zip(ent, cb_glob)) / n_frames + 2.0  # + the two threshold flags
-    out = {"utterances": int(n_frames) // L, "utterances_this_rank": B, "ranks": world,
+    out = {"utterances": int(n_frames) // L, "utterances_this_rank": B, "distinct_utterances": int(n_frames) // L, "ranks": world,
            "encode_ms": (t1 - t0) * 1e3, "decode_ms": (t2 - t1) * 1e3,
            "rtf_aggregate": rep["samples"] / rep["elapsed_s"] / 16000.0, "keep_rates": keep,
            "entropy_bits_per_symbol": ent, "bits_per_frame": bits_frame, "bitrate_bps": bits_frame * 100.0,

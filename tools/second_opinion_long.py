@@ -97,10 +97,29 @@ def run(density, T, seed, utt0):
                 margins_of_differing_draws=margins, condition_max_abs_err=cond_err)
 
 
+RECORD = os.path.join(ROOT, "profiles", "second_opinion_long.txt")
+
+
+def write_record(rows):
+    """profiles/second_opinion_long.txt, regenerated (by `python tools/second_opinion_long.py` and by
+    tests/test_vocoder_second_opinion.py::test_three_second_trace_all_kernel_variant_weight_sets)"""
+    with open(RECORD, "w") as f:
+        f.write("float64 numpy restatement of the published LPCNet algorithm, teacher-forced along the vocoder oracle's own trace,\n"
+                "half of the frames voiced, per weight set (the three sets select the three decode-kernel instances 208 / 408 /\n"
+                "1616); regenerated by tools/second_opinion_long.py and by the CPU test suite, never edited by hand:\n")
+        for r in rows:
+            r = dict(r)
+            r["rate"] = r["differ"] / r["samples"]
+            f.write(repr(r) + "\n")
+
+
 if __name__ == "__main__":
     T = int(sys.argv[1]) if len(sys.argv) > 1 else 300
+    rows = []
     for k, dens in enumerate([(0.02, 0.02, 0.10), (0.05, 0.05, 0.20), (0.05, 0.05, 0.26)]):
         t0 = time.time()
         r = run(dens, T, 777 + k, 60 + k)
-        r["rate"] = r["differ"] / r["samples"]
-        print(r, f"{time.time() - t0:.0f} s", flush=True)
+        rows.append(r)
+        print(dict(r, rate=r["differ"] / r["samples"]), f"{time.time() - t0:.0f} s", flush=True)
+    if T == 300:
+        write_record(rows)
