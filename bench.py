@@ -130,6 +130,28 @@ def cpu_baseline_encode(cores, frames=100):
             "reference_python_s_per_3s_utterance": 17.0}
 
 
+def decode_kernel_hash():
+    """sha256 over the sources k_decode is compiled from: ties a PMC record to the kernel it was taken on"""
+    import hashlib
+    h = hashlib.sha256()
+    for rel in ("lpcnet_decode.h", "lpcnet.hip"):
+        with open(os.path.join(ROOT, "feature-predictor-for-speech-codec_amd", "csrc", rel), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()
+
+
+def _pci_bus_id(dev):
+    try:
+        import ctypes
+        hip = ctypes.CDLL("libamdhip64.so")
+        buf = ctypes.create_string_buffer(64)
+        if hip.hipDeviceGetPCIBusId(buf, 64, int(dev)) == 0:
+            return buf.value.decode()
+    except Exception:
+        pass
+    return "unknown"
+
+
 def e2e_config5(voc, torch, synth, parallel, rank, world, L=300):
     """BASELINE config 5, this rank's share of the global utterance list: encode (GRU predictor + thresholds +
     scalar/2-stage VQ) -> x24.1 -> ceps2lpc -> LPCNet decode; the codebook-usage histograms and the frame /
@@ -249,13 +271,17 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     ndev = max(1, torch.cuda.device_count())
-    dev = local % ndev  # one process per GPU; the modulo only matters for single-GPU rehearsals
+    backend = os.environ.get("FPC_BENCH_BACKEND", "nccl")  # "nccl" == RCCL on ROCm; "gloo" for rehearsals
+    if world > 1 and backend == "nccl" and world > torch.cuda.device_count():
+        # one process per GPU: a measured N-GPU line must come from N distinct GPUs (ranks folded onto fewer devices
+        # are a rehearsal: FPC_BENCH_BACKEND=gloo)
+        sys.exit(f"bench.py: --gpus {world} under RCCL needs {world} visible GPUs, found {torch.cuda.device_count()}")
+    dev = local % ndev  # (the modulo only acts in the gloo rehearsal on fewer GPUs than ranks)
     torch.cuda.set_device(dev)
     _lib.require_gpu()
     dist = None
     if world > 1:
         import torch.distributed as dist
-        backend = os.environ.get("FPC_BENCH_BACKEND", "nccl")  # "nccl" == RCCL on ROCm; "gloo" for rehearsals
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", dev))
         else:
@@ -300,6 +326,12 @@ def main():
     samples_step = B * (T * 160 - 17)
     rep = parallel.gather_report(dt_local, samples_step * args.steps)  # MAX elapsed, SUM samples over ranks
     dt, total = rep["elapsed_s"], rep["samples"]
+    props = torch.cuda.get_device_properties(dev)
+    ranks = parallel.gather_records({  # who ran what where: a SCALE record shows N distinct GPUs by itself
+        "rank": rank, "device_index": dev, "device_name": props.name,
+        "pci_bus_id": _pci_bus_id(dev), "uuid": str(getattr(props, "uuid", "")),
+        "utterances": [int(lo), int(hi)], "samples": int(samples_step * args.steps), "elapsed_s": float(dt_local),
+        "decode_ms": float(np.mean(dec_ms))})
     value = total / dt
     dec_s = float(np.mean(dec_ms)) / 1e3
     dec_rate = samples_step / dec_s  # per GPU, decode kernel only
@@ -308,16 +340,22 @@ def main():
         os.makedirs(args.dump_pcm, exist_ok=True)
         np.savez(os.path.join(args.dump_pcm, f"rank{rank}.npz"), pcm=pcm.cpu().numpy(), lo=lo, hi=hi)
 
-    traffic = None  # HBM bytes per k_decode launch from the committed PMC passes (same workload only)
+    # HBM bytes per k_decode launch: PMC counters cannot be read inside this process, so the figure comes from the
+    # committed PMC passes (tools/traffic_round.sh) -- but only from a record taken on THIS kernel (hash of the decode
+    # kernel's sources) and this workload; a stale record reads null, never a silently outdated number
+    traffic = None
     traffic_src = None
-    for name in ("r02_traffic.json", "r01_traffic.json"):
+    khash = decode_kernel_hash()
+    for name in sorted((n for n in os.listdir(os.path.join(ROOT, "profiles")) if n.endswith("_traffic.json")), reverse=True):
         try:
             tj = json.load(open(os.path.join(ROOT, "profiles", name)))
-            if B == 256 and T == 300:
-                traffic, traffic_src = tj["hbm_bytes_per_launch"], name
-            break
         except Exception:
             continue
+        if tj.get("kernel_source_sha256") == khash and B == 256 and T == 300:
+            traffic, traffic_src = tj["hbm_bytes_per_launch"], name
+            break
+    if traffic is None:
+        traffic_src = f"none matches kernel sources {khash[:12]}"
     out = {
         "metric": "LPCNet synthesis samples/sec (16 kHz RTF) per GPU; 1/2/4/8-GPU throughput",
         "value": value, "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -330,6 +368,8 @@ def main():
                                   "specifies pitch-corr U(-.4,.4); voiced frames cost more: see voiced_50"},
         "rtf_aggregate": value / 16000.0,
         "rtf_per_stream": dec_rate / B / 16000.0,
+        "ranks": ranks,
+        "distinct_gpus": len({(r["pci_bus_id"], r["uuid"]) for r in ranks}),
         "roofline": {
             "bound": "valu_f32",
             "note": "per-stream latency-bound recurrence; ceiling = FP32 vector rate (157.3 TF = f32 MFMA dense peak); "

@@ -35,3 +35,13 @@ def gather_report(elapsed_s, samples, hist=None, device=None):
         dist.all_reduce(h, op=dist.ReduceOp.SUM)
         out["hist"] = h.cpu().numpy()
     return out
+
+
+def gather_records(record):
+    """every rank's small dict (rank, device identity, shard, elapsed) on every rank, in rank order"""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+        return [record]
+    out = [None] * dist.get_world_size()
+    dist.all_gather_object(out, record)
+    return out

@@ -319,6 +319,32 @@ def test_bench_refuses_a_world_size_that_contradicts_gpus():
     assert r.returncode != 0 and "WORLD_SIZE" in (r.stdout + r.stderr)
 
 
+def test_bench_refuses_more_rccl_ranks_than_gpus():
+    """one process per GPU: under the RCCL backend a world larger than the visible device count must not be folded onto
+    fewer GPUs and reported as an N-GPU line (round-2 review item 7); here no GPU is visible at all"""
+    env = dict(os.environ, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29999")
+    env.pop("FPC_BENCH_BACKEND", None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1"],
+                       env=env, capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 and "visible GPUs" in (r.stdout + r.stderr)
+
+
+def test_traffic_record_is_tied_to_the_kernel_sources():
+    """bench.py takes roofline.traffic only from a PMC record whose kernel_source_sha256 equals the hash of the decode
+    kernel's sources in the tree (a stale record reads null, never an outdated number)"""
+    import json
+    sys.path.insert(0, ROOT)
+    import bench
+    h = bench.decode_kernel_hash()
+    assert len(h) == 64
+    recs = [n for n in os.listdir(os.path.join(ROOT, "profiles")) if n.endswith("_traffic.json")]
+    assert recs
+    tagged = [n for n in recs if "kernel_source_sha256" in json.load(open(os.path.join(ROOT, "profiles", n)))]
+    # round-1/2 records carry no hash and can never match; a record that carries one names a 64-digit hash
+    for n in tagged:
+        assert len(json.load(open(os.path.join(ROOT, "profiles", n)))["kernel_source_sha256"]) == 64
+
+
 def test_wavernn_module_surface_without_gpu(synth):
     """the torch.nn.Module-like surface the reference's scripts touch (synthesis_qtz.py:79-87, train_frame.py:235-250):
     constructor keywords, .to/.cuda/.train/.eval chaining, state_dict round trip, parameters(), strict=False"""
