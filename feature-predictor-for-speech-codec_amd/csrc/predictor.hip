@@ -225,7 +225,7 @@ __device__ __forceinline__ float seg_tree(const float (*p)[3 * MAX_H1], int S, i
 }
 
 // ---- GRU layer: both mat-vecs in one pass over (matrix, row quad, segment) work items ----
-__device__ void gru_rows(const float* __restrict__ wiT, const float* __restrict__ whT,
+__device__ __forceinline__ void gru_rows(const float* __restrict__ wiT, const float* __restrict__ whT,
                          const float* __restrict__ bi, const float* __restrict__ bh,
                          const float* x, int K, const float* h, int H, PredLds& L, int tid, int nsplit = 1, int half = 0,
                          int part = 0 /* 0: both mat-vecs, 1: recurrent only, 2: input only */) {
@@ -249,14 +249,14 @@ __device__ void gru_rows(const float* __restrict__ wiT, const float* __restrict_
     __syncthreads();
 }
 
-__device__ void gru_gates(int K, float* h, int H, PredLds& L, int tid, int nsplit, int half);
-__device__ void gru_layer(const float* __restrict__ wiT, const float* __restrict__ whT,
+__device__ __forceinline__ void gru_gates(int K, float* h, int H, PredLds& L, int tid, int nsplit, int half);
+__device__ __forceinline__ void gru_layer(const float* __restrict__ wiT, const float* __restrict__ whT,
                           const float* __restrict__ bi, const float* __restrict__ bh,
                           const float* x, int K, float* h, int H, PredLds& L, int tid, int nsplit = 1, int half = 0) {
     gru_rows(wiT, whT, bi, bh, x, K, h, H, L, tid, nsplit, half);
     gru_gates(K, h, H, L, tid, nsplit, half);
 }
-__device__ void gru_gates(int K, float* h, int H, PredLds& L, int tid, int nsplit, int half) {
+__device__ __forceinline__ void gru_gates(int K, float* h, int H, PredLds& L, int tid, int nsplit, int half) {
     const int Si = segments(K), Sh = segments(H);
     const int Hh = H / nsplit;
     for (int ii = tid; ii < Hh; ii += NT) {  // torch.nn.GRU gate rows [r; z; n]
@@ -272,7 +272,7 @@ __device__ void gru_gates(int K, float* h, int H, PredLds& L, int tid, int nspli
 }
 
 // one frame of Wavernn.forward: L.x -> L.fo, states in L.h1/L.h2
-__device__ void pred_step(const PredDev& P, PredLds& L, int tid, SplitCtx* X = nullptr) {
+__device__ __forceinline__ void pred_step(const PredDev& P, PredLds& L, int tid, SplitCtx* X = nullptr) {
     if (X && X->n > 1) {  // this workgroup's slice of the units of each GRU, then the slices change hands
         // (GRU2's recurrent product under the first exchange -- two passes of 96 + 288 work items instead of one of 384 on
         //  576 threads -- was measured 5 % slower: the passes stay whole)
