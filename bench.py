@@ -280,7 +280,9 @@ def main():
     torch.cuda.set_device(dev)
     _lib.require_gpu()
     dist = None
-    if world > 1:
+    # FPC_BENCH_FORCE_DIST=1: initialise the process group even for one rank, so that the RCCL code path of the report
+    # (barrier, all_reduce, all_gather_object on device tensors) can be exercised on a one-GPU box
+    if world > 1 or os.environ.get("FPC_BENCH_FORCE_DIST") == "1":
         import torch.distributed as dist
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", dev))

@@ -617,6 +617,32 @@ def test_bench_rank_path_two_ranks_one_gpu(torch_cuda, synth, tmp_path):
         assert np.array_equal(z["pcm"], full[rank * S:(rank + 1) * S])
 
 
+def test_bench_rccl_branch_single_rank(torch_cuda, tmp_path):
+    """the RCCL (`nccl`) branch of bench.py -- process group on the device, barrier, all_reduce of the report,
+    all_gather_object of the rank records -- has no multi-GPU box to run on during the round, so it is executed here with
+    ONE rank through the launcher the driver uses (FPC_BENCH_FORCE_DIST=1): the same calls on device tensors, world size 1"""
+    import json
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sk = socket.socket()
+    sk.bind(("127.0.0.1", 0))
+    port = sk.getsockname()[1]
+    sk.close()
+    env = dict(os.environ, FPC_BENCH_FORCE_DIST="1", MASTER_ADDR="127.0.0.1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "FPC_BENCH_BACKEND"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1",
+                        "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"),
+                        "--gpus", "1", "--steps", "1", "--warmup", "1", "--streams", "8", "--secs", "1", "--no-cpu-baseline"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    j = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert j["n_gpus"] == 1 and j["distinct_gpus"] == 1 and len(j["ranks"]) == 1 and j["ranks"][0]["pci_bus_id"] != "unknown"
+    assert j["e2e"]["ranks"] == 1 and j["e2e"]["utterances"] == 128
+
+
 def test_train_cb_stage_loop_vs_reference_golden(torch_cuda, synth, golden, tmp_path):
     """G10: the batch loop of src/train_cb.py:160-217 re-enacted with the reference's own cb_func (first batch
     vq_train per stage, second batch 10 x update per stage, stage sizes 12 and 6) -- the GPU driver reproduces both
