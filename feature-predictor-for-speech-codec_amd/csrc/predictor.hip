@@ -22,7 +22,18 @@
 
 namespace {
 
-constexpr int NT = 576;  // 9 wave64; 2 x 576 = 1152 gate rows of GRU1
+#ifndef FPC_NT
+#define FPC_NT 576
+#endif
+#ifdef FPC_WAVES_EU
+#define FPC_OCC __attribute__((amdgpu_waves_per_eu(FPC_WAVES_EU, FPC_WAVES_EU)))
+#else
+#define FPC_OCC
+#endif
+#ifndef FPC_CD
+#define FPC_CD 16
+#endif
+constexpr int NT = FPC_NT;  // 9 wave64; 2 x 576 = 1152 gate rows of GRU1
 constexpr int NW = NT / 64;
 constexpr int MAX_H1 = 512, MAX_H2 = 256, MAX_IN = 64, MAX_FC = 32;
 constexpr int NDIM = 17, SURV = 5;
@@ -153,7 +164,20 @@ struct __attribute__((aligned(16))) PredLds {
 #ifdef FPC_VQ_PROF
     long long prof[16];  // diagnostic builds only: cycle stamps of the search phases
 #endif
+#ifdef FPC_PRED_PROF
+    long long pprof[12], plast;  // diagnostic builds only: cycles per phase of the predictor step, summed over frames
+#endif
 };
+#ifdef FPC_PRED_PROF
+#define PSTAMP(k)                                           \
+    if (tid == 0) {                                         \
+        const long long now_ = __builtin_readcyclecounter(); \
+        L.pprof[k] += now_ - L.plast;                       \
+        L.plast = now_;                                     \
+    }
+#else
+#define PSTAMP(k)
+#endif
 #ifdef FPC_VQ_PROF
 #define VQ_STAMP(k) \
     if (tid == 0) L.prof[k] = clock64();
@@ -175,39 +199,101 @@ __device__ __forceinline__ float chain1(const float* __restrict__ wT, const floa
     return a;
 }
 
-// four adjacent rows (r..r+3, R % 4 == 0) advance together: one 16-byte load per k serves 4 chains, CD k
-// in flight per block (dword loads would be bound by the texture-address unit, not by L2)
-constexpr int CD = 16;  // k-steps of 16-byte loads in flight per thread and block
-__device__ __forceinline__ void chain4(const float* __restrict__ wT, const float* v, int K, int R, int r, float4& a) {
-    int k = 0;
-    for (; k + CD <= K; k += CD) {
-        float4 w[CD];
+// four adjacent rows (r..r+3, R % 4 == 0) advance together: one 16-byte load per k serves 4 chains (dword loads
+// would be bound by the texture-address unit, not by L2).  The loads run as a ROLLING WINDOW of CD k-steps: a
+// register is refilled with k + CD as soon as k has been used, so CD - 1 loads stay in flight for the whole chain
+// (a block that loads CD, waits for all and then computes pays one L2 round trip per block: 6 per 96-long chain,
+// measured 1 400-1 750 cycles each, and the CU's L2 port idles meanwhile).  Same k order: same bits.
+constexpr int CD = FPC_CD;  // k-steps of 16-byte loads in flight per thread (multiple of 4)
+// (the loads and their waits are written out: left to itself the scheduler gathers the window's loads behind one
+//  full wait again.  The compiler does not count these loads, so every use of a window register goes through
+//  landed<N>(): s_waitcnt vmcnt(N) with the register as an operand, N = the loads issued after the one awaited;
+//  loads return in order, and the compiler's own waits can only be stricter than it thinks.)
+typedef float v4f __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ v4f ld4(const float* q) {
+    v4f r;
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(r) : "v"(q));
+    return r;
+}
+// the same load, placed after the fmaf's that produced a (instruction selection is otherwise free to sink the
+// arithmetic below later loads and to keep a second set of window registers alive for it)
+__device__ __forceinline__ v4f ld4_after(const float* q, const float4& a) {
+    v4f r;
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(r) : "v"(q), "v"(a.x), "v"(a.y), "v"(a.z), "v"(a.w));
+    return r;
+}
+template <int N>
+__device__ __forceinline__ void landed(v4f& w) {
+    asm volatile("s_waitcnt vmcnt(%1)" : "+v"(w) : "n"(N));
+}
+__device__ __forceinline__ void fma4(float4& a, float hv, const v4f& w) {
+    a.x = fmaf(hv, w.x, a.x);
+    a.y = fmaf(hv, w.y, a.y);
+    a.z = fmaf(hv, w.z, a.z);
+    a.w = fmaf(hv, w.w, a.w);
+}
+constexpr int CT = 4;  // tail loads that go out before the last window is consumed (K = 20: 16 + 4)
+template <int J = 0>
+__device__ __forceinline__ void last_window(float4& a, const float (&hv)[CD], v4f (&w)[CD]) {
+    if constexpr (J < CD) {
+        landed<CD - 1 - J>(w[J]);  // (tail loads behind it only make the wait stricter)
+        fma4(a, hv[J], w[J]);
+        last_window<J + 1>(a, hv, w);
+    }
+}
+// a: the chain's start value, possibly still in flight (ld4 of the bias issued by the caller just before)
+__device__ __forceinline__ void chain4(const float* __restrict__ wT, const float* v, int K, int R, int r, v4f& a0,
+                                       float4& a) {
+    const float* q = wT + r;  // ONE running address, advanced by a row per load (the loads go out in k order)
+    const int nb = K / CD;
+    int rem = K - nb * CD;  // full windows, tail
+    v4f w[CD], wt[CT];
+    float hv[CD];
+    if (nb > 0) {
 #pragma unroll
-        for (int j = 0; j < CD; ++j) w[j] = *reinterpret_cast<const float4*>(&wT[(size_t)(k + j) * R + r]);
+        for (int j = 0; j < CD; ++j, q += R) w[j] = ld4(q);
+    }
+    if (nb > 0)
+        landed<CD - 1>(a0);  // (in order: the start value has landed when all but the youngest CD - 1 loads have)
+    else
+        landed<0>(a0);
+    a = make_float4(a0.x, a0.y, a0.z, a0.w);
+    for (int b = 0; b + 1 < nb; ++b, v += CD) {
 #pragma unroll
-        for (int j = 0; j < CD; ++j) {
-            const float hv = v[k + j];
-            a.x = fmaf(hv, w[j].x, a.x);
-            a.y = fmaf(hv, w[j].y, a.y);
-            a.z = fmaf(hv, w[j].z, a.z);
-            a.w = fmaf(hv, w[j].w, a.w);
+        for (int j = 0; j < CD; ++j) hv[j] = v[j];
+#pragma unroll
+        for (int j = 0; j < CD; ++j, q += R) {
+            landed<CD - 1>(w[j]);
+            fma4(a, hv[j], w[j]);
+            w[j] = ld4_after(q, a);
         }
     }
-    int rem = K - k;  // tail (e.g. K = 20): all remaining loads in flight together
-    if (rem > 0) {
-        float4 w[CD - 1];
+    const int t0 = rem < CT ? rem : CT;
 #pragma unroll
-        for (int j = 0; j < CD - 1; ++j)
-            if (j < rem) w[j] = *reinterpret_cast<const float4*>(&wT[(size_t)(k + j) * R + r]);
+    for (int j = 0; j < CT; ++j)
+        if (j < t0) wt[j] = ld4(q + (size_t)j * R);
+    q += (size_t)t0 * R;
+    if (nb > 0) {
 #pragma unroll
-        for (int j = 0; j < CD - 1; ++j)
+        for (int j = 0; j < CD; ++j) hv[j] = v[j];
+        last_window(a, hv, w);
+        v += CD;
+    }
+    while (rem > 0) {  // (more than CT left over: one round trip per further CT -- no shipped size has that)
+#pragma unroll
+        for (int j = 0; j < CT; ++j)
             if (j < rem) {
-                const float hv = v[k + j];
-                a.x = fmaf(hv, w[j].x, a.x);
-                a.y = fmaf(hv, w[j].y, a.y);
-                a.z = fmaf(hv, w[j].z, a.z);
-                a.w = fmaf(hv, w[j].w, a.w);
+                landed<0>(wt[j]);
+                fma4(a, v[j], wt[j]);
             }
+        rem -= CT;
+        v += CT;
+        if (rem > 0) {
+#pragma unroll
+            for (int j = 0; j < CT; ++j)
+                if (j < rem) wt[j] = ld4(q + (size_t)j * R);
+            q += (size_t)CT * R;
+        }
     }
 }
 
@@ -241,9 +327,10 @@ __device__ __forceinline__ void gru_rows(const float* __restrict__ wiT, const fl
         const int q = j % Q, sg = j / Q;  // consecutive threads -> adjacent row quads: coalesced 16-byte loads
         const int gate = q / Qg, qq = q - gate * Qg;
         const int len = (is_h ? H : K) / (is_h ? Sh : Si), k0 = sg * len, r = gate * H + 4 * (half * Qg + qq);
-        float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (sg == 0) a = *reinterpret_cast<const float4*>(&(is_h ? bh : bi)[r]);
-        chain4((is_h ? whT : wiT) + (size_t)k0 * R, (is_h ? h : x) + k0, len, R, r, a);
+        v4f a0 = {0.f, 0.f, 0.f, 0.f};
+        if (sg == 0) a0 = ld4(&(is_h ? bh : bi)[r]);
+        float4 a;
+        chain4((is_h ? whT : wiT) + (size_t)k0 * R, (is_h ? h : x) + k0, len, R, r, a0, a);
         *reinterpret_cast<float4*>(&(is_h ? L.ph : L.pi)[sg][r]) = a;
     }
     __syncthreads();
@@ -276,10 +363,19 @@ __device__ __forceinline__ void pred_step(const PredDev& P, PredLds& L, int tid,
     if (X && X->n > 1) {  // this workgroup's slice of the units of each GRU, then the slices change hands
         // (GRU2's recurrent product under the first exchange -- two passes of 96 + 288 work items instead of one of 384 on
         //  576 threads -- was measured 5 % slower: the passes stay whole)
-        gru_layer(P.w1i, P.w1h, P.b1i, P.b1h, L.x, P.in, L.h1, P.h1, L, tid, X->n, X->half);
+        PSTAMP(0)
+        gru_rows(P.w1i, P.w1h, P.b1i, P.b1h, L.x, P.in, L.h1, P.h1, L, tid, X->n, X->half);
+        PSTAMP(1)
+        gru_gates(P.in, L.h1, P.h1, L, tid, X->n, X->half);
+        PSTAMP(2)
         exchange_halves(L.h1, P.h1, *X, X->g1, tid);
-        gru_layer(P.w2i, P.w2h, P.b2i, P.b2h, L.h1, P.h1, L.h2, P.h2, L, tid, X->n, X->half);
+        PSTAMP(3)
+        gru_rows(P.w2i, P.w2h, P.b2i, P.b2h, L.h1, P.h1, L.h2, P.h2, L, tid, X->n, X->half);
+        PSTAMP(4)
+        gru_gates(P.h1, L.h2, P.h2, L, tid, X->n, X->half);
+        PSTAMP(5)
         exchange_halves(L.h2, P.h2, *X, X->g2, tid);
+        PSTAMP(6)
     } else {
         gru_layer(P.w1i, P.w1h, P.b1i, P.b1h, L.x, P.in, L.h1, P.h1, L, tid);
         gru_layer(P.w2i, P.w2h, P.b2i, P.b2h, L.h1, P.h1, L.h2, P.h2, L, tid);
@@ -302,6 +398,7 @@ __device__ __forceinline__ void pred_step(const PredDev& P, PredLds& L, int tid,
         L.fo[tid] = t + t;  // the "dual" FC is the same Linear summed twice (wavernn.py:89-92)
     }
     __syncthreads();
+    PSTAMP(7)
 }
 
 // ---- float64 squared distance with numpy's pairwise association (vq_func.py:18) ----
@@ -736,7 +833,7 @@ __device__ __forceinline__ SplitCtx split_ctx(const SplitArgs& S, const PredDev&
     return X;
 }
 
-__global__ __launch_bounds__(NT) void k_forward(const PredDev P, const float* __restrict__ x, int Lf,
+__global__ __launch_bounds__(NT) FPC_OCC void k_forward(const PredDev P, const float* __restrict__ x, int Lf,
                                                 float* h1, float* h2, float* __restrict__ y, const SplitArgs S) {
     __shared__ PredLds L;
     const int b = blockIdx.x / S.n, half = blockIdx.x % S.n, tid = threadIdx.x;
@@ -746,6 +843,12 @@ __global__ __launch_bounds__(NT) void k_forward(const PredDev P, const float* __
     for (int i = tid; i < P.h2; i += NT) L.h2[i] = h2[(size_t)b * P.h2 + i];
     __syncthreads();
     int t = 0;
+#ifdef FPC_PRED_PROF
+    if (tid == 0) {
+        for (int i = 0; i < 12; ++i) L.pprof[i] = 0;
+        L.plast = __builtin_readcyclecounter();
+    }
+#endif
     for (; t < Lf; ++t) {
         if (tid < P.in) L.x[tid] = x[((size_t)b * Lf + t) * P.in + tid];
         __syncthreads();
@@ -754,6 +857,10 @@ __global__ __launch_bounds__(NT) void k_forward(const PredDev P, const float* __
         if (writer && tid < P.fc) y[((size_t)b * Lf + t) * P.fc + tid] = L.fo[tid];
     }
     __syncthreads();
+#ifdef FPC_PRED_PROF
+    if (tid == 0 && blockIdx.x == gridDim.x / 2)
+        for (int i = 0; i < 8; ++i) S.err[1 + i] = (unsigned)(L.pprof[i] / (Lf > 0 ? Lf : 1));
+#endif
     if (X.dead) {  // fail loudly: NaN from this frame on, NaN states; the host reports FPC_ERR_TIMEOUT
         if (writer) {
             const float qnan = __uint_as_float(0x7fc00000u);
@@ -780,7 +887,7 @@ struct EncArgs {
     unsigned long long* hist;
 };
 
-__global__ __launch_bounds__(NT) void k_encode(const PredDev P, const CbDev C, const EncArgs A, const SplitArgs S) {
+__global__ __launch_bounds__(NT) FPC_OCC void k_encode(const PredDev P, const CbDev C, const EncArgs A, const SplitArgs S) {
     __shared__ PredLds L;
     const int b = blockIdx.x / S.n, half = blockIdx.x % S.n, tid = threadIdx.x;
     SplitCtx X = split_ctx(S, P, b, half);
@@ -901,7 +1008,7 @@ __global__ __launch_bounds__(NT) void k_encode(const PredDev P, const CbDev C, c
 // receiver side of k_encode: the same predictor steps, the residual looked up from the transmitted symbols
 // (float64 entry sums narrowed to float32 exactly as the encoder does), so c_out equals the encoder's c_in.
 // A symbol outside its codebook sets *bad and decodes as "not coded".
-__global__ __launch_bounds__(NT) void k_decode_feat(const PredDev P, const CbDev C, const float* __restrict__ pitch,
+__global__ __launch_bounds__(NT) FPC_OCC void k_decode_feat(const PredDev P, const CbDev C, const float* __restrict__ pitch,
                                                     const int* __restrict__ idx, int Lf, float* __restrict__ c_out,
                                                     int* bad, const SplitArgs S) {
     __shared__ PredLds L;
@@ -1139,8 +1246,9 @@ __device__ __forceinline__ void tprod_items(const float* __restrict__ W, const f
     // (row split: this workgroup's slice of the output columns k; every chain is the one of the unsplit form)
     const int Qs = cols / 4 / nsplit, S = segments(rows), len = rows / S;
     const int q = half * Qs + item % Qs, sg = item / Qs;
-    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
-    chain4(W + (size_t)sg * len * cols, d + sg * len, len, cols, 4 * q, a);
+    v4f a0 = {0.f, 0.f, 0.f, 0.f};
+    float4 a;
+    chain4(W + (size_t)sg * len * cols, d + sg * len, len, cols, 4 * q, a0, a);
     *reinterpret_cast<float4*>(&part[sg][4 * q]) = a;
 }
 __device__ __forceinline__ float tree4(const float (*p)[MAX_H1], int S, int k) {
@@ -1546,6 +1654,14 @@ extern "C" int fpc_predictor_forward(fpc_predictor* p, const float* x_dev, int B
     hipLaunchKernelGGL(k_forward, dim3(B * sp.n), dim3(NT), 0, static_cast<hipStream_t>(s), p->d, x_dev, L,
                        h1_dev, h2_dev, y_dev, sp);
     FPC_HIP(hipGetLastError());
+#ifdef FPC_PRED_PROF
+    (void)hipStreamSynchronize(static_cast<hipStream_t>(s));
+    {
+        const volatile unsigned* w = (const volatile unsigned*)p->status_host;
+        fprintf(stderr, "k_forward B=%d n=%d cycles/frame: next-x %u | rows1 %u gates1 %u xchg1 %u | rows2 %u gates2 %u xchg2 %u | fc %u\n",
+                B, sp.n, w[1], w[2], w[3], w[4], w[5], w[6], w[7], w[8]);
+    }
+#endif
     return after_launch(p, static_cast<hipStream_t>(s));
 }
 
