@@ -86,6 +86,35 @@ __device__ __forceinline__ void publish_slice(const float* h, int H, SplitCtx& X
     if (X.withhold) return;    // (test hook: the partners' spins must time out)
     for (int i = tid; i < Hs; i += NT) store_granule(&g[mine + i], epoch, h[mine + i]);
 }
+// wait for the value tagged `epoch` in granule *g (NaN if the wait is given up or the workgroup is already dead)
+__device__ __forceinline__ float await_granule(unsigned long long* g, unsigned epoch, SplitCtx& X, bool& gave_up) {
+    unsigned long long x = 0x7fc00000ull;  // NaN unless the partner's value arrives: poisons everything downstream
+    unsigned spins = 0;
+    unsigned long long t0 = 0;
+    while (!X.dead) {
+        const unsigned long long v = __hip_atomic_load((gu64*)g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((unsigned)(v >> 32) == epoch) {
+            x = v;
+            break;
+        }
+        // every 64 polls (~10-100 us): has the partner been missing for X.limit of wall clock, or has another
+        // workgroup already given up?  Then stop waiting, here and from now on -- the launch must end quickly
+        // and loudly, never hang the GPU
+        if ((++spins & 63u) == 0) {
+            const unsigned long long now = __builtin_amdgcn_s_memrealtime();
+            if (t0 == 0) t0 = now;
+            if (now - t0 > X.limit || (status_load(X.err) & FPC_ST_TIMEOUT) != 0u) {
+                status_or(X.err, FPC_ST_TIMEOUT);
+                gave_up = true;
+                break;
+            }
+        }
+#ifndef FPC_XCHG_NOSLEEP
+        __builtin_amdgcn_s_sleep(1);
+#endif
+    }
+    return __uint_as_float((unsigned)x);
+}
 // ... and pick every other slice of that epoch up (ends with a barrier); independent work may sit between the two
 __device__ __forceinline__ void consume_slices(float* h, int H, SplitCtx& X, unsigned long long* g, int tid) {
     const int Hs = H / X.n, mine = X.half * Hs;  // this workgroup's slice of the units; every other slice is read
@@ -93,32 +122,7 @@ __device__ __forceinline__ void consume_slices(float* h, int H, SplitCtx& X, uns
     bool gave_up = false;
     for (int ii = tid; ii < H - Hs; ii += NT) {
         const int i = ii < mine ? ii : ii + Hs;
-        unsigned long long x = 0x7fc00000ull;  // NaN unless the partner's value arrives: poisons everything downstream
-        unsigned spins = 0;
-        unsigned long long t0 = 0;
-        while (!X.dead) {
-            const unsigned long long v = __hip_atomic_load((gu64*)&g[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if ((unsigned)(v >> 32) == epoch) {
-                x = v;
-                break;
-            }
-            // every 64 polls (~10-100 us): has the partner been missing for X.limit of wall clock, or has another
-            // workgroup already given up?  Then stop waiting, here and from now on -- the launch must end quickly
-            // and loudly, never hang the GPU
-            if ((++spins & 63u) == 0) {
-                const unsigned long long now = __builtin_amdgcn_s_memrealtime();
-                if (t0 == 0) t0 = now;
-                if (now - t0 > X.limit || (status_load(X.err) & FPC_ST_TIMEOUT) != 0u) {
-                    status_or(X.err, FPC_ST_TIMEOUT);
-                    gave_up = true;
-                    break;
-                }
-            }
-#ifndef FPC_XCHG_NOSLEEP
-            __builtin_amdgcn_s_sleep(1);
-#endif
-        }
-        h[i] = __uint_as_float((unsigned)x);
+        h[i] = await_granule(&g[i], epoch, X, gave_up);
     }
     if (__syncthreads_or(gave_up)) X.dead = true;
 }
@@ -141,16 +145,9 @@ struct CbDev {
     const double *scl_hi, *scl_lo;
 };
 
-struct __attribute__((aligned(16))) PredLds {
-    float x[MAX_IN];
-    float h1[MAX_H1];
-    float h2[MAX_H2];
-    float pi[4][3 * MAX_H1];  // segment sums of the input mat-vec rows [segment][row]
-    float ph[4][3 * MAX_H1];  // ... of the recurrent mat-vec rows
-    float pf[8][MAX_FC];      // ... of the output layer
-    float relu[MAX_H2];
-    float fo[MAX_FC];
-    float rs[MAX_FC];
+// scratch of the residual searches (one utterance at a time)
+struct __attribute__((aligned(16))) SearchLds {
+    float rs[MAX_FC];           // residual of the frame: rs[0] scalar, rs[1..17] the VQ target
     double xq[SURV][NDIM];      // search targets (stage 1: xq[0]; stage 2: 5 residuals)
     double wd[SURV][NW][SURV];  // per-wave M-best lists
     int wi[SURV][NW][SURV];
@@ -164,10 +161,26 @@ struct __attribute__((aligned(16))) PredLds {
 #ifdef FPC_VQ_PROF
     long long prof[16];  // diagnostic builds only: cycle stamps of the search phases
 #endif
+};
+struct __attribute__((aligned(16))) PredLds : SearchLds {
+    float x[MAX_IN];
+    float h1[MAX_H1];
+    float h2[MAX_H2];
+    float pi[4][3 * MAX_H1];  // segment sums of the input mat-vec rows [segment][row]
+    float ph[4][3 * MAX_H1];  // ... of the recurrent mat-vec rows
+    float pf[8][MAX_FC];      // ... of the output layer
+    float relu[MAX_H2];
+    float fo[MAX_FC];
 #ifdef FPC_PRED_PROF
     long long pprof[12], plast;  // diagnostic builds only: cycles per phase of the predictor step, summed over frames
 #endif
 };
+#ifdef FPC_VQ_PROF
+#define VQ_STAMP(k) \
+    if (tid == 0) L.prof[k] = clock64();
+#else
+#define VQ_STAMP(k)
+#endif
 #ifdef FPC_PRED_PROF
 #define PSTAMP(k)                                           \
     if (tid == 0) {                                         \
@@ -483,7 +496,7 @@ __device__ __forceinline__ void wave_argmin(double& d, int& i) {
 }
 
 // per-wave M-best (5 smallest by (distance, index)) of search `srch` -> L.wd/L.wi
-__device__ void wave_mbest(PredLds& L, int srch, const double* __restrict__ cbT, int N, int tid) {
+__device__ void wave_mbest(SearchLds& L, int srch, const double* __restrict__ cbT, int N, int tid) {
     const int wave = tid >> 6, lane = tid & 63;
     double d5[SURV];
     int i5[SURV];
@@ -529,7 +542,7 @@ __device__ void wave_mbest(PredLds& L, int srch, const double* __restrict__ cbT,
 }
 
 // merge the per-wave lists of search `srch` (executed by ONE wave) -> L.od/L.oi
-__device__ void merge_mbest(PredLds& L, int srch, int lane) {
+__device__ void merge_mbest(SearchLds& L, int srch, int lane) {
     double d = INFINITY;
     int ix = 0x7fffffff;
     if (lane < NW * SURV) {
@@ -559,7 +572,7 @@ __device__ void merge_mbest(PredLds& L, int srch, int lane) {
 // stage 2, whose merge-insert (:110-125) only ever returns the path at position 0 = the smallest total error,
 // earlier survivors winning ties (strict <).
 template <int T>
-__device__ __forceinline__ void block_argmin(PredLds& L, const double* __restrict__ cbT, int N, int tid) {
+__device__ __forceinline__ void block_argmin(SearchLds& L, const double* __restrict__ cbT, int N, int tid) {
     // N <= 2 * NT: a thread owns entries tid and tid + NT; their coordinates stay in registers across the targets
     const int wave = tid >> 6, lane = tid & 63;
     const int e0 = tid, e1 = tid + NT;
@@ -625,7 +638,7 @@ __device__ __forceinline__ void block_argmin(PredLds& L, const double* __restric
 
 // stage-1 M-best of a stage of <= 2 * NT entries: a thread owns entries tid and tid + NT (coordinates loaded
 // together), its sorted pair feeds the per-wave rounds -> L.wd/L.wi[0]; merge_mbest(L, 0, .) finishes
-__device__ __forceinline__ void wave_mbest2(PredLds& L, const double* __restrict__ cbT, int N, int tid) {
+__device__ __forceinline__ void wave_mbest2(SearchLds& L, const double* __restrict__ cbT, int N, int tid) {
     const int wave = tid >> 6, lane = tid & 63;
     const int e0 = tid, e1 = tid + NT;
     const bool has0 = e0 < N, has1 = e1 < N;
@@ -685,7 +698,7 @@ __device__ __forceinline__ void wave_mbest2(PredLds& L, const double* __restrict
 
 // quantize_mstage (vq_func.py:82-131) on L.rs[1..17]; result in L.qv, L.res_i[0..1].
 // Block-uniform control flow; ends with a barrier.
-__device__ __forceinline__ void vq_mstage(PredLds& L, int S, const double* cb0T, const double* cb0R, int N0,
+__device__ __forceinline__ void vq_mstage(SearchLds& L, int S, const double* cb0T, const double* cb0R, int N0,
                           const double* cb1T, const double* cb1R, int N1, int tid) {
     const int wave = tid >> 6, lane = tid & 63;
     VQ_STAMP(0)
@@ -756,7 +769,7 @@ __device__ __forceinline__ void vq_mstage(PredLds& L, int S, const double* cb0T,
 }
 
 // scl_quantize (vq_func.py:167-185): first arg-min of (x-c)^2 in float64 -> L.qs, L.res_i[2]
-__device__ void scl_search(PredLds& L, float xv, const double* __restrict__ codes, int n, int tid) {
+__device__ void scl_search(SearchLds& L, float xv, const double* __restrict__ codes, int n, int tid) {
     const int wave = tid >> 6, lane = tid & 63;
     double bd = INFINITY;
     int bi = 0x7fffffff;
@@ -887,121 +900,177 @@ struct EncArgs {
     unsigned long long* hist;
 };
 
+// The frame's tail of Wavernn.encoder for ONE utterance (wavernn.py:196-252), run by the whole workgroup: residual of the
+// prediction fo[0..F), thresholds, searches, outputs of frame fi (stored when `store`), next input -> xn[0..Cc).
+// Ends with a barrier.
+__device__ __forceinline__ void encode_frame(SearchLds& L, const float* fo, float* xn, const PredDev& P, const CbDev& C,
+                                             const EncArgs& A, unsigned* err, size_t fi, bool store, int tid) {
+    const int Cc = P.in, F = P.fc;
+    const int off_sl = C.n_hi, off_v0 = off_sl + C.n_lo, off_v1 = off_v0 + C.N_hi0,
+              off_vl = off_v1 + (C.S_hi == 2 ? C.N_hi1 : 0);
+    const float* f = A.feat + fi * Cc;
+    if (tid < F) L.rs[tid] = f[tid] - fo[tid];  // :196
+    __syncthreads();
+    float sabs = 0.0f;
+    for (int d = 1; d < F; ++d) sabs += fabsf(L.rs[d]);
+    const int i1 = fabsf(L.rs[0]) > A.l1;  // :202
+    const int i2 = sabs > A.l2;            // :206
+    // a NaN / infinite residual (non-finite features or weights) has no nearest entry: the arg-min would come back
+    // as 0x7fffffff and be used as an address.  Such a frame is not searched: status bit 1, symbols -2
+    // (every thread evaluates the same LDS values: workgroup-uniform without a barrier)
+    const bool nonfinite = !(fabsf(L.rs[0]) <= 3.0e38f) || !(sabs <= 3.0e38f);
+    if (nonfinite && A.qtz && tid == 0 && store) status_or(err, FPC_ST_NONFINITE);
+    float rq = 0.0f;                       // this thread's r_qtz[d] (tid < F)
+    int ix0 = -1, ix1 = -1, ix2 = -1, ix3 = -1;
+    if (nonfinite) ix0 = ix1 = ix2 = ix3 = -2;
+    if (A.qtz && !nonfinite) {
+        if (i1 || C.scl_lo) {  // :218-225
+            scl_search(L, L.rs[0], i1 ? C.scl_hi : C.scl_lo, i1 ? C.n_hi : C.n_lo, tid);
+            if (tid == 0) {
+                rq = (float)L.qs;
+                ix0 = L.res_i[2] + (i1 ? 0 : C.n_hi);
+                if (A.hist && store) atomicAdd(&A.hist[(i1 ? 0 : off_sl) + L.res_i[2]], 1ull);
+            }
+        }
+        if (i2 || C.vq_lo) {  // :229-240: above the threshold the 1- or 2-stage book, below it the 1-stage one
+            // (one call site: the search is one copy of code, inlined with global pointers)
+            vq_mstage(L, i2 ? C.S_hi : 1, i2 ? C.vq_hi0 : C.vq_lo, i2 ? C.vq_hi0_r : C.vq_lo_r,
+                      i2 ? C.N_hi0 : C.N_lo, i2 ? C.vq_hi1 : nullptr, i2 ? C.vq_hi1_r : nullptr,
+                      i2 ? C.N_hi1 : 0, tid);
+            if (tid >= 1 && tid < F) rq = (float)L.qv[tid - 1];
+            if (tid == 0) {
+                if (i2) {
+                    ix1 = L.res_i[0];
+                    ix2 = L.res_i[1];
+                    if (A.hist && store) {
+                        atomicAdd(&A.hist[off_v0 + ix1], 1ull);
+                        if (C.S_hi == 2) atomicAdd(&A.hist[off_v1 + ix2], 1ull);
+                    }
+                } else {
+                    ix3 = L.res_i[0];
+                    if (A.hist && store) atomicAdd(&A.hist[off_vl + ix3], 1ull);
+                }
+            }
+        }
+    }
+    if (tid < F) {
+        const float rs = L.rs[tid];
+        const int ind = tid == 0 ? i1 : i2;
+        float rv, ru, cn;
+        if (A.qtz) {
+            rv = rs;  // un-thresholded residual (:197)
+            ru = 0.0f;
+            cn = fo[tid] + rq;  // :242
+        } else {                  // :244-252
+            ru = rs * (float)(1 - ind);
+            rv = rs * (float)ind;
+            cn = fo[tid] + rv;
+        }
+        if (store) {
+            A.r[fi * F + tid] = rv;
+            A.r_qtz[fi * F + tid] = rq;
+            A.r_under[fi * F + tid] = ru;
+            A.c_in[fi * Cc + tid] = cn;
+        }
+        xn[tid] = cn;
+    } else if (tid < Cc) {  // pitch columns pass through (:178)
+        const float v = f[tid];
+        if (store) A.c_in[fi * Cc + tid] = v;
+        xn[tid] = v;
+    }
+    if (tid == 0 && store) {
+        A.ind1[fi] = (float)i1;
+        A.ind2[fi] = (float)i2;
+        if (A.idx) {
+            A.idx[fi * 4 + 0] = ix0;
+            A.idx[fi * 4 + 1] = ix1;
+            A.idx[fi * 4 + 2] = ix2;
+            A.idx[fi * 4 + 3] = ix3;
+        }
+    }
+    __syncthreads();
+}
+// a launch that gave up at frame i0 fails loudly: NaN and symbols -2 from that frame on for utterance b (the histograms
+// are not touched any more); the host reports FPC_ERR_TIMEOUT
+__device__ __forceinline__ void encode_poison(const PredDev& P, const EncArgs& A, int b, int i0, int tid) {
+    const int Cc = P.in, F = P.fc;
+    const float qnan = __uint_as_float(0x7fc00000u);
+    for (size_t k = (size_t)i0 * F + tid; k < (size_t)A.Lf * F; k += NT) {
+        const size_t o = (size_t)b * A.Lf * F + k;
+        A.r[o] = qnan;
+        A.r_qtz[o] = qnan;
+        A.r_under[o] = qnan;
+    }
+    for (size_t k = (size_t)i0 * Cc + tid; k < (size_t)A.Lf * Cc; k += NT) A.c_in[(size_t)b * A.Lf * Cc + k] = qnan;
+    for (size_t k = (size_t)i0 + tid; k < (size_t)A.Lf; k += NT) {
+        const size_t o = (size_t)b * A.Lf + k;
+        A.ind1[o] = qnan;
+        A.ind2[o] = qnan;
+        if (A.idx)
+            for (int c = 0; c < 4; ++c) A.idx[o * 4 + c] = -2;
+    }
+}
+
 __global__ __launch_bounds__(NT) FPC_OCC void k_encode(const PredDev P, const CbDev C, const EncArgs A, const SplitArgs S) {
     __shared__ PredLds L;
     const int b = blockIdx.x / S.n, half = blockIdx.x % S.n, tid = threadIdx.x;
     SplitCtx X = split_ctx(S, P, b, half);
     const bool writer = half == 0;  // both halves run the same closed loop on the same bits; one stores the outputs
-    const int Cc = P.in, F = P.fc;
     for (int i = tid; i < P.h1; i += NT) L.h1[i] = 0.0f;  // h=None -> zeros (wavernn.py:182)
     for (int i = tid; i < P.h2; i += NT) L.h2[i] = 0.0f;
-    if (tid < Cc) L.x[tid] = 0.0f;  // c_in[:,0,:] is all zero (wavernn.py:177-178)
+    if (tid < P.in) L.x[tid] = 0.0f;  // c_in[:,0,:] is all zero (wavernn.py:177-178)
     __syncthreads();
-    const int off_sl = C.n_hi, off_v0 = off_sl + C.n_lo, off_v1 = off_v0 + C.N_hi0,
-              off_vl = off_v1 + (C.S_hi == 2 ? C.N_hi1 : 0);
     int i = 0;
     for (; i < A.Lf; ++i) {
-        const size_t fi = (size_t)b * A.Lf + i;
-        const float* f = A.feat + fi * Cc;
         pred_step(P, L, tid, &X);  // wavernn.py:194-195
         if (X.dead) break;         // (workgroup-uniform) a spin of the row split gave up
-        if (tid < F) L.rs[tid] = f[tid] - L.fo[tid];  // :196
-        __syncthreads();
-        float sabs = 0.0f;
-        for (int d = 1; d < F; ++d) sabs += fabsf(L.rs[d]);
-        const int i1 = fabsf(L.rs[0]) > A.l1;  // :202
-        const int i2 = sabs > A.l2;            // :206
-        // a NaN / infinite residual (non-finite features or weights) has no nearest entry: the arg-min would come back
-        // as 0x7fffffff and be used as an address.  Such a frame is not searched: status bit 1, symbols -2
-        // (every thread evaluates the same LDS values: workgroup-uniform without a barrier)
-        const bool nonfinite = !(fabsf(L.rs[0]) <= 3.0e38f) || !(sabs <= 3.0e38f);
-        if (nonfinite && A.qtz && tid == 0 && writer) status_or(S.err, FPC_ST_NONFINITE);
-        float rq = 0.0f;                       // this thread's r_qtz[d] (tid < F)
-        int ix0 = -1, ix1 = -1, ix2 = -1, ix3 = -1;
-        if (nonfinite) ix0 = ix1 = ix2 = ix3 = -2;
-        if (A.qtz && !nonfinite) {
-            if (i1 || C.scl_lo) {  // :218-225
-                scl_search(L, L.rs[0], i1 ? C.scl_hi : C.scl_lo, i1 ? C.n_hi : C.n_lo, tid);
-                if (tid == 0) {
-                    rq = (float)L.qs;
-                    ix0 = L.res_i[2] + (i1 ? 0 : C.n_hi);
-                    if (A.hist && writer) atomicAdd(&A.hist[(i1 ? 0 : off_sl) + L.res_i[2]], 1ull);
-                }
-            }
-            if (i2 || C.vq_lo) {  // :229-240: above the threshold the 1- or 2-stage book, below it the 1-stage one
-                // (one call site: the search is one copy of code, inlined with global pointers)
-                vq_mstage(L, i2 ? C.S_hi : 1, i2 ? C.vq_hi0 : C.vq_lo, i2 ? C.vq_hi0_r : C.vq_lo_r,
-                          i2 ? C.N_hi0 : C.N_lo, i2 ? C.vq_hi1 : nullptr, i2 ? C.vq_hi1_r : nullptr,
-                          i2 ? C.N_hi1 : 0, tid);
-                if (tid >= 1 && tid < F) rq = (float)L.qv[tid - 1];
-                if (tid == 0) {
-                    if (i2) {
-                        ix1 = L.res_i[0];
-                        ix2 = L.res_i[1];
-                        if (A.hist && writer) {
-                            atomicAdd(&A.hist[off_v0 + ix1], 1ull);
-                            if (C.S_hi == 2) atomicAdd(&A.hist[off_v1 + ix2], 1ull);
-                        }
-                    } else {
-                        ix3 = L.res_i[0];
-                        if (A.hist && writer) atomicAdd(&A.hist[off_vl + ix3], 1ull);
-                    }
-                }
-            }
-        }
-        if (tid < F) {
-            const float rs = L.rs[tid];
-            const int ind = tid == 0 ? i1 : i2;
-            float rv, ru, cn;
-            if (A.qtz) {
-                rv = rs;  // un-thresholded residual (:197)
-                ru = 0.0f;
-                cn = L.fo[tid] + rq;  // :242
-            } else {                  // :244-252
-                ru = rs * (float)(1 - ind);
-                rv = rs * (float)ind;
-                cn = L.fo[tid] + rv;
-            }
-            if (writer) {
-                A.r[fi * F + tid] = rv;
-                A.r_qtz[fi * F + tid] = rq;
-                A.r_under[fi * F + tid] = ru;
-                A.c_in[fi * Cc + tid] = cn;
-            }
-            L.x[tid] = cn;
-        } else if (tid < Cc) {  // pitch columns pass through (:178)
-            const float v = f[tid];
-            if (writer) A.c_in[fi * Cc + tid] = v;
-            L.x[tid] = v;
-        }
-        if (tid == 0 && writer) {
-            A.ind1[fi] = (float)i1;
-            A.ind2[fi] = (float)i2;
-            if (A.idx) {
-                A.idx[fi * 4 + 0] = ix0;
-                A.idx[fi * 4 + 1] = ix1;
-                A.idx[fi * 4 + 2] = ix2;
-                A.idx[fi * 4 + 3] = ix3;
-            }
-        }
-        __syncthreads();
+        encode_frame(L, L.fo, L.x, P, C, A, S.err, (size_t)b * A.Lf + i, writer, tid);
     }
-    if (X.dead && writer) {  // fail loudly: NaN and symbols -2 from this frame on (the histograms are not touched any
-        const float qnan = __uint_as_float(0x7fc00000u);  // more); the host reports FPC_ERR_TIMEOUT
-        for (size_t k = (size_t)i * F + tid; k < (size_t)A.Lf * F; k += NT) {
-            const size_t o = (size_t)b * A.Lf * F + k;
-            A.r[o] = qnan;
-            A.r_qtz[o] = qnan;
-            A.r_under[o] = qnan;
+    if (X.dead && writer) encode_poison(P, A, b, i, tid);
+}
+
+// the receiver's frame tail for one utterance: threads (c < Cc) of one wave (k_decode_feat)
+__device__ __forceinline__ void decode_frame(const float* fo, float* xn, const PredDev& P, const CbDev& C,
+                                             const float* __restrict__ pitch, const int* __restrict__ idx,
+                                             float* __restrict__ c_out, int* bad, size_t fi, bool store, int c) {
+    const int Cc = P.in, F = P.fc;
+    if (c < F) {
+        const int* ix = idx + fi * 4;
+        float rq = 0.0f;
+        if (c == 0) {
+            const int k = ix[0];
+            if (k >= 0) {
+                if (k < C.n_hi)
+                    rq = (float)C.scl_hi[k];
+                else if (C.scl_lo && k - C.n_hi < C.n_lo)
+                    rq = (float)C.scl_lo[k - C.n_hi];
+                else if (store)
+                    atomicOr(bad, 1);
+            }
+        } else {
+            const int d = c - 1, k1 = ix[1], k2 = ix[2], k3 = ix[3];
+            if (k1 >= 0) {
+                if (k1 >= C.N_hi0 || (C.S_hi == 2 && (k2 < 0 || k2 >= C.N_hi1))) {
+                    if (store) atomicOr(bad, 1);
+                } else {
+                    const double e0 = C.vq_hi0_r[(size_t)k1 * NDIM + d];
+                    rq = (float)(C.S_hi == 2 ? e0 + C.vq_hi1_r[(size_t)k2 * NDIM + d] : e0);
+                }
+            } else if (k3 >= 0) {
+                if (!C.vq_lo_r || k3 >= C.N_lo) {
+                    if (store) atomicOr(bad, 1);
+                } else {
+                    rq = (float)C.vq_lo_r[(size_t)k3 * NDIM + d];
+                }
+            }
         }
-        for (size_t k = (size_t)i * Cc + tid; k < (size_t)A.Lf * Cc; k += NT) A.c_in[(size_t)b * A.Lf * Cc + k] = qnan;
-        for (size_t k = (size_t)i + tid; k < (size_t)A.Lf; k += NT) {
-            const size_t o = (size_t)b * A.Lf + k;
-            A.ind1[o] = qnan;
-            A.ind2[o] = qnan;
-            if (A.idx)
-                for (int c = 0; c < 4; ++c) A.idx[o * 4 + c] = -2;
-        }
+        const float cn = fo[c] + rq;
+        if (store) c_out[fi * Cc + c] = cn;
+        xn[c] = cn;
+    } else if (c < Cc) {
+        const float v = pitch[fi * (Cc - F) + (c - F)];
+        if (store) c_out[fi * Cc + c] = v;
+        xn[c] = v;
     }
 }
 
@@ -1015,7 +1084,7 @@ __global__ __launch_bounds__(NT) FPC_OCC void k_decode_feat(const PredDev P, con
     const int b = blockIdx.x / S.n, half = blockIdx.x % S.n, tid = threadIdx.x;
     SplitCtx X = split_ctx(S, P, b, half);
     const bool writer = half == 0;
-    const int Cc = P.in, F = P.fc;
+    const int Cc = P.in;
     for (int i = tid; i < P.h1; i += NT) L.h1[i] = 0.0f;
     for (int i = tid; i < P.h2; i += NT) L.h2[i] = 0.0f;
     if (tid < Cc) L.x[tid] = 0.0f;
@@ -1025,43 +1094,7 @@ __global__ __launch_bounds__(NT) FPC_OCC void k_decode_feat(const PredDev P, con
         const size_t fi = (size_t)b * Lf + i;
         pred_step(P, L, tid, &X);
         if (X.dead) break;  // (workgroup-uniform) a spin of the row split gave up
-        if (tid < F) {
-            const int* ix = idx + fi * 4;
-            float rq = 0.0f;
-            if (tid == 0) {
-                const int k = ix[0];
-                if (k >= 0) {
-                    if (k < C.n_hi)
-                        rq = (float)C.scl_hi[k];
-                    else if (C.scl_lo && k - C.n_hi < C.n_lo)
-                        rq = (float)C.scl_lo[k - C.n_hi];
-                    else
-                        { if (writer) atomicOr(bad, 1); }
-                }
-            } else {
-                const int d = tid - 1, k1 = ix[1], k2 = ix[2], k3 = ix[3];
-                if (k1 >= 0) {
-                    if (k1 >= C.N_hi0 || (C.S_hi == 2 && (k2 < 0 || k2 >= C.N_hi1))) {
-                        { if (writer) atomicOr(bad, 1); }
-                    } else {
-                        const double e0 = C.vq_hi0_r[(size_t)k1 * NDIM + d];
-                        rq = (float)(C.S_hi == 2 ? e0 + C.vq_hi1_r[(size_t)k2 * NDIM + d] : e0);
-                    }
-                } else if (k3 >= 0) {
-                    if (!C.vq_lo_r || k3 >= C.N_lo)
-                        { if (writer) atomicOr(bad, 1); }
-                    else
-                        rq = (float)C.vq_lo_r[(size_t)k3 * NDIM + d];
-                }
-            }
-            const float cn = L.fo[tid] + rq;
-            if (writer) c_out[fi * Cc + tid] = cn;
-            L.x[tid] = cn;
-        } else if (tid < Cc) {
-            const float v = pitch[fi * (Cc - F) + (tid - F)];
-            if (writer) c_out[fi * Cc + tid] = v;
-            L.x[tid] = v;
-        }
+        if (tid < 64) decode_frame(L.fo, L.x, P, C, pitch, idx, c_out, bad, fi, writer, tid);
         __syncthreads();
     }
     if (X.dead && writer) {  // fail loudly: NaN from this frame on; the host reports FPC_ERR_TIMEOUT
@@ -1069,6 +1102,8 @@ __global__ __launch_bounds__(NT) FPC_OCC void k_decode_feat(const PredDev P, con
         for (size_t k = (size_t)i * Cc + tid; k < (size_t)Lf * Cc; k += NT) c_out[(size_t)b * Lf * Cc + k] = qnan;
     }
 }
+
+#include "predictor_df.h"
 
 // stand-alone quantizers: one workgroup per input row
 __global__ __launch_bounds__(NT) void k_vq(const CbDev C, int which, const float* __restrict__ r, double* qr,
@@ -1565,6 +1600,13 @@ static int split_args(fpc_predictor* p, int B, hipStream_t st, SplitArgs* out) {
     return FPC_OK;
 }
 
+// the two-role kernels (predictor_df.h) are the shipped form; FPC_PRED_DF=0 runs the phase-after-phase kernels (tests
+// compare the two bit for bit)
+static bool two_roles() {
+    const char* e = getenv("FPC_PRED_DF");
+    return !(e && e[0] == '0');
+}
+
 static void predictor_unref(fpc_predictor* p) {
     if (p && p->refs.fetch_sub(1) <= 1) delete p;
 }
@@ -1651,13 +1693,22 @@ extern "C" int fpc_predictor_forward(fpc_predictor* p, const float* x_dev, int B
     SplitArgs sp;
     const int rc = split_args(p, B, static_cast<hipStream_t>(s), &sp);
     if (rc != FPC_OK) return rc;
-    hipLaunchKernelGGL(k_forward, dim3(B * sp.n), dim3(NT), 0, static_cast<hipStream_t>(s), p->d, x_dev, L,
-                       h1_dev, h2_dev, y_dev, sp);
+    if (two_roles())
+        hipLaunchKernelGGL(k_forward_df, dim3(B * sp.n), dim3(NT), 0, static_cast<hipStream_t>(s), p->d, x_dev, L,
+                           h1_dev, h2_dev, y_dev, sp);
+    else
+        hipLaunchKernelGGL(k_forward, dim3(B * sp.n), dim3(NT), 0, static_cast<hipStream_t>(s), p->d, x_dev, L,
+                           h1_dev, h2_dev, y_dev, sp);
     FPC_HIP(hipGetLastError());
 #ifdef FPC_PRED_PROF
     (void)hipStreamSynchronize(static_cast<hipStream_t>(s));
     {
         const volatile unsigned* w = (const volatile unsigned*)p->status_host;
+        if (two_roles())
+            fprintf(stderr, "k_forward_df B=%d n=%d cycles/frame FG: I %u waitA %u gates1 %u hop1 %u Ashare %u waitB %u waitC %u gates2 %u hop2 %u fc %u"
+                    " | BG: waitH1 %u C %u A %u waitH2 %u B %u\n", B, sp.n, w[1], w[2], w[3], w[4], w[5], w[10], w[6], w[7], w[8], w[9], w[11],
+                    w[12], w[13], w[14], w[15]);
+        else
         fprintf(stderr, "k_forward B=%d n=%d cycles/frame: next-x %u | rows1 %u gates1 %u xchg1 %u | rows2 %u gates2 %u xchg2 %u | fc %u\n",
                 B, sp.n, w[1], w[2], w[3], w[4], w[5], w[6], w[7], w[8]);
     }
@@ -1755,7 +1806,10 @@ extern "C" int fpc_encode(fpc_predictor* p, const fpc_codebooks* cb, const float
     SplitArgs sp;
     const int rc = split_args(p, B, static_cast<hipStream_t>(s), &sp);
     if (rc != FPC_OK) return rc;
-    hipLaunchKernelGGL(k_encode, dim3(B * sp.n), dim3(NT), 0, static_cast<hipStream_t>(s), p->d, cd, a, sp);
+    if (two_roles())
+        hipLaunchKernelGGL(k_encode_df, dim3(B * sp.n), dim3(NT), 0, static_cast<hipStream_t>(s), p->d, cd, a, sp);
+    else
+        hipLaunchKernelGGL(k_encode, dim3(B * sp.n), dim3(NT), 0, static_cast<hipStream_t>(s), p->d, cd, a, sp);
     FPC_HIP(hipGetLastError());
     return after_launch(p, static_cast<hipStream_t>(s));
 }
@@ -1774,8 +1828,12 @@ extern "C" int fpc_decode_features(fpc_predictor* p, const fpc_codebooks* cb, co
     SplitArgs sp;
     const int rc = split_args(p, B, st, &sp);
     if (rc != FPC_OK) return rc;
-    hipLaunchKernelGGL(k_decode_feat, dim3(B * sp.n), dim3(NT), 0, st, p->d, cb->d, pitch_dev, idx_dev, L, c_out_dev,
-                       p->flag.as<int>(), sp);
+    if (two_roles())
+        hipLaunchKernelGGL(k_decode_feat_df, dim3(B * sp.n), dim3(NT), 0, st, p->d, cb->d, pitch_dev, idx_dev, L, c_out_dev,
+                           p->flag.as<int>(), sp);
+    else
+        hipLaunchKernelGGL(k_decode_feat, dim3(B * sp.n), dim3(NT), 0, st, p->d, cb->d, pitch_dev, idx_dev, L, c_out_dev,
+                           p->flag.as<int>(), sp);
     FPC_HIP(hipGetLastError());
     int h = 0;
     FPC_HIP(hipMemcpyAsync(&h, p->flag.p, sizeof(int), hipMemcpyDeviceToHost, st));
