@@ -191,12 +191,6 @@ struct __attribute__((aligned(16))) PredLds : SearchLds {
 #else
 #define PSTAMP(k)
 #endif
-#ifdef FPC_VQ_PROF
-#define VQ_STAMP(k) \
-    if (tid == 0) L.prof[k] = clock64();
-#else
-#define VQ_STAMP(k)
-#endif
 
 // k-ordered fmaf chains of one row over v[0..K) with weights wT[k][R]: 16 loads in flight per block
 __device__ __forceinline__ float chain1(const float* __restrict__ wT, const float* v, int K, int R, int r, float a) {
@@ -903,13 +897,14 @@ struct EncArgs {
 // The frame's tail of Wavernn.encoder for ONE utterance (wavernn.py:196-252), run by the whole workgroup: residual of the
 // prediction fo[0..F), thresholds, searches, outputs of frame fi (stored when `store`), next input -> xn[0..Cc).
 // Ends with a barrier.
+// fv: this thread's column of the frame's feature row (tid < Cc), fetched by the caller before the predictor step so
+// that its latency is off the closed loop.
 __device__ __forceinline__ void encode_frame(SearchLds& L, const float* fo, float* xn, const PredDev& P, const CbDev& C,
-                                             const EncArgs& A, unsigned* err, size_t fi, bool store, int tid) {
+                                             const EncArgs& A, unsigned* err, size_t fi, float fv, bool store, int tid) {
     const int Cc = P.in, F = P.fc;
     const int off_sl = C.n_hi, off_v0 = off_sl + C.n_lo, off_v1 = off_v0 + C.N_hi0,
               off_vl = off_v1 + (C.S_hi == 2 ? C.N_hi1 : 0);
-    const float* f = A.feat + fi * Cc;
-    if (tid < F) L.rs[tid] = f[tid] - fo[tid];  // :196
+    if (tid < F) L.rs[tid] = fv - fo[tid];  // :196
     __syncthreads();
     float sabs = 0.0f;
     for (int d = 1; d < F; ++d) sabs += fabsf(L.rs[d]);
@@ -974,9 +969,8 @@ __device__ __forceinline__ void encode_frame(SearchLds& L, const float* fo, floa
         }
         xn[tid] = cn;
     } else if (tid < Cc) {  // pitch columns pass through (:178)
-        const float v = f[tid];
-        if (store) A.c_in[fi * Cc + tid] = v;
-        xn[tid] = v;
+        if (store) A.c_in[fi * Cc + tid] = fv;
+        xn[tid] = fv;
     }
     if (tid == 0 && store) {
         A.ind1[fi] = (float)i1;
@@ -1022,9 +1016,10 @@ __global__ __launch_bounds__(NT) FPC_OCC void k_encode(const PredDev P, const Cb
     __syncthreads();
     int i = 0;
     for (; i < A.Lf; ++i) {
+        const float fv = tid < P.in ? A.feat[((size_t)b * A.Lf + i) * P.in + tid] : 0.0f;
         pred_step(P, L, tid, &X);  // wavernn.py:194-195
         if (X.dead) break;         // (workgroup-uniform) a spin of the row split gave up
-        encode_frame(L, L.fo, L.x, P, C, A, S.err, (size_t)b * A.Lf + i, writer, tid);
+        encode_frame(L, L.fo, L.x, P, C, A, S.err, (size_t)b * A.Lf + i, fv, writer, tid);
     }
     if (X.dead && writer) encode_poison(P, A, b, i, tid);
 }

@@ -717,6 +717,42 @@ def test_predictor_row_split_equals_single_workgroup_form(torch_cuda, model, syn
                 assert np.array_equal(a, b), (B, L, mode)
 
 
+def test_predictor_two_roles_equal_phase_form(torch_cuda, model, synth, cb_paths, monkeypatch):
+    """the shipped two-role kernels (csrc/predictor_df.h: three waves walk the frame's latency chain, six stream the next
+    frame's recurrent products, LDS counters instead of workgroup barriers) against the phase-after-phase kernels
+    (FPC_PRED_DF=0, one workgroup per utterance): forward incl. carried states, encoder with and without quantisation incl.
+    symbols and histograms, receiver -- bit for bit at 1 / 7 / 128 / 200 utterances on 1, 2, 4 and 8 workgroups each
+    (1 workgroup: the input product streams from L2; 2-8: from its LDS copy)"""
+    torch = torch_cuda
+    cfg = dict(scl_cb_path=cb_paths["scl_hi"], cb_path=cb_paths["vq_hi"], bl_scl_cb_path=cb_paths["scl_lo"],
+               bl_cb_path=cb_paths["vq_lo"])
+
+    def run(feat):
+        y, h1, h2 = model.forward(feat)
+        y2, h1b, h2b = model.forward(feat[:, :5], h1, h2)
+        enc = model.encoder(cfg, feat, None, 0.09, 0.28, qtz=True, return_indices=True)
+        enc2 = model.encoder(cfg, feat, None, 0.09, 0.28, qtz=False)
+        dec = model.decode_indices(cfg, enc[7], feat[:, :, 18:].contiguous())
+        torch.cuda.synchronize()
+        return ([t.cpu().numpy() for t in (y, h1, h2, y2, h1b, h2b)] + [t.cpu().numpy() for t in enc[:6]] + list(enc[6]) +
+                [enc[7].cpu().numpy()] + [t.cpu().numpy() for t in enc2[:6]] + [dec.cpu().numpy()])
+
+    for B, L in ((1, 30), (7, 40), (128, 60), (200, 20)):
+        feat = torch.from_numpy(synth.predictor_features(B, L, utt0=7000)).cuda()
+        monkeypatch.setenv("FPC_PRED_SPLIT", "0")
+        monkeypatch.setenv("FPC_PRED_DF", "0")
+        ref = run(feat)
+        monkeypatch.delenv("FPC_PRED_DF")
+        for n in ("0", "2", "4", "8"):
+            if B * max(int(n), 1) > 512:
+                continue
+            monkeypatch.setenv("FPC_PRED_SPLIT", n)
+            got = run(feat)
+            assert len(got) == len(ref)
+            for k, (a, b) in enumerate(zip(ref, got)):
+                assert np.array_equal(a, b), (B, L, n, k)
+
+
 def test_predictor_row_split_under_uneven_load(torch_cuda, model, vocoder, synth, oracle, cb_paths):
     """the row-split exchange with the chip busy and the workgroups of a group NOT starting together: a 256-workgroup
     vocoder launch (one per CU, too much LDS to share a CU) is queued on a side stream right before the split encoder,
@@ -773,8 +809,10 @@ def test_train_step_row_split_equals_single_workgroup_form(torch_cuda, synth, mo
             assert not np.isnan(b).any() and np.array_equal(a, b), mode
 
 
-def test_row_split_timeout_is_an_error_not_garbage(torch_cuda, synth, cb_paths, monkeypatch):
-    """a row-split exchange that gives up must fail loudly at the ABI (round-2 review item 3): with the test hooks
+@pytest.mark.parametrize("two_roles", ["1", "0"])
+def test_row_split_timeout_is_an_error_not_garbage(torch_cuda, synth, cb_paths, monkeypatch, two_roles):
+    """(both kernel forms: the shipped two-role kernels and, FPC_PRED_DF=0, the phase kernels)
+    a row-split exchange that gives up must fail loudly at the ABI (round-2 review item 3): with the test hooks
     (FPC_TEST_WITHHOLD_PUBLISH: the last slice of utterance 0 never publishes; FPC_SPIN_LIMIT_US: 20 ms instead of 1 s)
     the partner's spin times out ONCE, deterministically.  The asynchronous entry point itself returns FPC_OK; the
     handle's sticky status word turns the next call on the handle and fpc_predictor_status into FPC_ERR_TIMEOUT; the
@@ -792,6 +830,8 @@ def test_row_split_timeout_is_an_error_not_garbage(torch_cuda, synth, cb_paths, 
     B, L = 2, 30
     feat = torch.from_numpy(synth.predictor_features(B, L, utt0=5100)).cuda()
     monkeypatch.setenv("FPC_PRED_SPLIT", "2")
+    if two_roles == "0":
+        monkeypatch.setenv("FPC_PRED_DF", "0")
     good = m.encoder(cfg, feat, None, 0.09, 0.28, qtz=True, return_indices=True)
     yg, _, _ = m.forward(feat)
     torch.cuda.synchronize()
