@@ -48,7 +48,7 @@ struct __attribute__((aligned(16))) DfLds : SearchLds {
         L.plast = now_;                                      \
     }
 #define BSTAMP(k)                                            \
-    if (threadIdx.x == FGT) {                                \
+    if (threadIdx.x == FGT + 64 * FPC_BSTAMP_WAVE) {         \
         const long long now_ = __builtin_readcyclecounter(); \
         L.pprof[k] += now_ - L.plast_bg;                     \
         L.plast_bg = now_;                                   \
@@ -81,6 +81,12 @@ __device__ __forceinline__ void fg_sync(DfLds& L, int& fg_epoch) {
 // chain4 (predictor.hip) for a wave-uniform weight matrix: the loads take the matrix base from scalar registers and ONE
 // 32-bit byte offset per lane that walks down the rows (the 64-bit addresses of a window cost two registers per load in
 // flight), which leaves room for a window of DFW loads: more bytes in flight per wave, and the waves of a role are few.
+#ifndef FPC_BSTAMP_WAVE
+#define FPC_BSTAMP_WAVE 0
+#endif
+#ifndef FPC_FG_PRIO
+#define FPC_FG_PRIO 2
+#endif
 #ifndef FPC_DFW
 #define FPC_DFW 16
 #endif
@@ -333,23 +339,38 @@ __device__ __forceinline__ bool df_foreground(const PredDev& P, const DfStep& D,
     const int lenf = P.h2 / Sf;
     for (int j = ft; j < P.fc * Sf; j += FGT) {
         const int o = j % P.fc, sg = j / P.fc;
-        const float* wT = D.cF ? L.fcc + P.fc + (size_t)sg * lenf * P.fc : P.fcw + (size_t)sg * lenf * P.fc;
         const float* hv = L.h2 + sg * lenf;
-        float a = sg == 0 ? (D.cF ? L.fcc[o] : P.fcb[o]) : 0.0f;
-        int k = 0;
-        for (; k + 16 <= lenf; k += 16) {
-            float w[16], v[16];
+        float a;
+        if (D.cF) {  // bias row, then [k][fc] in LDS
+            const float* wl = L.fcc + P.fc + sg * lenf * P.fc + o;
+            a = sg == 0 ? L.fcc[o] : 0.0f;
+            int k = 0;
+            for (; k + 16 <= lenf; k += 16) {
+                float w[16], v[16];
 #pragma unroll
-            for (int jj = 0; jj < 16; ++jj) {
-                w[jj] = D.cF ? L.fcc[P.fc + (size_t)(sg * lenf + k + jj) * P.fc + o] : wT[(size_t)(k + jj) * P.fc + o];
-                v[jj] = hv[k + jj] > 0.0f ? hv[k + jj] : 0.0f;
+                for (int jj = 0; jj < 16; ++jj) {
+                    w[jj] = wl[(k + jj) * P.fc];
+                    v[jj] = hv[k + jj];
+                }
+#pragma unroll
+                for (int jj = 0; jj < 16; ++jj) a = fmaf(v[jj] > 0.0f ? v[jj] : 0.0f, w[jj], a);
             }
+            for (; k < lenf; ++k) a = fmaf(hv[k] > 0.0f ? hv[k] : 0.0f, wl[k * P.fc], a);
+        } else {
+            const float* wT = P.fcw + (size_t)sg * lenf * P.fc + o;
+            a = sg == 0 ? P.fcb[o] : 0.0f;
+            int k = 0;
+            for (; k + 16 <= lenf; k += 16) {
+                float w[16], v[16];
 #pragma unroll
-            for (int jj = 0; jj < 16; ++jj) a = fmaf(v[jj], w[jj], a);
-        }
-        for (; k < lenf; ++k) {
-            const float w = D.cF ? L.fcc[P.fc + (size_t)(sg * lenf + k) * P.fc + o] : wT[(size_t)k * P.fc + o];
-            a = fmaf(hv[k] > 0.0f ? hv[k] : 0.0f, w, a);
+                for (int jj = 0; jj < 16; ++jj) {
+                    w[jj] = wT[(size_t)(k + jj) * P.fc];
+                    v[jj] = hv[k + jj];
+                }
+#pragma unroll
+                for (int jj = 0; jj < 16; ++jj) a = fmaf(v[jj] > 0.0f ? v[jj] : 0.0f, w[jj], a);
+            }
+            for (; k < lenf; ++k) a = fmaf(hv[k] > 0.0f ? hv[k] : 0.0f, wT[(size_t)k * P.fc], a);
         }
         L.pf[sg][o] = a;
     }
@@ -408,7 +429,7 @@ __global__ __launch_bounds__(NT) void k_forward_df(const PredDev P, const float*
 #endif
     int t = 0;
     if (tid < FGT) {
-        __builtin_amdgcn_s_setprio(2);
+        __builtin_amdgcn_s_setprio(FPC_FG_PRIO);
         int fg_epoch = 0;
         for (; t < Lf; ++t) {
             float xn = 0.0f;  // (teacher forcing: the next input row is fetched while this frame runs)
@@ -466,7 +487,7 @@ __global__ __launch_bounds__(NT) void k_encode_df(const PredDev P, const CbDev C
     for (; i < A.Lf; ++i) {
         const float fv = tid < P.in ? A.feat[((size_t)b * A.Lf + i) * P.in + tid] : 0.0f;
         if (tid < FGT) {
-            __builtin_amdgcn_s_setprio(2);
+            __builtin_amdgcn_s_setprio(FPC_FG_PRIO);
             (void)df_foreground(P, D, L, X, i, i + 1 == A.Lf, tid, fg_epoch);
             __builtin_amdgcn_s_setprio(0);
         } else {
@@ -494,7 +515,7 @@ __global__ __launch_bounds__(NT) void k_decode_feat_df(const PredDev P, const Cb
     df_prologue(P, D, L, tid, S.n, half);
     int done = 0;  // frames completed (foreground)
     if (tid < FGT) {
-        __builtin_amdgcn_s_setprio(2);
+        __builtin_amdgcn_s_setprio(FPC_FG_PRIO);
         int fg_epoch = 0;
         for (; done < Lf; ++done) {
             if (!df_foreground(P, D, L, X, done, done + 1 == Lf, tid, fg_epoch)) break;
