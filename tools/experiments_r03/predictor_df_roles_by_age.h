@@ -1,0 +1,542 @@
+// predictor_df.h -- the predictor step as TWO ROLES in one workgroup (included by predictor.hip inside its namespace).
+//
+// The phase-after-phase step (pred_step) spends a third of a frame in phases that stream nothing -- gate arithmetic on
+// 192 of 576 threads, two exchange hops, the 18 output rows, the next input -- while the L2 port idles, and the rest in
+// mat-vec passes that wait for each other (profiles/r03_predictor_phases.txt).  Here the 9 waves of a workgroup take two
+// roles:
+//   * waves 0-2 (FOREGROUND) walk the latency chain of a frame: input product I(t) = W1i x(t) (weights in LDS when the
+//     slice fits), GRU1 gates, hop 1, C(t) = W2i h1(t), GRU2 gates, hop 2, output layer (weights in LDS), next input;
+//   * waves 3-8 (BACKGROUND) stream the NEXT frame's recurrent products as soon as their inputs exist:
+//     A(t+1) = W1h h1(t) after hop 1 (two thirds of all bytes), B(t+1) = W2h h2(t) after hop 2.
+// The roles meet through counters in LDS (one release-add per wave and stage, acquire-polls with s_sleep) instead of
+// workgroup barriers, so stream and chain overlap; every dependence is a counter wait, listed at the waits below.
+// Each row is evaluated exactly as in pred_step -- same segments, same k order, same trees, same gate arithmetic --
+// only WHEN changes: bit-identical results (tests: every form against the phase form and the oracle).
+// Measured (profiles/r03_predictor_two_roles.txt): 27.0k cycles per frame against 37.2k (128 utterances on 2 workgroups).
+// Reference: Wavernn.forward (wavernn.py:69-95); callers as in predictor.hip.
+
+constexpr int FGW = 3, FGT = FGW * 64, BGT = NT - FGT;
+constexpr int WC_FLOATS = 12288, FCC_FLOATS = 4096;  // 48 + 16 kB of LDS
+static_assert(NT > FGT, "background role needs waves");
+enum { SIG_H1 = 0, SIG_H2, SIG_A, SIG_B, SIG_FG, SIG_C, NSIG };
+
+struct __attribute__((aligned(16))) DfLds : SearchLds {
+    float x[MAX_IN];
+    float h1[MAX_H1];
+    float h2[MAX_H2];
+    float pI[2][3 * MAX_H1];  // segment sums of I(t)  (in <= 64: at most 2 segments)
+    float pA[4][3 * MAX_H1];  // ... of A(t): GRU1 recurrent rows
+    float pB[4][3 * MAX_H2];  // ... of B(t): GRU2 recurrent rows
+    float pC[4][3 * MAX_H2];  // ... of C(t): GRU2 input rows
+    float pf[8][MAX_FC];
+    float fo[MAX_FC];
+    // weights of the chain's own small products, copied once per launch when they fit: the foreground then reads them
+    // from LDS instead of paying an L2 round trip per frame for 11 + 9 kB
+    float wc[WC_FLOATS];    // [1 + in][4 Q]: bias row, then this workgroup's slice of W1i (row quads as in mv_item)
+    float fcc[FCC_FLOATS];  // [1 + h2][fc]: bias row, then the output layer
+    int sig[NSIG];  // monotonic stage counters (one add per wave and stage)
+    int dead;       // an exchange spin gave up: nobody waits any more
+#ifdef FPC_PRED_PROF
+    long long pprof[17], plast, plast_bg;  // diagnostic builds: cycles per stage, foreground [0..9) and background [9..15)
+#endif
+};
+#ifdef FPC_PRED_PROF
+#define FSTAMP(k)                                            \
+    if (threadIdx.x == BGT) {                                \
+        const long long now_ = __builtin_readcyclecounter(); \
+        L.pprof[k] += now_ - L.plast;                        \
+        L.plast = now_;                                      \
+    }
+#define BSTAMP(k)                                            \
+    if (threadIdx.x == 64 * FPC_BSTAMP_WAVE) {               \
+        const long long now_ = __builtin_readcyclecounter(); \
+        L.pprof[k] += now_ - L.plast_bg;                     \
+        L.plast_bg = now_;                                   \
+    }
+#else
+#define FSTAMP(k)
+#define BSTAMP(k)
+#endif
+
+// one wave has finished its share of a stage (its LDS writes are ordered before the add: one in-order LDS queue per wave)
+__device__ __forceinline__ void df_signal(int* s) {
+    if ((threadIdx.x & 63) == 0) (void)__hip_atomic_fetch_add(s, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+// wait until `target` waves have signalled (false: the launch is dead, do not use the data)
+__device__ __forceinline__ bool df_wait(int* s, int target, int* dead) {
+    unsigned spins = 0;
+    while (__hip_atomic_load(s, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < target) {
+        if ((++spins & 7u) == 0 && __hip_atomic_load(dead, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0) return false;
+        __builtin_amdgcn_s_sleep(1);
+    }
+    return true;
+}
+// barrier of the foreground waves only
+__device__ __forceinline__ void fg_sync(DfLds& L, int& fg_epoch) {
+    ++fg_epoch;
+    df_signal(&L.sig[SIG_FG]);
+    (void)df_wait(&L.sig[SIG_FG], FGW * fg_epoch, &L.dead);
+}
+
+// chain4 (predictor.hip) for a wave-uniform weight matrix: the loads take the matrix base from scalar registers and ONE
+// 32-bit byte offset per lane that walks down the rows (the 64-bit addresses of a window cost two registers per load in
+// flight), which leaves room for a window of DFW loads: more bytes in flight per wave, and the waves of a role are few.
+#ifndef FPC_BSTAMP_WAVE
+#define FPC_BSTAMP_WAVE 0
+#endif
+#ifndef FPC_FG_PRIO
+#define FPC_FG_PRIO 2
+#endif
+#ifndef FPC_DFW
+#define FPC_DFW 16
+#endif
+constexpr int DFW = FPC_DFW;
+__device__ __forceinline__ v4f ld4s(const float* base, unsigned& off, unsigned stride) {
+    v4f r;
+    asm volatile("global_load_dwordx4 %0, %1, %2\n\tv_add_u32 %1, %3, %1" : "=&v"(r), "+v"(off) : "s"(base), "s"(stride));
+    return r;
+}
+__device__ __forceinline__ v4f ld4s_after(const float* base, unsigned& off, unsigned stride, const float4& a) {
+    v4f r;
+    asm volatile("global_load_dwordx4 %0, %1, %2\n\tv_add_u32 %1, %3, %1"
+                 : "=&v"(r), "+v"(off)
+                 : "s"(base), "s"(stride), "v"(a.x), "v"(a.y), "v"(a.z), "v"(a.w));
+    return r;
+}
+template <int J = 0>
+__device__ __forceinline__ void last_window_s(float4& a, const float (&hv)[DFW], v4f (&w)[DFW]) {
+    if constexpr (J < DFW) {
+        landed<DFW - 1 - J>(w[J]);
+        fma4(a, hv[J], w[J]);
+        last_window_s<J + 1>(a, hv, w);
+    }
+}
+// W: wave-uniform base of the matrix; off0: this lane's byte offset of (row k0, column r); strideB = 4 R
+__device__ __forceinline__ void chain4s(const float* __restrict__ W, unsigned off0, unsigned strideB, const float* v, int K,
+                                        v4f& a0, float4& a) {
+    unsigned off = off0;
+    const int nb = K / DFW;
+    int rem = K - nb * DFW;
+    v4f w[DFW], wt[CT];
+    if (nb > 0) {
+#pragma unroll
+        for (int j = 0; j < DFW; ++j) w[j] = ld4s(W, off, strideB);
+    }
+    if (nb > 0)
+        landed<DFW - 1>(a0);
+    else
+        landed<0>(a0);
+    a = make_float4(a0.x, a0.y, a0.z, a0.w);
+    float hv[DFW];  // the window's input values, read from LDS ahead of the arithmetic
+    for (int b = 0; b + 1 < nb; ++b, v += DFW) {
+#pragma unroll
+        for (int j = 0; j < DFW; ++j) hv[j] = v[j];
+#pragma unroll
+        for (int j = 0; j < DFW; ++j) {
+            landed<DFW - 1>(w[j]);
+            fma4(a, hv[j], w[j]);
+            w[j] = ld4s_after(W, off, strideB, a);
+        }
+    }
+    const int t0 = rem < CT ? rem : CT;
+#pragma unroll
+    for (int j = 0; j < CT; ++j)
+        if (j < t0) wt[j] = ld4s(W, off, strideB);
+    if (nb > 0) {
+#pragma unroll
+        for (int j = 0; j < DFW; ++j) hv[j] = v[j];
+        last_window_s(a, hv, w);
+        v += DFW;
+    }
+    while (rem > 0) {
+#pragma unroll
+        for (int j = 0; j < CT; ++j)
+            if (j < rem) {
+                landed<0>(wt[j]);
+                fma4(a, v[j], wt[j]);
+            }
+        rem -= CT;
+        v += CT;
+        if (rem > 0) {
+#pragma unroll
+            for (int j = 0; j < CT; ++j)
+                if (j < rem) wt[j] = ld4s(W, off, strideB);
+        }
+    }
+}
+
+// one mat-vec of the step: weights W [K][3H] (transposed), bias b, input v[0..K) in LDS, segment sums -> part[sg][row]
+struct Mv {
+    const float* W;
+    const float* b;
+    const float* v;
+    float* part;
+    int K, H, pitch;
+};
+__device__ __forceinline__ int mv_count(const Mv& m, int nsplit) { return 3 * (m.H / 4 / nsplit) * segments(m.K); }
+// item `it` of this workgroup's slice: (row quad, input segment) -- the chain of gru_rows
+__device__ __forceinline__ void mv_item(const Mv& m, int it, int nsplit, int half) {
+    const int R = 3 * m.H, Qg = m.H / 4 / nsplit, Q = 3 * Qg, S = segments(m.K);
+    const int q = it % Q, sg = it / Q, gate = q / Qg, qq = q - gate * Qg;
+    const int len = m.K / S, k0 = sg * len, r = gate * m.H + 4 * (half * Qg + qq);
+    v4f a0 = {0.f, 0.f, 0.f, 0.f};
+    if (sg == 0) a0 = ld4(&m.b[r]);
+    float4 a;
+    chain4s(m.W, (unsigned)(k0 * R + r) * 4u, (unsigned)R * 4u, m.v + k0, len, a0, a);
+    *reinterpret_cast<float4*>(&m.part[sg * m.pitch + r]) = a;
+}
+__device__ __forceinline__ float tree_df(const float* p, int pitch, int S, int row) {
+    if (S == 4) return (p[row] + p[pitch + row]) + (p[2 * pitch + row] + p[3 * pitch + row]);
+    if (S == 2) return p[row] + p[pitch + row];
+    return p[row];
+}
+// torch.nn.GRU gates [r; z; n] of this workgroup's slice of the units (gru_gates), by the threads ft, ft + FGT, ...
+__device__ __forceinline__ void gates_df(const float* pin, int pitch_in, int Sin, const float* prec, int pitch_rec, int Srec,
+                                         float* h, int H, int nsplit, int half, int ft) {
+    const int Hs = H / nsplit;
+    for (int ii = ft; ii < Hs; ii += FGT) {
+        const int i = half * Hs + ii;
+        const float gir = tree_df(pin, pitch_in, Sin, i), giz = tree_df(pin, pitch_in, Sin, H + i),
+                    gin = tree_df(pin, pitch_in, Sin, 2 * H + i);
+        const float ghr = tree_df(prec, pitch_rec, Srec, i), ghz = tree_df(prec, pitch_rec, Srec, H + i),
+                    ghn = tree_df(prec, pitch_rec, Srec, 2 * H + i);
+        const float r = fpc_sigmoidf(gir + ghr);
+        const float z = fpc_sigmoidf(giz + ghz);
+        const float n = fpc_tanhf(fmaf(r, ghn, gin));
+        h[i] = fmaf(z, h[i] - n, n);
+    }
+}
+// one hop by the foreground threads: this workgroup's slice goes out under a new epoch, the others come in
+// (same thread -> unit mapping as gates_df: a thread publishes the units it has just computed)
+__device__ __forceinline__ void hop_df(float* h, int H, SplitCtx& X, unsigned long long* g, int ft, DfLds& L) {
+    if (X.n == 1) return;
+    const int Hs = H / X.n, mine = X.half * Hs;
+    const unsigned epoch = ++X.epoch;
+    if (!X.withhold)
+        for (int i = ft; i < Hs; i += FGT) store_granule(&g[mine + i], epoch, h[mine + i]);
+    bool gave_up = false;
+    for (int ii = ft; ii < H - Hs; ii += FGT) {
+        const int i = ii < mine ? ii : ii + Hs;
+        h[i] = await_granule(&g[i], epoch, X, gave_up);
+    }
+    if (gave_up) {
+        X.dead = true;
+        __hip_atomic_store(&L.dead, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+}
+
+struct DfStep {
+    Mv I, A, B, C;
+    int nI, nA, nB, nC;  // items of this workgroup's slice
+    int SI, SA, SB, SC;  // segments
+    bool cI, cF;         // I's weights / the output layer are in LDS
+};
+__device__ __forceinline__ DfStep df_setup(const PredDev& P, DfLds& L, int n) {
+    DfStep D;
+    D.I = Mv{P.w1i, P.b1i, L.x, &L.pI[0][0], P.in, P.h1, 3 * MAX_H1};
+    D.A = Mv{P.w1h, P.b1h, L.h1, &L.pA[0][0], P.h1, P.h1, 3 * MAX_H1};
+    D.B = Mv{P.w2h, P.b2h, L.h2, &L.pB[0][0], P.h2, P.h2, 3 * MAX_H2};
+    D.C = Mv{P.w2i, P.b2i, L.h1, &L.pC[0][0], P.h1, P.h2, 3 * MAX_H2};
+    D.nI = mv_count(D.I, n);
+    D.nA = mv_count(D.A, n);
+    D.nB = mv_count(D.B, n);
+    D.nC = mv_count(D.C, n);
+    D.SI = segments(P.in);
+    D.SA = segments(P.h1);
+    D.SB = segments(P.h2);
+    D.SC = segments(P.h1);
+    D.cI = (1 + P.in) * 12 * (P.h1 / 4 / n) <= WC_FLOATS;
+    D.cF = (1 + P.h2) * P.fc <= FCC_FLOATS;
+    return D;
+}
+
+// everything before frame 0 by all threads: counters, A(0), B(0).  States and x(0) are in LDS; ends with a barrier.
+__device__ __forceinline__ void df_prologue(const PredDev& P, const DfStep& D, DfLds& L, int tid, int n, int half) {
+    if (tid < NSIG) L.sig[tid] = 0;
+    if (tid == 0) L.dead = 0;
+    if (D.cI) {
+        const int Qg = P.h1 / 4 / n, Q = 3 * Qg;
+        for (int idx = tid; idx < (1 + P.in) * Q; idx += NT) {
+            const int k = idx / Q, q = idx - k * Q, gate = q / Qg, r = gate * P.h1 + 4 * (half * Qg + (q - gate * Qg));
+            const float* src = k == 0 ? P.b1i + r : P.w1i + (size_t)(k - 1) * 3 * P.h1 + r;
+            *reinterpret_cast<float4*>(&L.wc[idx * 4]) = *reinterpret_cast<const float4*>(src);
+        }
+    }
+    if (D.cF)
+        for (int idx = tid; idx < (1 + P.h2) * P.fc; idx += NT) L.fcc[idx] = idx < P.fc ? P.fcb[idx] : P.fcw[idx - P.fc];
+    __syncthreads();  // (the states are in LDS)
+    // (one matrix per loop: the loads take its base from scalar registers)
+    for (int it = tid; it < D.nA; it += NT) mv_item(D.A, it, n, half);
+    for (int it = tid; it < D.nB; it += NT) mv_item(D.B, it, n, half);
+    __syncthreads();
+}
+
+// FOREGROUND, frame t: L.x = x(t), A(t) and B(t) under way or done -> L.fo; returns false when the launch is dead.
+// `last`: no frame follows (A(t+1) is not started).
+__device__ __forceinline__ bool df_foreground(const PredDev& P, const DfStep& D, DfLds& L, SplitCtx& X, int t, bool last, int ft,
+                                              int& fg_epoch) {
+    const int n = X.n, half = X.half;
+    if (D.cI) {  // I(t) from the LDS copy: same chains (bias, then k ascending within the segment)
+        const int Qg = P.h1 / 4 / n, Q = 3 * Qg, len = P.in / D.SI;
+        for (int it = ft; it < D.nI; it += FGT) {
+            const int q = it % Q, sg = it / Q, gate = q / Qg, k0 = sg * len, r = gate * P.h1 + 4 * (half * Qg + (q - gate * Qg));
+            float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (sg == 0) a = *reinterpret_cast<const float4*>(&L.wc[4 * q]);
+            int k = k0;
+            for (; k + 4 <= k0 + len; k += 4) {  // four steps' LDS reads ahead of their fmaf's (same k order)
+                float4 w[4];
+                float hv[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    w[j] = *reinterpret_cast<const float4*>(&L.wc[((1 + k + j) * Q + q) * 4]);
+                    hv[j] = L.x[k + j];
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    a.x = fmaf(hv[j], w[j].x, a.x);
+                    a.y = fmaf(hv[j], w[j].y, a.y);
+                    a.z = fmaf(hv[j], w[j].z, a.z);
+                    a.w = fmaf(hv[j], w[j].w, a.w);
+                }
+            }
+            for (; k < k0 + len; ++k) {
+                const float4 w = *reinterpret_cast<const float4*>(&L.wc[((1 + k) * Q + q) * 4]);
+                const float hv = L.x[k];
+                a.x = fmaf(hv, w.x, a.x);
+                a.y = fmaf(hv, w.y, a.y);
+                a.z = fmaf(hv, w.z, a.z);
+                a.w = fmaf(hv, w.w, a.w);
+            }
+            *reinterpret_cast<float4*>(&L.pI[sg][r]) = a;
+        }
+    } else {
+        for (int it = ft; it < D.nI; it += FGT) mv_item(D.I, it, n, half);
+    }
+    fg_sync(L, fg_epoch);                                          // (gates read rows other threads summed)
+    FSTAMP(0)
+    if (!df_wait(&L.sig[SIG_A], (NW - FGW) * t, &L.dead)) return false;  // A(t): one signal per background wave and frame, A(0) in the prologue
+    FSTAMP(1)
+    gates_df(&L.pI[0][0], 3 * MAX_H1, D.SI, &L.pA[0][0], 3 * MAX_H1, D.SA, L.h1, P.h1, n, half, ft);
+    FSTAMP(2)
+    hop_df(L.h1, P.h1, X, X.g1, ft, L);
+    df_signal(&L.sig[SIG_H1]);
+    if (!df_wait(&L.sig[SIG_H1], FGW * (t + 1), &L.dead)) return false;  // h1(t) whole in LDS
+    FSTAMP(3)
+    {  // C(t): the background waves that hold C items report
+        const int cw = (D.nC + 63) / 64 < NW - FGW ? (D.nC + 63) / 64 : NW - FGW;
+        if (!df_wait(&L.sig[SIG_C], cw * (t + 1), &L.dead)) return false;
+    }
+    FSTAMP(4)
+    if (!df_wait(&L.sig[SIG_B], (NW - FGW) * t, &L.dead)) return false;  // B(t)
+    FSTAMP(9)
+    FSTAMP(5)
+    gates_df(&L.pC[0][0], 3 * MAX_H2, D.SC, &L.pB[0][0], 3 * MAX_H2, D.SB, L.h2, P.h2, n, half, ft);
+    FSTAMP(6)
+    hop_df(L.h2, P.h2, X, X.g2, ft, L);
+    df_signal(&L.sig[SIG_H2]);
+    if (!df_wait(&L.sig[SIG_H2], FGW * (t + 1), &L.dead)) return false;  // h2(t) whole in LDS
+    FSTAMP(7)
+    // output layer on relu(h2): the rectified value is formed in the chain (same value as pred_step's relu pass)
+    const int Sf = (P.h2 % 8 == 0 && P.h2 >= 64) ? 8 : 1;
+    const int lenf = P.h2 / Sf;
+    for (int j = ft; j < P.fc * Sf; j += FGT) {
+        const int o = j % P.fc, sg = j / P.fc;
+        const float* hv = L.h2 + sg * lenf;
+        float a;
+        if (D.cF) {  // bias row, then [k][fc] in LDS
+            const float* wl = L.fcc + P.fc + sg * lenf * P.fc + o;
+            a = sg == 0 ? L.fcc[o] : 0.0f;
+            int k = 0;
+            for (; k + 16 <= lenf; k += 16) {
+                float w[16], v[16];
+#pragma unroll
+                for (int jj = 0; jj < 16; ++jj) {
+                    w[jj] = wl[(k + jj) * P.fc];
+                    v[jj] = hv[k + jj];
+                }
+#pragma unroll
+                for (int jj = 0; jj < 16; ++jj) a = fmaf(v[jj] > 0.0f ? v[jj] : 0.0f, w[jj], a);
+            }
+            for (; k < lenf; ++k) a = fmaf(hv[k] > 0.0f ? hv[k] : 0.0f, wl[k * P.fc], a);
+        } else {
+            const float* wT = P.fcw + (size_t)sg * lenf * P.fc + o;
+            a = sg == 0 ? P.fcb[o] : 0.0f;
+            int k = 0;
+            for (; k + 16 <= lenf; k += 16) {
+                float w[16], v[16];
+#pragma unroll
+                for (int jj = 0; jj < 16; ++jj) {
+                    w[jj] = wT[(size_t)(k + jj) * P.fc];
+                    v[jj] = hv[k + jj];
+                }
+#pragma unroll
+                for (int jj = 0; jj < 16; ++jj) a = fmaf(v[jj] > 0.0f ? v[jj] : 0.0f, w[jj], a);
+            }
+            for (; k < lenf; ++k) a = fmaf(hv[k] > 0.0f ? hv[k] : 0.0f, wT[(size_t)k * P.fc], a);
+        }
+        L.pf[sg][o] = a;
+    }
+    fg_sync(L, fg_epoch);
+    if (ft < P.fc) {
+        float acc = L.pf[0][ft];
+        if (Sf == 8)
+            acc = ((L.pf[0][ft] + L.pf[1][ft]) + (L.pf[2][ft] + L.pf[3][ft])) +
+                  ((L.pf[4][ft] + L.pf[5][ft]) + (L.pf[6][ft] + L.pf[7][ft]));
+        const float tt = fpc_tanhf(acc);
+        L.fo[ft] = tt + tt;
+    }
+    fg_sync(L, fg_epoch);
+    FSTAMP(8)
+    return __hip_atomic_load(&L.dead, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == 0;
+}
+
+// BACKGROUND, frame t: C(t) and the rest of A(t+1) once h1(t) is whole, B(t+1) once h2(t) is
+__device__ __forceinline__ bool df_background(const DfStep& D, DfLds& L, int n, int half, int t, bool last, int bt) {
+    if (!df_wait(&L.sig[SIG_H1], FGW * (t + 1), &L.dead)) return false;
+    BSTAMP(15)
+    // (holding A(t+1) back until the foreground has C(t) shortens C from 8.0k to 6.2k cycles and lengthens the wait
+    //  for A by as much: measured, no gain)
+    // pass 1: C(t) on the first threads (the oldest waves: the L2 port serves them first), A(t+1) on the others
+    if (bt < D.nC)
+        mv_item(D.C, bt, n, half);
+    else if (!last && bt - D.nC < D.nA)
+        mv_item(D.A, bt - D.nC, n, half);
+    for (int it = bt + BGT; it < D.nC; it += BGT) mv_item(D.C, it, n, half);  // (more C than threads: one workgroup per utterance)
+    if ((bt & ~63) < D.nC) df_signal(&L.sig[SIG_C]);
+    if (!last) {
+        const int first = D.nC < BGT ? BGT - D.nC : 0;  // A items taken in pass 1
+        for (int it = first + bt; it < D.nA; it += BGT) mv_item(D.A, it, n, half);
+    }
+
+    BSTAMP(10)
+    df_signal(&L.sig[SIG_A]);
+    BSTAMP(11)
+    if (!df_wait(&L.sig[SIG_H2], FGW * (t + 1), &L.dead)) return false;
+    BSTAMP(12)
+    if (!last)
+        for (int it = bt; it < D.nB; it += BGT) mv_item(D.B, it, n, half);
+    df_signal(&L.sig[SIG_B]);
+    BSTAMP(13)
+    return true;
+}
+
+__global__ __launch_bounds__(NT) void k_forward_df(const PredDev P, const float* __restrict__ x, int Lf, float* h1, float* h2,
+                                                   float* __restrict__ y, const SplitArgs S) {
+    __shared__ DfLds L;
+    const int b = blockIdx.x / S.n, half = blockIdx.x % S.n, tid = threadIdx.x;
+    SplitCtx X = split_ctx(S, P, b, half);
+    const bool writer = half == 0;
+    for (int i = tid; i < P.h1; i += NT) L.h1[i] = h1[(size_t)b * P.h1 + i];
+    for (int i = tid; i < P.h2; i += NT) L.h2[i] = h2[(size_t)b * P.h2 + i];
+    if (tid < P.in && Lf > 0) L.x[tid] = x[(size_t)b * Lf * P.in + tid];
+    __syncthreads();
+    const DfStep D = df_setup(P, L, S.n);
+    df_prologue(P, D, L, tid, S.n, half);
+#ifdef FPC_PRED_PROF
+    if (tid == 0) {
+        for (int i = 0; i < 17; ++i) L.pprof[i] = 0;
+        L.plast = L.plast_bg = __builtin_readcyclecounter();
+    }
+    __syncthreads();
+#endif
+    int t = 0;
+    if (tid >= BGT) {
+        const int ft = tid - BGT;
+        int fg_epoch = 0;
+        for (; t < Lf; ++t) {
+            float xn = 0.0f;  // (teacher forcing: the next input row is fetched while this frame runs)
+            if (t + 1 < Lf && ft < P.in) xn = x[((size_t)b * Lf + t + 1) * P.in + ft];
+            if (!df_foreground(P, D, L, X, t, t + 1 == Lf, ft, fg_epoch)) break;
+            if (writer && ft < P.fc) y[((size_t)b * Lf + t) * P.fc + ft] = L.fo[ft];
+            if (t + 1 < Lf) {
+                if (ft < P.in) L.x[ft] = xn;
+                fg_sync(L, fg_epoch);
+            }
+            FSTAMP(14)
+        }
+    } else {
+        for (int tb = 0; tb < Lf; ++tb)
+            if (!df_background(D, L, S.n, half, tb, tb + 1 == Lf, tid)) break;
+    }
+    __syncthreads();
+#ifdef FPC_PRED_PROF
+    if (tid == 0 && blockIdx.x == gridDim.x / 2) {
+        const int src[15] = {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 15, 10, 11, 12, 13};
+        for (int i = 0; i < 15; ++i) S.err[1 + i] = (unsigned)(L.pprof[src[i]] / (Lf > 0 ? Lf : 1));
+    }
+#endif
+    if (L.dead != 0 || X.dead) {  // fail loudly (k_forward): NaN outputs and states, FPC_ERR_TIMEOUT on the host
+        // (the frame at which the foreground stopped is not known to the other waves: the whole launch is poisoned)
+        if (writer) {
+            const float qnan = __uint_as_float(0x7fc00000u);
+            for (size_t k = tid; k < (size_t)Lf * P.fc; k += NT) y[(size_t)b * Lf * P.fc + k] = qnan;
+            for (int i = tid; i < P.h1; i += NT) h1[(size_t)b * P.h1 + i] = qnan;
+            for (int i = tid; i < P.h2; i += NT) h2[(size_t)b * P.h2 + i] = qnan;
+        }
+        return;
+    }
+    if (writer) {
+        for (int i = tid; i < P.h1; i += NT) h1[(size_t)b * P.h1 + i] = L.h1[i];
+        for (int i = tid; i < P.h2; i += NT) h2[(size_t)b * P.h2 + i] = L.h2[i];
+    }
+}
+
+__global__ __launch_bounds__(NT) void k_encode_df(const PredDev P, const CbDev C, const EncArgs A, const SplitArgs S) {
+    __shared__ DfLds L;
+    const int b = blockIdx.x / S.n, half = blockIdx.x % S.n, tid = threadIdx.x;
+    SplitCtx X = split_ctx(S, P, b, half);
+    const bool writer = half == 0;
+    for (int i = tid; i < P.h1; i += NT) L.h1[i] = 0.0f;
+    for (int i = tid; i < P.h2; i += NT) L.h2[i] = 0.0f;
+    if (tid < P.in) L.x[tid] = 0.0f;
+    __syncthreads();
+    const DfStep D = df_setup(P, L, S.n);
+    df_prologue(P, D, L, tid, S.n, half);
+    int fg_epoch = 0;
+    int i = 0;
+    for (; i < A.Lf; ++i) {
+        const float fv = tid < P.in ? A.feat[((size_t)b * A.Lf + i) * P.in + tid] : 0.0f;
+        if (tid >= BGT)
+            (void)df_foreground(P, D, L, X, i, i + 1 == A.Lf, tid - BGT, fg_epoch);
+        else
+            (void)df_background(D, L, S.n, half, i, i + 1 == A.Lf, tid);
+        // the searches take the whole workgroup: both roles meet (fo(i) is ready, the streams of frame i are done)
+        if (__syncthreads_or(L.dead != 0 || X.dead)) break;
+        encode_frame(L, L.fo, L.x, P, C, A, S.err, (size_t)b * A.Lf + i, fv, writer, tid);
+    }
+    if (i < A.Lf && writer) encode_poison(P, A, b, i, tid);
+}
+
+__global__ __launch_bounds__(NT) void k_decode_feat_df(const PredDev P, const CbDev C, const float* __restrict__ pitch,
+                                                       const int* __restrict__ idx, int Lf, float* __restrict__ c_out,
+                                                       int* bad, const SplitArgs S) {
+    __shared__ DfLds L;
+    const int b = blockIdx.x / S.n, half = blockIdx.x % S.n, tid = threadIdx.x;
+    SplitCtx X = split_ctx(S, P, b, half);
+    const bool writer = half == 0;
+    for (int i = tid; i < P.h1; i += NT) L.h1[i] = 0.0f;
+    for (int i = tid; i < P.h2; i += NT) L.h2[i] = 0.0f;
+    if (tid < P.in) L.x[tid] = 0.0f;
+    __syncthreads();
+    const DfStep D = df_setup(P, L, S.n);
+    df_prologue(P, D, L, tid, S.n, half);
+    int done = 0;  // frames completed (foreground)
+    if (tid >= BGT) {
+        const int ft = tid - BGT;
+        int fg_epoch = 0;
+        for (; done < Lf; ++done) {
+            if (!df_foreground(P, D, L, X, done, done + 1 == Lf, ft, fg_epoch)) break;
+            // the residual is a lookup: one foreground wave rebuilds the next input row (columns < in <= 64)
+            if (ft < 64) decode_frame(L.fo, L.x, P, C, pitch, idx, c_out, bad, (size_t)b * Lf + done, writer, ft);
+            fg_sync(L, fg_epoch);
+        }
+    } else {
+        for (int tb = 0; tb < Lf; ++tb)
+            if (!df_background(D, L, S.n, half, tb, tb + 1 == Lf, tid)) break;
+    }
+    __syncthreads();
+    if ((L.dead != 0 || X.dead) && writer) {  // fail loudly: the whole launch is poisoned
+        const float qnan = __uint_as_float(0x7fc00000u);
+        for (size_t k = tid; k < (size_t)Lf * P.in; k += NT) c_out[(size_t)b * Lf * P.in + k] = qnan;
+    }
+}
