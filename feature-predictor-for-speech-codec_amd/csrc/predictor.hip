@@ -1483,11 +1483,14 @@ __global__ void k_colsum(const GradJobs J, int N) {
 }
 
 // torch.optim.Adam, single-tensor path (betas 0.9 / 0.999, eps 1e-8, no weight decay)
+// the handle's status word lives in host memory (one PCIe round trip per reader): one thread copies it into device memory
+// once per step, and the ten Adam launches read the copy
+__global__ void k_latch_status(const unsigned* status, unsigned* latch) { *latch = status_load(status); }
 __global__ void k_adam(float* __restrict__ p, float* __restrict__ m, float* __restrict__ v, const float* __restrict__ g,
-                       size_t n, float step_size, float bc2_sqrt, const unsigned* status) {
+                       size_t n, float step_size, float bc2_sqrt, const unsigned* __restrict__ latch) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    if (status_load(status) != 0u) return;  // the step's forward or backward gave up: the weights stay as they are
+    if (*latch != 0u) return;  // the step's forward or backward gave up: the weights stay as they are
     const float gi = g[i];
     const float mi = fmaf(0.1f, gi - m[i], m[i]);
     const float vi = fmaf(0.001f, gi * gi, v[i] * 0.999f);
@@ -1847,6 +1850,7 @@ struct fpc_trainer {
     fpc_predictor* p = nullptr;
     int maxB = 0, maxL = 0, step = 0;
     fpc::DevBuf ws, grad[10], m[10], v[10], lossb, wt[3], gpart[5];  // wt: torch-layout copies of w2i, w2h, w1h
+    fpc::DevBuf latch;  // device copy of the handle's status word, refreshed once per step (k_latch_status)
     TrainBufs T;
     size_t sz[10];
 };
@@ -1880,6 +1884,7 @@ extern "C" int fpc_trainer_create(fpc_predictor* p, int max_B, int max_L, fpc_tr
     const size_t per = (size_t)6 * H1 + 7 * H2 + 2 * F + 6 * H1 + 6 * H2;
     FPC_HIP(t->ws.alloc(N * per * 4));
     FPC_HIP(t->lossb.alloc(sizeof(double) * (size_t)max_B));
+    FPC_HIP(t->latch.alloc(sizeof(unsigned)));
     {
         const int wi[5] = {0, 1, 4, 5, 8};
         for (int j = 0; j < 5; ++j) FPC_HIP(t->gpart[j].alloc(sz[wi[j]] * 4 * GSEG));
@@ -1974,10 +1979,11 @@ extern "C" int fpc_trainer_step(fpc_trainer* t, const float* feat_dev, int B, in
     t->step += 1;
     const double bc1 = 1.0 - pow(0.9, t->step), bc2 = 1.0 - pow(0.999, t->step);
     const float step_size = (float)(lr / bc1), bc2_sqrt = (float)sqrt(bc2);
+    hipLaunchKernelGGL(k_latch_status, dim3(1), dim3(1), 0, st, p->status_dev, t->latch.as<unsigned>());
     for (int k = 0; k < 10; ++k)
         hipLaunchKernelGGL(k_adam, dim3((unsigned)((t->sz[k] + 255) / 256)), dim3(256), 0, st, param_ptr(p, k),
                            t->m[k].as<float>(), t->v[k].as<float>(), t->grad[k].as<float>(), t->sz[k], step_size, bc2_sqrt,
-                           p->status_dev);
+                           t->latch.as<unsigned>());
     refresh();
     FPC_HIP(hipGetLastError());
     {
