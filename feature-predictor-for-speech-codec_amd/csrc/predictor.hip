@@ -1806,6 +1806,16 @@ extern "C" int fpc_encode(fpc_predictor* p, const fpc_codebooks* cb, const float
     if (rc != FPC_OK) return rc;
     if (two_roles())
         hipLaunchKernelGGL(k_encode_df, dim3(B * sp.n), dim3(NT), 0, static_cast<hipStream_t>(s), p->d, cd, a, sp);
+#ifdef FPC_PRED_PROF
+    if (two_roles()) {
+        (void)hipStreamSynchronize(static_cast<hipStream_t>(s));
+        const volatile unsigned* w = (const volatile unsigned*)p->status_host;
+        fprintf(stderr, "k_encode_df B=%d n=%d qtz=%d cycles/frame FG: I %u waitA %u gates1 %u hop1 %u C %u waitB %u gates2 %u hop2 %u out %u | rendezvous %u"
+                " frame tail + searches %u | BG: waitH1 %u A %u (signal %u) B %u\n", B, sp.n, qtz, w[1], w[2], w[3], w[4], w[5], w[6], w[7], w[8],
+                w[9], w[10], w[11], w[12], w[13], w[14], w[15]);
+        for (int k = 1; k < 16; ++k) ((volatile unsigned*)p->status_host)[k] = 0;
+    }
+#endif
     else
         hipLaunchKernelGGL(k_encode, dim3(B * sp.n), dim3(NT), 0, static_cast<hipStream_t>(s), p->d, cd, a, sp);
     FPC_HIP(hipGetLastError());

@@ -389,7 +389,15 @@ __device__ __forceinline__ bool df_foreground(const PredDev& P, const DfStep& D,
 }
 
 // BACKGROUND, frame t: C(t) and the rest of A(t+1) once h1(t) is whole, B(t+1) once h2(t) is
+// BACKGROUND, frame t: B(t) = W2h h2(t-1) first -- its input has been whole since hop 2 of the previous frame and the
+// foreground needs it only at the GRU2 gates, so it fills the wait for hop 1 -- then A(t+1) once h1(t) is whole
 __device__ __forceinline__ bool df_background(const DfStep& D, DfLds& L, int n, int half, int t, bool last, int bt) {
+    if (t > 0) {  // (B(0) comes from the prologue)
+        if (!df_wait(&L.sig[SIG_H2], FGW * t, &L.dead)) return false;
+        for (int it = bt; it < D.nB; it += BGT) mv_item(D.B, it, n, half);
+        df_signal(&L.sig[SIG_B]);
+    }
+    BSTAMP(13)
     if (!df_wait(&L.sig[SIG_H1], FGW * (t + 1), &L.dead)) return false;
     BSTAMP(15)
     // (holding A(t+1) back until the foreground has C(t) shortens C from 8.0k to 6.2k cycles and lengthens the wait
@@ -399,12 +407,6 @@ __device__ __forceinline__ bool df_background(const DfStep& D, DfLds& L, int n, 
     BSTAMP(10)
     df_signal(&L.sig[SIG_A]);
     BSTAMP(11)
-    if (!df_wait(&L.sig[SIG_H2], FGW * (t + 1), &L.dead)) return false;
-    BSTAMP(12)
-    if (!last)
-        for (int it = bt; it < D.nB; it += BGT) mv_item(D.B, it, n, half);
-    df_signal(&L.sig[SIG_B]);
-    BSTAMP(13)
     return true;
 }
 
@@ -482,6 +484,13 @@ __global__ __launch_bounds__(NT) void k_encode_df(const PredDev P, const CbDev C
     __syncthreads();
     const DfStep D = df_setup(P, L, S.n);
     df_prologue(P, D, L, tid, S.n, half);
+#ifdef FPC_PRED_PROF
+    if (tid == 0) {
+        for (int k = 0; k < 17; ++k) L.pprof[k] = 0;
+        L.plast = L.plast_bg = __builtin_readcyclecounter();
+    }
+    __syncthreads();
+#endif
     int fg_epoch = 0;
     int i = 0;
     for (; i < A.Lf; ++i) {
@@ -495,8 +504,16 @@ __global__ __launch_bounds__(NT) void k_encode_df(const PredDev P, const CbDev C
         }
         // the searches take the whole workgroup: both roles meet (fo(i) is ready, the streams of frame i are done)
         if (__syncthreads_or(L.dead != 0 || X.dead)) break;
+        FSTAMP(14)
         encode_frame(L, L.fo, L.x, P, C, A, S.err, (size_t)b * A.Lf + i, fv, writer, tid);
+        FSTAMP(16)
     }
+#ifdef FPC_PRED_PROF
+    if (tid == 0 && blockIdx.x == gridDim.x / 2) {
+        const int src[15] = {0, 1, 2, 3, 4, 5, 6, 7, 8, 14, 16, 15, 10, 11, 13};
+        for (int k = 0; k < 15; ++k) S.err[1 + k] = (unsigned)(L.pprof[src[k]] / (A.Lf > 0 ? A.Lf : 1));
+    }
+#endif
     if (i < A.Lf && writer) encode_poison(P, A, b, i, tid);
 }
 
