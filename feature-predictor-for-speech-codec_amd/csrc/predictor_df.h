@@ -2,11 +2,11 @@
 //
 // The phase-after-phase step (pred_step) spends a third of a frame in phases that stream nothing -- gate arithmetic on
 // 192 of 576 threads, two exchange hops, the 18 output rows, the next input -- while the L2 port idles, and the rest in
-// mat-vec passes that wait for each other (profiles/r03_predictor_phases.txt).  Here the 9 waves of a workgroup take two
+// mat-vec passes that wait for each other (profiles/r03_predictor_phases.txt).  Here the waves of a workgroup take two
 // roles:
 //   * waves 0-2 (FOREGROUND) walk the latency chain of a frame: input product I(t) = W1i x(t) (weights in LDS when the
 //     slice fits), GRU1 gates, hop 1, C(t) = W2i h1(t), GRU2 gates, hop 2, output layer (weights in LDS), next input;
-//   * waves 3-8 (BACKGROUND) stream the NEXT frame's recurrent products as soon as their inputs exist:
+//   * the other waves (BACKGROUND: 3-7 at 512 threads) stream the NEXT frame's recurrent products as soon as their inputs exist:
 //     A(t+1) = W1h h1(t) after hop 1 (two thirds of all bytes), B(t+1) = W2h h2(t) after hop 2.
 // The roles meet through counters in LDS (one release-add per wave and stage, acquire-polls with s_sleep) instead of
 // workgroup barriers, so stream and chain overlap; every dependence is a counter wait, listed at the waits below.
@@ -78,91 +78,64 @@ __device__ __forceinline__ void fg_sync(DfLds& L, int& fg_epoch) {
     (void)df_wait(&L.sig[SIG_FG], FGW * fg_epoch, &L.dead);
 }
 
-// chain4 (predictor.hip) for a wave-uniform weight matrix: the loads take the matrix base from scalar registers and ONE
-// 32-bit byte offset per lane that walks down the rows (the 64-bit addresses of a window cost two registers per load in
-// flight), which leaves room for a window of DFW loads: more bytes in flight per wave, and the waves of a role are few.
-#ifndef FPC_BSTAMP_WAVE
-#define FPC_BSTAMP_WAVE 0
+// The chains of the two-role kernels: chain4's rolling window (predictor.hip) for a wave-uniform weight matrix, in PLAIN
+// loads -- matrix base in scalar registers, one 32-bit byte offset per lane walking down the rows -- that the compiler
+// counts itself (its waits are right by construction); the interleaving (the fmaf's of the oldest window register, then
+// its refill) is asked for through scheduling group barriers.  The inline-assembly form of chain4 is as fast at 576 threads,
+// but a register the compiler copies or spills between such a load and its wait is read too early, and a change of the
+// surrounding code shape (a window of 24, both chain forms inlined side by side) produced exactly that: the kernels of
+// the product path do not depend on it any more.
+#ifndef FPC_DFW
+#define FPC_DFW 16
 #endif
 #ifndef FPC_FG_PRIO
 #define FPC_FG_PRIO 2
 #endif
-#ifndef FPC_DFW
-#define FPC_DFW 16
+#ifndef FPC_BSTAMP_WAVE
+#define FPC_BSTAMP_WAVE 0
 #endif
 constexpr int DFW = FPC_DFW;
-__device__ __forceinline__ v4f ld4s(const float* base, unsigned& off, unsigned stride) {
-    v4f r;
-    asm volatile("global_load_dwordx4 %0, %1, %2\n\tv_add_u32 %1, %3, %1" : "=&v"(r), "+v"(off) : "s"(base), "s"(stride));
-    return r;
+__device__ __forceinline__ void fma4f(float4& a, float hv, const float4& w) {
+    a.x = fmaf(hv, w.x, a.x);
+    a.y = fmaf(hv, w.y, a.y);
+    a.z = fmaf(hv, w.z, a.z);
+    a.w = fmaf(hv, w.w, a.w);
 }
-__device__ __forceinline__ v4f ld4s_after(const float* base, unsigned& off, unsigned stride, const float4& a) {
-    v4f r;
-    asm volatile("global_load_dwordx4 %0, %1, %2\n\tv_add_u32 %1, %3, %1"
-                 : "=&v"(r), "+v"(off)
-                 : "s"(base), "s"(stride), "v"(a.x), "v"(a.y), "v"(a.z), "v"(a.w));
-    return r;
-}
-template <int J = 0>
-__device__ __forceinline__ void last_window_s(float4& a, const float (&hv)[DFW], v4f (&w)[DFW]) {
-    if constexpr (J < DFW) {
-        landed<DFW - 1 - J>(w[J]);
-        fma4(a, hv[J], w[J]);
-        last_window_s<J + 1>(a, hv, w);
-    }
-}
-// W: wave-uniform base of the matrix; off0: this lane's byte offset of (row k0, column r); strideB = 4 R
+// W: wave-uniform base of the matrix; off0: this lane's byte offset of (row k0, column r); strideB = 4 R; a: the chain's
+// start value (bias or 0) on entry
 __device__ __forceinline__ void chain4s(const float* __restrict__ W, unsigned off0, unsigned strideB, const float* v, int K,
-                                        v4f& a0, float4& a) {
+                                        float4& a) {
+    const char* base = reinterpret_cast<const char*>(W);
     unsigned off = off0;
-    const int nb = K / DFW;
-    int rem = K - nb * DFW;
-    v4f w[DFW], wt[CT];
+    const int nb = K / DFW, rem = K - nb * DFW;
+    float4 w[DFW];
+    float hv[DFW];
     if (nb > 0) {
 #pragma unroll
-        for (int j = 0; j < DFW; ++j) w[j] = ld4s(W, off, strideB);
+        for (int j = 0; j < DFW; ++j, off += strideB) w[j] = *reinterpret_cast<const float4*>(base + off);
     }
-    if (nb > 0)
-        landed<DFW - 1>(a0);
-    else
-        landed<0>(a0);
-    a = make_float4(a0.x, a0.y, a0.z, a0.w);
-    float hv[DFW];  // the window's input values, read from LDS ahead of the arithmetic
     for (int b = 0; b + 1 < nb; ++b, v += DFW) {
 #pragma unroll
         for (int j = 0; j < DFW; ++j) hv[j] = v[j];
 #pragma unroll
+        for (int j = 0; j < DFW; ++j, off += strideB) {
+            fma4f(a, hv[j], w[j]);
+            w[j] = *reinterpret_cast<const float4*>(base + off);
+        }
+#pragma unroll
         for (int j = 0; j < DFW; ++j) {
-            landed<DFW - 1>(w[j]);
-            fma4(a, hv[j], w[j]);
-            w[j] = ld4s_after(W, off, strideB, a);
+            __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);  // the step's arithmetic (2 packed fmaf + address)
+            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);  // one load
         }
     }
-    const int t0 = rem < CT ? rem : CT;
-#pragma unroll
-    for (int j = 0; j < CT; ++j)
-        if (j < t0) wt[j] = ld4s(W, off, strideB);
     if (nb > 0) {
 #pragma unroll
         for (int j = 0; j < DFW; ++j) hv[j] = v[j];
-        last_window_s(a, hv, w);
+#pragma unroll
+        for (int j = 0; j < DFW; ++j) fma4f(a, hv[j], w[j]);
         v += DFW;
     }
-    while (rem > 0) {
-#pragma unroll
-        for (int j = 0; j < CT; ++j)
-            if (j < rem) {
-                landed<0>(wt[j]);
-                fma4(a, v[j], wt[j]);
-            }
-        rem -= CT;
-        v += CT;
-        if (rem > 0) {
-#pragma unroll
-            for (int j = 0; j < CT; ++j)
-                if (j < rem) wt[j] = ld4s(W, off, strideB);
-        }
-    }
+    for (int k = 0; k < rem; ++k, off += strideB) fma4f(a, v[k], *reinterpret_cast<const float4*>(base + off));
 }
 
 // one mat-vec of the step: weights W [K][3H] (transposed), bias b, input v[0..K) in LDS, segment sums -> part[sg][row]
@@ -179,10 +152,9 @@ __device__ __forceinline__ void mv_item(const Mv& m, int it, int nsplit, int hal
     const int R = 3 * m.H, Qg = m.H / 4 / nsplit, Q = 3 * Qg, S = segments(m.K);
     const int q = it % Q, sg = it / Q, gate = q / Qg, qq = q - gate * Qg;
     const int len = m.K / S, k0 = sg * len, r = gate * m.H + 4 * (half * Qg + qq);
-    v4f a0 = {0.f, 0.f, 0.f, 0.f};
-    if (sg == 0) a0 = ld4(&m.b[r]);
-    float4 a;
-    chain4s(m.W, (unsigned)(k0 * R + r) * 4u, (unsigned)R * 4u, m.v + k0, len, a0, a);
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (sg == 0) a = *reinterpret_cast<const float4*>(&m.b[r]);
+    chain4s(m.W, (unsigned)(k0 * R + r) * 4u, (unsigned)R * 4u, m.v + k0, len, a);
     *reinterpret_cast<float4*>(&m.part[sg * m.pitch + r]) = a;
 }
 __device__ __forceinline__ float tree_df(const float* p, int pitch, int S, int row) {

@@ -1,5 +1,6 @@
-"""Guard for the hand-placed weight-load windows of the predictor kernels (csrc/predictor.hip chain4, csrc/predictor_df.h
-chain4s): their loads and waits are inline assembly the compiler does not count, so a window register must never be spilled
+"""Guard for the hand-placed weight-load windows of the phase-form and training predictor kernels (csrc/predictor.hip chain4;
+the shipped two-role kernels of csrc/predictor_df.h use plain loads the compiler counts): the loads and waits are inline
+assembly the compiler does not count, so a window register must never be spilled
 (or reloaded) between its load and its wait -- the spill would read it before the load has landed.  Compiles predictor.hip
 to gfx950 assembly and reports, per kernel, the scratch operations that lie within `near` lines of such a load.
 
