@@ -91,7 +91,7 @@ FPC_API void fpc_predictor_destroy(fpc_predictor* p);
  *  - Launches of ONE handle may be issued on different streams: a call on another stream first waits (on the device)
  *    for the handle's previous launch.  Creating and destroying handles is thread-safe; calls on one handle are not.
  * Kernel form: fpc_predictor_forward, fpc_encode and fpc_decode_features run the two-role kernels (csrc/predictor_df.h:
- * three waves of a workgroup walk a frame's latency chain, six stream the next frame's recurrent products; LDS counters
+ * three waves of a workgroup walk a frame's latency chain, the others stream the recurrent products; LDS counters
  * instead of workgroup barriers); FPC_PRED_DF=0 selects the phase-after-phase kernels, which give the same bits (the
  * tests' reference form).  The training step runs the phase form.
  * Environment: FPC_PRED_SPLIT=0 keeps one workgroup per utterance, 2|4|8 fixes the count (tests); FPC_PRED_DF=0 see
