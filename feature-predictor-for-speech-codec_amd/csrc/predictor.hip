@@ -1230,6 +1230,46 @@ __global__ __launch_bounds__(NT) void k_train_fwd(const PredDev P, const float* 
     }
 }
 
+// the training forward as two roles (predictor_df.h): k_train_fwd's frames with the latency chain on three waves and the
+// recurrent products streamed by the others; same chains, same kept activations
+__global__ __launch_bounds__(NT) void k_train_fwd_df(const PredDev P, const float* __restrict__ feat, int Lf, const TrainBufs T,
+                                                     const SplitArgs S) {
+    __shared__ DfLds L;
+    const int b = blockIdx.x / S.n, half = blockIdx.x % S.n, tid = threadIdx.x;
+    SplitCtx X = split_ctx(S, P, b, half);
+    const bool writer = half == 0;
+    for (int i = tid; i < P.h1; i += NT) L.h1[i] = 0.0f;
+    for (int i = tid; i < P.h2; i += NT) L.h2[i] = 0.0f;
+    if (tid < P.in && Lf > 0) L.x[tid] = feat[(size_t)b * Lf * P.in + tid];
+    __syncthreads();
+    const DfStep D = df_setup(P, L, S.n);
+    df_prologue(P, D, L, tid, S.n, half);
+    if (tid < FGT) {
+        __builtin_amdgcn_s_setprio(FPC_FG_PRIO);
+        int fg_epoch = 0;
+        for (int t = 0; t < Lf; ++t) {
+            const size_t n = (size_t)b * Lf + t;
+            float xn = 0.0f;
+            if (t + 1 < Lf && tid < P.in) xn = feat[(n + 1) * P.in + tid];
+            if (writer) {  // the states the frame starts from (whole in LDS since the previous frame's hops)
+                for (int i = tid; i < P.h1; i += FGT) T.h1p[n * P.h1 + i] = L.h1[i];
+                for (int i = tid; i < P.h2; i += FGT) T.h2p[n * P.h2 + i] = L.h2[i];
+            }
+            const DfSave sv{T.r1, T.z1, T.n1, T.hn1, T.h1, T.r2, T.z2, T.n2, T.hn2, T.h2, T.relu, T.th, n, writer};
+            if (!df_foreground<true>(P, D, L, X, t, t + 1 == Lf, tid, fg_epoch, &sv)) break;
+            if (t + 1 < Lf) {
+                if (tid < P.in) L.x[tid] = xn;
+                fg_sync(L, fg_epoch);
+            }
+        }
+        __builtin_amdgcn_s_setprio(0);
+    } else {
+        for (int tb = 0; tb < Lf; ++tb)
+            if (!df_background(D, L, S.n, half, tb, tb + 1 == Lf, tid - FGT)) break;
+    }
+    // (a launch that gave up leaves its status bit: the step's Adam update is skipped, the host reports FPC_ERR_TIMEOUT)
+}
+
 // dL/dpre of every frame and the utterance's share of the loss (float64, frames then outputs in order)
 __global__ __launch_bounds__(256) void k_train_loss(const float* __restrict__ feat, int in, int F, int Lf, float scale,
                                                     const TrainBufs T) {
@@ -1957,7 +1997,10 @@ extern "C" int fpc_trainer_step(fpc_trainer* t, const float* feat_dev, int B, in
         const int rc = split_args(p, B, st, &sp);
         if (rc != FPC_OK) return rc;
     }
-    hipLaunchKernelGGL(k_train_fwd, dim3(B * sp.n), dim3(NT), 0, st, P, feat_dev, L, T, sp);
+    if (two_roles())
+        hipLaunchKernelGGL(k_train_fwd_df, dim3(B * sp.n), dim3(NT), 0, st, P, feat_dev, L, T, sp);
+    else
+        hipLaunchKernelGGL(k_train_fwd, dim3(B * sp.n), dim3(NT), 0, st, P, feat_dev, L, T, sp);
     const double cnt = (double)B * (L - 1) * F;
     hipLaunchKernelGGL(k_train_loss, dim3(B), dim3(256), sizeof(float) * (size_t)L * F, st, feat_dev, in, F, L,
                        (float)(2.0 / cnt), T);

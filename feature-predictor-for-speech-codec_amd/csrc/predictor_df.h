@@ -163,8 +163,18 @@ __device__ __forceinline__ float tree_df(const float* p, int pitch, int S, int r
     return p[row];
 }
 // torch.nn.GRU gates [r; z; n] of this workgroup's slice of the units (gru_gates), by the threads ft, ft + FGT, ...
+// what the training forward keeps per sample for the backward pass (k_train_fwd's gates_save): activations of this
+// workgroup's units, ReLU and tanh outputs by the writing slice
+struct DfSave {
+    float *r1, *z1, *n1, *hn1, *h1, *r2, *z2, *n2, *hn2, *h2, *relu, *th;
+    size_t n;  // sample index b * L + t
+    bool writer;
+};
+template <bool SAVE = false>
 __device__ __forceinline__ void gates_df(const float* pin, int pitch_in, int Sin, const float* prec, int pitch_rec, int Srec,
-                                         float* h, int H, int nsplit, int half, int ft) {
+                                         float* h, int H, int nsplit, int half, int ft, float* r_ = nullptr,
+                                         float* z_ = nullptr, float* n_ = nullptr, float* hn_ = nullptr, float* hout = nullptr,
+                                         size_t smp = 0) {
     const int Hs = H / nsplit;
     for (int ii = ft; ii < Hs; ii += FGT) {
         const int i = half * Hs + ii;
@@ -175,7 +185,15 @@ __device__ __forceinline__ void gates_df(const float* pin, int pitch_in, int Sin
         const float r = fpc_sigmoidf(gir + ghr);
         const float z = fpc_sigmoidf(giz + ghz);
         const float n = fpc_tanhf(fmaf(r, ghn, gin));
-        h[i] = fmaf(z, h[i] - n, n);
+        const float hv = fmaf(z, h[i] - n, n);
+        h[i] = hv;
+        if (SAVE) {
+            r_[smp * H + i] = r;
+            z_[smp * H + i] = z;
+            n_[smp * H + i] = n;
+            hn_[smp * H + i] = ghn;
+            hout[smp * H + i] = hv;
+        }
     }
 }
 // one hop by the foreground threads: this workgroup's slice goes out under a new epoch, the others come in
@@ -245,8 +263,9 @@ __device__ __forceinline__ void df_prologue(const PredDev& P, const DfStep& D, D
 
 // FOREGROUND, frame t: L.x = x(t), A(t) and B(t) under way or done -> L.fo; returns false when the launch is dead.
 // `last`: no frame follows (A(t+1) is not started).
+template <bool SAVE = false>
 __device__ __forceinline__ bool df_foreground(const PredDev& P, const DfStep& D, DfLds& L, SplitCtx& X, int t, bool last, int ft,
-                                              int& fg_epoch) {
+                                              int& fg_epoch, const DfSave* sv = nullptr) {
     const int n = X.n, half = X.half;
     if (D.cI) {  // I(t) from the LDS copy: same chains (bias, then k ascending within the segment)
         const int Qg = P.h1 / 4 / n, Q = 3 * Qg, len = P.in / D.SI;
@@ -288,7 +307,11 @@ __device__ __forceinline__ bool df_foreground(const PredDev& P, const DfStep& D,
     FSTAMP(0)
     if (!df_wait(&L.sig[SIG_A], (NW - FGW) * t, &L.dead)) return false;  // A(t): one signal per background wave and frame, A(0) in the prologue
     FSTAMP(1)
-    gates_df(&L.pI[0][0], 3 * MAX_H1, D.SI, &L.pA[0][0], 3 * MAX_H1, D.SA, L.h1, P.h1, n, half, ft);
+    if (SAVE)
+        gates_df<true>(&L.pI[0][0], 3 * MAX_H1, D.SI, &L.pA[0][0], 3 * MAX_H1, D.SA, L.h1, P.h1, n, half, ft, sv->r1, sv->z1,
+                       sv->n1, sv->hn1, sv->h1, sv->n);
+    else
+        gates_df(&L.pI[0][0], 3 * MAX_H1, D.SI, &L.pA[0][0], 3 * MAX_H1, D.SA, L.h1, P.h1, n, half, ft);
     FSTAMP(2)
     hop_df(L.h1, P.h1, X, X.g1, ft, L);
     df_signal(&L.sig[SIG_H1]);
@@ -300,7 +323,11 @@ __device__ __forceinline__ bool df_foreground(const PredDev& P, const DfStep& D,
     if (!df_wait(&L.sig[SIG_B], (NW - FGW) * t, &L.dead)) return false;  // B(t)
     FSTAMP(9)
     FSTAMP(5)
-    gates_df(&L.pC[0][0], 3 * MAX_H2, D.SC, &L.pB[0][0], 3 * MAX_H2, D.SB, L.h2, P.h2, n, half, ft);
+    if (SAVE)
+        gates_df<true>(&L.pC[0][0], 3 * MAX_H2, D.SC, &L.pB[0][0], 3 * MAX_H2, D.SB, L.h2, P.h2, n, half, ft, sv->r2, sv->z2,
+                       sv->n2, sv->hn2, sv->h2, sv->n);
+    else
+        gates_df(&L.pC[0][0], 3 * MAX_H2, D.SC, &L.pB[0][0], 3 * MAX_H2, D.SB, L.h2, P.h2, n, half, ft);
     FSTAMP(6)
     hop_df(L.h2, P.h2, X, X.g2, ft, L);
     df_signal(&L.sig[SIG_H2]);
@@ -345,6 +372,8 @@ __device__ __forceinline__ bool df_foreground(const PredDev& P, const DfStep& D,
             for (; k < lenf; ++k) a = fmaf(hv[k] > 0.0f ? hv[k] : 0.0f, wT[(size_t)k * P.fc], a);
         }
         L.pf[sg][o] = a;
+        if (SAVE && o == 0 && sv->writer)  // (the rectified state, kept for the backward pass)
+            for (int k = 0; k < lenf; ++k) sv->relu[sv->n * P.h2 + sg * lenf + k] = hv[k] > 0.0f ? hv[k] : 0.0f;
     }
     fg_sync(L, fg_epoch);
     if (ft < P.fc) {
@@ -354,6 +383,7 @@ __device__ __forceinline__ bool df_foreground(const PredDev& P, const DfStep& D,
                   ((L.pf[4][ft] + L.pf[5][ft]) + (L.pf[6][ft] + L.pf[7][ft]));
         const float tt = fpc_tanhf(acc);
         L.fo[ft] = tt + tt;
+        if (SAVE && sv->writer) sv->th[sv->n * P.fc + ft] = tt;
     }
     fg_sync(L, fg_epoch);
     FSTAMP(8)

@@ -93,7 +93,7 @@ FPC_API void fpc_predictor_destroy(fpc_predictor* p);
  * Kernel form: fpc_predictor_forward, fpc_encode and fpc_decode_features run the two-role kernels (csrc/predictor_df.h:
  * three waves of a workgroup walk a frame's latency chain, the others stream the recurrent products; LDS counters
  * instead of workgroup barriers); FPC_PRED_DF=0 selects the phase-after-phase kernels, which give the same bits (the
- * tests' reference form).  The training step runs the phase form.
+ * tests' reference form); the training step's forward follows the same switch.
  * Environment: FPC_PRED_SPLIT=0 keeps one workgroup per utterance, 2|4|8 fixes the count (tests); FPC_PRED_DF=0 see
  * above; FPC_SPIN_LIMIT_US / FPC_TEST_WITHHOLD_PUBLISH are test hooks (a shorter bound; the last slice of utterance 0
  * never publishes). */
