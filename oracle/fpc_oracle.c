@@ -79,7 +79,7 @@ static void gru_cell(const float* w_ih, const float* w_hh, const float* b_ih, co
 static void pred_step(const orc_pred* p, const float* x, float* h1, float* h2, float* y,
                       float* scratch) {
     float* gi = scratch;
-    float* gh = scratch + 3 * p->h1;
+    float* gh = scratch + 3 * (p->h1 > p->h2 ? p->h1 : p->h2); /* (either layer may be the wider one) */
     gru_cell(p->w1_ih, p->w1_hh, p->b1_ih, p->b1_hh, x, p->in, h1, p->h1, gi, gh);
     gru_cell(p->w2_ih, p->w2_hh, p->b2_ih, p->b2_hh, h1, p->h1, h2, p->h2, gi, gh);
     float* relu = gi;

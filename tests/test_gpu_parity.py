@@ -99,6 +99,53 @@ def test_encoder_bit_identical_to_oracle(torch_cuda, model, synth, oracle, cb_pa
         assert np.array_equal(np.atleast_1d(out[6][i]), hs[i])
 
 
+def test_predictor_other_dimensions_bit_identical_to_oracle(torch_cuda, synth, oracle, cb_paths, monkeypatch):
+    """the predictor kernels are generic in the layer sizes (in <= 64, gru_units1 <= 512, gru_units2 <= 256, fc <= 32): forward
+    incl. carried states at five other shapes -- different segment counts per row (1, 2, 4), the input product from its LDS
+    copy or streamed, row quads that do not fill a wave -- and the closed-loop encoder at the shapes it supports (20 inputs, 18
+    outputs), against the CPU oracle bit for bit, on 1 / 2 / 4 workgroups per utterance, in both kernel forms"""
+    from fpcodec_amd.wavernn import Wavernn
+    torch = torch_cuda
+    c = synth.codebooks()
+    CB = oracle.Codebooks(c["vq_hi"], c["scl_hi"], c["vq_lo"], c["scl_lo"])
+    cfg = dict(scl_cb_path=cb_paths["scl_hi"], cb_path=cb_paths["vq_hi"], bl_scl_cb_path=cb_paths["scl_lo"],
+               bl_cb_path=cb_paths["vq_lo"])
+    rng = np.random.default_rng(77)
+    for dims in ((20, 256, 64, 18), (20, 128, 256, 18), (20, 512, 32, 18), (64, 192, 96, 24), (36, 64, 16, 12)):
+        inf, h1, h2, fc = dims
+        sd = synth.predictor_state_dict(inf, h1, h2, fc, seed=900 + h1 + h2)
+        P = oracle.Predictor(sd)
+        B, L = 5, 14
+        if inf == 20:
+            feat = synth.predictor_features(B, L, utt0=8100)
+        else:
+            feat = (rng.normal(size=(B, L, inf)) * 0.1).astype(np.float32)
+        y0, a0, b0 = P.forward(feat)
+        y1, a1, b1 = P.forward(feat[:, :4], a0, b0)
+        enc0 = P.encode(feat, CB, 0.09, 0.28, True) if (inf, fc) == (20, 18) else None
+        m = Wavernn(inf, h1, h2, fc)
+        m.load_state_dict(sd)
+        x = torch.from_numpy(feat).cuda()
+        for df in ("1", "0"):
+            for n in ("0", "2", "4"):
+                if int(n) and (h1 % (4 * int(n)) or h2 % (4 * int(n))):
+                    continue
+                monkeypatch.setenv("FPC_PRED_SPLIT", n)
+                if df == "0":
+                    monkeypatch.setenv("FPC_PRED_DF", "0")
+                else:
+                    monkeypatch.delenv("FPC_PRED_DF", raising=False)
+                y, a, b = m.forward(x)
+                y2, a2, b2 = m.forward(x[:, :4].contiguous(), a, b)
+                for got, ref in ((y, y0), (a, a0), (b, b0), (y2, y1), (a2, a1), (b2, b1)):
+                    assert np.array_equal(got.cpu().numpy().reshape(ref.shape), ref), (dims, df, n)
+                if enc0 is not None:
+                    out = m.encoder(cfg, x, None, 0.09, 0.28, qtz=True, return_indices=True)
+                    assert np.array_equal(out[7].cpu().numpy(), enc0["idx"]), (dims, df, n)
+                    for k, v in (("c_in", out[0]), ("r", out[1]), ("r_qtz", out[2])):
+                        assert np.array_equal(v.cpu().numpy(), enc0[k]), (dims, df, n, k)
+
+
 def test_quantizers_vs_golden(torch_cuda, synth, golden, cb_paths):
     from fpcodec_amd.vq_func import vq_quantize, scl_quantize
     g = golden("g3_quant")
