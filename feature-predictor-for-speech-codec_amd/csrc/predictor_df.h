@@ -6,13 +6,14 @@
 // roles:
 //   * waves 0-2 (FOREGROUND) walk the latency chain of a frame: input product I(t) = W1i x(t) (weights in LDS when the
 //     slice fits), GRU1 gates, hop 1, C(t) = W2i h1(t), GRU2 gates, hop 2, output layer (weights in LDS), next input;
-//   * the other waves (BACKGROUND: 3-7 at 512 threads) stream the NEXT frame's recurrent products as soon as their inputs exist:
-//     A(t+1) = W1h h1(t) after hop 1 (two thirds of all bytes), B(t+1) = W2h h2(t) after hop 2.
+//   * the other waves (BACKGROUND: 3-7 at 512 threads) stream the recurrent products as soon as their inputs exist:
+//     B(t) = W2h h2(t-1) while the chain is on its way to hop 1, A(t+1) = W1h h1(t) after hop 1 (two thirds of all bytes).
 // The roles meet through counters in LDS (one release-add per wave and stage, acquire-polls with s_sleep) instead of
 // workgroup barriers, so stream and chain overlap; every dependence is a counter wait, listed at the waits below.
 // Each row is evaluated exactly as in pred_step -- same segments, same k order, same trees, same gate arithmetic --
 // only WHEN changes: bit-identical results (tests: every form against the phase form and the oracle).
-// Measured (profiles/r03_predictor_two_roles.txt): 27.0k cycles per frame against 37.2k (128 utterances on 2 workgroups).
+// Measured (profiles/r03_predictor_two_roles.txt): 27.0k cycles per frame against 37.2k (128 utterances on 2 workgroups);
+// encode 9.0 -> 6.85 ms, forward 5.4 -> 3.8 ms at 128 x 300.
 // Reference: Wavernn.forward (wavernn.py:69-95); callers as in predictor.hip.
 
 constexpr int FGW = 3, FGT = FGW * 64, BGT = NT - FGT;
