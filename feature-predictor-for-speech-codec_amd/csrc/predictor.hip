@@ -67,6 +67,7 @@ struct SplitCtx {
     unsigned epoch = 0;             // last epoch used
     bool dead = false;              // a spin gave up: no further waiting in this workgroup
     bool withhold = false;          // test hook (FPC_TEST_WITHHOLD_PUBLISH=1): this workgroup never publishes
+    bool fast = false;              // every workgroup of the utterance reported the same XCD: plain stores (predictor_df.h)
 };
 constexpr unsigned FPC_ST_TIMEOUT = 1u, FPC_ST_NONFINITE = 2u;
 typedef __attribute__((address_space(1))) unsigned gu32;

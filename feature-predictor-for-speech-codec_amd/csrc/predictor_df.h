@@ -197,14 +197,59 @@ __device__ __forceinline__ void gates_df(const float* pin, int pitch_in, int Sin
         }
     }
 }
+// ---- exchange inside one XCD ------------------------------------------------------------------------------------------
+// A hop is a store that has to become visible to the partner's polling load.  The general form (store_granule: sc1) writes
+// through to memory because the partner may sit on another XCD, whose L2 is not coherent with this one; when ALL
+// workgroups of an utterance run on the same XCD, a plain store stays in that XCD's L2, where the partners' L1-bypassing
+// loads find it: tools/ubench/ub5.hip measures 1.35k cycles per hop instead of 2.0k, and no fabric write per value.
+// Placement is never assumed: the kernels only ARRANGE for it (blocks b and b + 8 share an XCD under the round-robin
+// dealing the hardware is observed to do, so the slices of an utterance are given block indices 8 apart), every workgroup
+// reads its own XCD id from the hardware register, the ids go round once through the general path, and the plain stores
+// are used only if all of them agree -- a different dealing costs speed, never correctness.
+__device__ __forceinline__ void df_block_role(const SplitArgs& S, int& b, int& half) {
+    const int i = blockIdx.x, n = S.n, B = gridDim.x / n;
+    if (n > 1 && B % 8 == 0) {
+        const int x = i % 8, m = i / 8;
+        b = (m / n) * 8 + x;
+        half = m % n;
+    } else {
+        b = i / n;
+        half = i % n;
+    }
+}
+__device__ __forceinline__ void store_granule_plain(unsigned long long* g, unsigned epoch, float v) {
+    const unsigned long long w = ((unsigned long long)epoch << 32) | (unsigned long long)__float_as_uint(v);
+    asm volatile("global_store_dwordx2 %0, %1, off" ::"v"(g), "v"(w) : "memory");
+}
+// once per launch, by all threads (ends with barriers): X.fast, or X.dead if a partner never shows up
+__device__ __forceinline__ void df_hello(SplitCtx& X, int tid) {
+    if (X.n == 1) return;
+    unsigned xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    xcc = (xcc & 0xfu) + 1u;
+    const unsigned tag = 0xffffffffu;  // (no frame's epoch; the granules g3 are unused by these kernels otherwise)
+    if (tid == 0 && !X.withhold) store_granule(&X.g3[X.half], tag, __uint_as_float(xcc));
+    bool same = true, gave_up = false;
+    if (tid < X.n && tid != X.half) same = __float_as_uint(await_granule(&X.g3[tid], tag, X, gave_up)) == xcc;
+    if (__syncthreads_or(gave_up)) X.dead = true;
+    X.fast = __syncthreads_and(same) != 0 && !X.dead;
+#ifdef FPC_NO_FAST_HOP
+    X.fast = false;
+#endif
+}
+
 // one hop by the foreground threads: this workgroup's slice goes out under a new epoch, the others come in
 // (same thread -> unit mapping as gates_df: a thread publishes the units it has just computed)
 __device__ __forceinline__ void hop_df(float* h, int H, SplitCtx& X, unsigned long long* g, int ft, DfLds& L) {
     if (X.n == 1) return;
     const int Hs = H / X.n, mine = X.half * Hs;
     const unsigned epoch = ++X.epoch;
-    if (!X.withhold)
-        for (int i = ft; i < Hs; i += FGT) store_granule(&g[mine + i], epoch, h[mine + i]);
+    if (!X.withhold) {
+        if (X.fast)
+            for (int i = ft; i < Hs; i += FGT) store_granule_plain(&g[mine + i], epoch, h[mine + i]);
+        else
+            for (int i = ft; i < Hs; i += FGT) store_granule(&g[mine + i], epoch, h[mine + i]);
+    }
     bool gave_up = false;
     for (int ii = ft; ii < H - Hs; ii += FGT) {
         const int i = ii < mine ? ii : ii + Hs;
@@ -416,7 +461,9 @@ __device__ __forceinline__ bool df_background(const DfStep& D, DfLds& L, int n, 
 __global__ __launch_bounds__(NT) void k_forward_df(const PredDev P, const float* __restrict__ x, int Lf, float* h1, float* h2,
                                                    float* __restrict__ y, const SplitArgs S) {
     __shared__ DfLds L;
-    const int b = blockIdx.x / S.n, half = blockIdx.x % S.n, tid = threadIdx.x;
+    const int tid = threadIdx.x;
+    int b, half;
+    df_block_role(S, b, half);
     SplitCtx X = split_ctx(S, P, b, half);
     const bool writer = half == 0;
     for (int i = tid; i < P.h1; i += NT) L.h1[i] = h1[(size_t)b * P.h1 + i];
@@ -425,6 +472,9 @@ __global__ __launch_bounds__(NT) void k_forward_df(const PredDev P, const float*
     __syncthreads();
     const DfStep D = df_setup(P, L, S.n);
     df_prologue(P, D, L, tid, S.n, half);
+    df_hello(X, tid);
+    if (X.dead && tid == 0) L.dead = 1;
+    __syncthreads();
 #ifdef FPC_PRED_PROF
     if (tid == 0) {
         for (int i = 0; i < 17; ++i) L.pprof[i] = 0;
@@ -478,7 +528,9 @@ __global__ __launch_bounds__(NT) void k_forward_df(const PredDev P, const float*
 
 __global__ __launch_bounds__(NT) void k_encode_df(const PredDev P, const CbDev C, const EncArgs A, const SplitArgs S) {
     __shared__ DfLds L;
-    const int b = blockIdx.x / S.n, half = blockIdx.x % S.n, tid = threadIdx.x;
+    const int tid = threadIdx.x;
+    int b, half;
+    df_block_role(S, b, half);
     SplitCtx X = split_ctx(S, P, b, half);
     const bool writer = half == 0;
     for (int i = tid; i < P.h1; i += NT) L.h1[i] = 0.0f;
@@ -487,6 +539,9 @@ __global__ __launch_bounds__(NT) void k_encode_df(const PredDev P, const CbDev C
     __syncthreads();
     const DfStep D = df_setup(P, L, S.n);
     df_prologue(P, D, L, tid, S.n, half);
+    df_hello(X, tid);
+    if (X.dead && tid == 0) L.dead = 1;
+    __syncthreads();
 #ifdef FPC_PRED_PROF
     if (tid == 0) {
         for (int k = 0; k < 17; ++k) L.pprof[k] = 0;
@@ -524,7 +579,9 @@ __global__ __launch_bounds__(NT) void k_decode_feat_df(const PredDev P, const Cb
                                                        const int* __restrict__ idx, int Lf, float* __restrict__ c_out,
                                                        int* bad, const SplitArgs S) {
     __shared__ DfLds L;
-    const int b = blockIdx.x / S.n, half = blockIdx.x % S.n, tid = threadIdx.x;
+    const int tid = threadIdx.x;
+    int b, half;
+    df_block_role(S, b, half);
     SplitCtx X = split_ctx(S, P, b, half);
     const bool writer = half == 0;
     for (int i = tid; i < P.h1; i += NT) L.h1[i] = 0.0f;
@@ -533,6 +590,9 @@ __global__ __launch_bounds__(NT) void k_decode_feat_df(const PredDev P, const Cb
     __syncthreads();
     const DfStep D = df_setup(P, L, S.n);
     df_prologue(P, D, L, tid, S.n, half);
+    df_hello(X, tid);
+    if (X.dead && tid == 0) L.dead = 1;
+    __syncthreads();
     int done = 0;  // frames completed (foreground)
     if (tid < FGT) {
         __builtin_amdgcn_s_setprio(FPC_FG_PRIO);
