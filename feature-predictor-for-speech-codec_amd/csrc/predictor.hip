@@ -40,6 +40,7 @@ constexpr int NT = FPC_NT;
 constexpr int NW = NT / 64;
 constexpr int MAX_H1 = 512, MAX_H2 = 256, MAX_IN = 64, MAX_FC = 32;
 constexpr int NDIM = 17, SURV = 5;
+constexpr int SCLC = 512;  // scalar codes kept in LDS by the encoder (4 kB)
 
 // ---- row split: one utterance on NSPLIT workgroups (SURVEY 2.1 "row-sliced weights-stationary across CUs") ----
 // Every frame streams the whole 2.67 MB weight set through ONE CU's L2 port (25 us at ~108 GB/s), 300 frames in
@@ -149,6 +150,14 @@ struct CbDev {
     const double *scl_hi, *scl_lo;
 };
 
+// workgroup barrier for data that changes hands through LDS only: __syncthreads also waits for the wave's outstanding
+// global stores (vmcnt), a round trip the frame tail does not need
+__device__ __forceinline__ void lds_barrier() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
 // scratch of the residual searches (one utterance at a time)
 struct __attribute__((aligned(16))) SearchLds {
     float rs[MAX_FC];           // residual of the frame: rs[0] scalar, rs[1..17] the VQ target
@@ -162,6 +171,7 @@ struct __attribute__((aligned(16))) SearchLds {
     int res_i[4];
     double qv[NDIM];
     double qs;
+    double sclc[SCLC];  // the scalar codebooks (above-threshold codes, then the below-threshold ones) when they fit: k_encode_df
 #ifdef FPC_VQ_PROF
     long long prof[16];  // diagnostic builds only: cycle stamps of the search phases
 #endif
@@ -817,6 +827,58 @@ __device__ void scl_search(SearchLds& L, float xv, const double* __restrict__ co
     __syncthreads();
 }
 
+// scl_search with the codes in LDS (L.sclc[off .. off + n)): the same scan, the same arg-min, no L2 round trips -- the
+// global form costs the frame two of them (the scan's loads, then the winner's code), ~3.3k cycles on every frame
+__device__ __forceinline__ void scl_search_lds(SearchLds& L, float xv, int off, int n, int tid) {
+    const int wave = tid >> 6, lane = tid & 63;
+    double bd = INFINITY;
+    int bi = 0x7fffffff;
+    const double v = (double)xv;
+    if (n <= 256) {
+        if (wave == 0) {
+            for (int c = lane; c < n; c += 64) {
+                const double df = v - L.sclc[off + c];
+                const double d = df * df;
+                if (d < bd) {
+                    bd = d;
+                    bi = c;
+                }
+            }
+            wave_argmin(bd, bi);
+            if (lane == 0) {
+                L.res_i[2] = bi;
+                L.qs = L.sclc[off + bi];
+            }
+        }
+        lds_barrier();
+        return;
+    }
+    for (int c = tid; c < n; c += NT) {
+        const double df = v - L.sclc[off + c];
+        const double d = df * df;
+        if (d < bd) {
+            bd = d;
+            bi = c;
+        }
+    }
+    wave_argmin(bd, bi);
+    if (lane == 0) {
+        L.sd[wave] = bd;
+        L.si[wave] = bi;
+    }
+    lds_barrier();
+    if (wave == 0) {
+        double d = lane < NW ? L.sd[lane] : INFINITY;
+        int ix = lane < NW ? L.si[lane] : 0x7fffffff;
+        wave_argmin(d, ix);
+        if (lane == 0) {
+            L.res_i[2] = ix;
+            L.qs = L.sclc[off + ix];
+        }
+    }
+    lds_barrier();
+}
+
 // ---------------------------------------------------------------------------------
 struct SplitArgs {
     int n;                    // workgroups per utterance (1, 2, 4 or 8)
@@ -904,7 +966,8 @@ struct EncArgs {
 // fv: this thread's column of the frame's feature row (tid < Cc), fetched by the caller before the predictor step so
 // that its latency is off the closed loop.
 __device__ __forceinline__ void encode_frame(SearchLds& L, const float* fo, float* xn, const PredDev& P, const CbDev& C,
-                                             const EncArgs& A, unsigned* err, size_t fi, float fv, bool store, int tid) {
+                                             const EncArgs& A, unsigned* err, size_t fi, float fv, bool store, int tid,
+                                             bool scl_in_lds = false) {
     const int Cc = P.in, F = P.fc;
     const int off_sl = C.n_hi, off_v0 = off_sl + C.n_lo, off_v1 = off_v0 + C.N_hi0,
               off_vl = off_v1 + (C.S_hi == 2 ? C.N_hi1 : 0);
@@ -924,7 +987,10 @@ __device__ __forceinline__ void encode_frame(SearchLds& L, const float* fo, floa
     if (nonfinite) ix0 = ix1 = ix2 = ix3 = -2;
     if (A.qtz && !nonfinite) {
         if (i1 || C.scl_lo) {  // :218-225
-            scl_search(L, L.rs[0], i1 ? C.scl_hi : C.scl_lo, i1 ? C.n_hi : C.n_lo, tid);
+            if (scl_in_lds)
+                scl_search_lds(L, L.rs[0], i1 ? 0 : C.n_hi, i1 ? C.n_hi : C.n_lo, tid);
+            else
+                scl_search(L, L.rs[0], i1 ? C.scl_hi : C.scl_lo, i1 ? C.n_hi : C.n_lo, tid);
             if (tid == 0) {
                 rq = (float)L.qs;
                 ix0 = L.res_i[2] + (i1 ? 0 : C.n_hi);
@@ -986,7 +1052,7 @@ __device__ __forceinline__ void encode_frame(SearchLds& L, const float* fo, floa
             A.idx[fi * 4 + 3] = ix3;
         }
     }
-    __syncthreads();
+    lds_barrier();  // (the next input row is in LDS; the frame's global stores need not have landed)
 }
 // a launch that gave up at frame i0 fails loudly: NaN and symbols -2 from that frame on for utterance b (the histograms
 // are not touched any more); the host reports FPC_ERR_TIMEOUT

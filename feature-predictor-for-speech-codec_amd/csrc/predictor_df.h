@@ -538,6 +538,11 @@ __global__ __launch_bounds__(NT) void k_encode_df(const PredDev P, const CbDev C
     if (tid < P.in) L.x[tid] = 0.0f;
     __syncthreads();
     const DfStep D = df_setup(P, L, S.n);
+    const bool scl_in_lds = C.n_hi + C.n_lo <= SCLC;  // the scalar codebooks in LDS (the scalar search runs on every frame)
+    if (scl_in_lds) {
+        for (int k = tid; k < C.n_hi; k += NT) L.sclc[k] = C.scl_hi[k];
+        for (int k = tid; k < C.n_lo; k += NT) L.sclc[C.n_hi + k] = C.scl_lo[k];
+    }
     df_prologue(P, D, L, tid, S.n, half);
     df_hello(X, tid);
     if (X.dead && tid == 0) L.dead = 1;
@@ -563,7 +568,7 @@ __global__ __launch_bounds__(NT) void k_encode_df(const PredDev P, const CbDev C
         // the searches take the whole workgroup: both roles meet (fo(i) is ready, the streams of frame i are done)
         if (__syncthreads_or(L.dead != 0 || X.dead)) break;
         FSTAMP(14)
-        encode_frame(L, L.fo, L.x, P, C, A, S.err, (size_t)b * A.Lf + i, fv, writer, tid);
+        encode_frame(L, L.fo, L.x, P, C, A, S.err, (size_t)b * A.Lf + i, fv, writer, tid, scl_in_lds);
         FSTAMP(16)
     }
 #ifdef FPC_PRED_PROF
