@@ -1169,6 +1169,7 @@ __global__ __launch_bounds__(NT) FPC_OCC void k_decode_feat(const PredDev P, con
 }
 
 #include "predictor_df.h"
+#include "predictor_ws.h"
 
 // stand-alone quantizers: one workgroup per input row
 __global__ __launch_bounds__(NT) void k_vq(const CbDev C, int which, const float* __restrict__ r, double* qr,
@@ -1621,6 +1622,7 @@ struct fpc_predictor {
     fpc::DevBuf buf[10];
     fpc::DevBuf flag;  // one int: "a symbol lay outside its codebook" (fpc_decode_features), allocated once per handle
     fpc::DevBuf xg;    // row-split exchange granules [B][2][h1 + h2] x 8 bytes, grown on demand
+    fpc::DevBuf wsg;   // weights-stationary form (predictor_ws.h): granule blocks [groups][WGRANULES] x 16 bytes
     // status word: host-mapped pinned memory the kernels OR failure bits into (FPC_ST_*); sticky until
     // fpc_predictor_status() clears it; read by the host without a synchronisation at the start of every call
     unsigned* status_host = nullptr;
@@ -1707,6 +1709,53 @@ static int split_args(fpc_predictor* p, int B, hipStream_t st, SplitArgs* out) {
     out->g = p->xg.as<unsigned long long>();
     return FPC_OK;
 }
+
+// The weights-stationary kernels (predictor_ws.h) serve the reference's production shape on a whole MI355X (8 XCDs x 32
+// CUs) whenever the caller has not pinned a row split: FPC_PRED_WS=0 turns them off (tests compare the forms bit for
+// bit), a pinned split (fpc_predictor_set_split, FPC_PRED_SPLIT) or FPC_PRED_DF=0 selects the row-split kernels.
+static bool ws_wanted(const fpc_predictor* p) {
+    if (p->d.in != WIN || p->d.h1 != WH1 || p->d.h2 != WH2 || p->d.fc != WFC) return false;
+    if (p->num_cus < 8 * WNS || p->forced_split != 0) return false;
+    if (getenv("FPC_PRED_SPLIT")) return false;
+    if (const char* e = getenv("FPC_PRED_DF"))
+        if (e[0] == '0') return false;
+    if (const char* e = getenv("FPC_PRED_WS"))
+        if (e[0] == '0') return false;
+    return true;
+}
+// granule blocks zeroed on the stream, test hooks read; the grid is ws_grid(args) workgroups
+static int ws_args(fpc_predictor* p, int B, hipStream_t st, WsArgs* out) {
+    out->B = B;
+    out->ngroups = (B + WG - 1) / WG;
+    out->err = p->status_dev;
+    out->limit = 100000000ull;  // 1 s of s_memrealtime (100 MHz)
+    out->withhold = 0;
+    out->no_fast = 0;
+    if (const char* lim = getenv("FPC_SPIN_LIMIT_US")) {  // test hook: a shorter give-up bound
+        const long us = atol(lim);
+        if (us > 0) out->limit = (unsigned long long)us * 100ull;
+    }
+    if (const char* wh = getenv("FPC_TEST_WITHHOLD_PUBLISH")) out->withhold = wh[0] == '1';  // test hook
+    if (const char* fh = getenv("FPC_FAST_HOP")) out->no_fast = fh[0] == '0';  // the write-through path everywhere
+    {
+        const int rc = before_launch(p, st);
+        if (rc != FPC_OK) return rc;
+    }
+    const size_t bytes = (size_t)out->ngroups * WGRANULES * sizeof(u32x4);
+    if (p->wsg.bytes < bytes) {
+        if (p->wsg.p) {
+            FPC_HIP(hipDeviceSynchronize());  // nothing may still be polling the old block (on any stream)
+            (void)hipFree(p->wsg.p);
+            p->wsg.p = nullptr;
+        }
+        FPC_HIP(p->wsg.alloc(bytes));
+    }
+    FPC_HIP(hipMemsetAsync(p->wsg.p, 0, bytes, st));  // tags start at 0; epochs count from 1 within the launch
+    out->g = p->wsg.as<u32x4>();
+    return FPC_OK;
+}
+// 32 workgroups per group, the groups dealt over the XCDs (ws_role): 256 workgroups per round of 8 groups
+static unsigned ws_grid(const WsArgs& a) { return 8u * WNS * (unsigned)((a.ngroups + 7) / 8); }
 
 // the two-role kernels (predictor_df.h) are the shipped form; FPC_PRED_DF=0 runs the phase-after-phase kernels (tests
 // compare the two bit for bit)
@@ -1798,6 +1847,15 @@ extern "C" int fpc_predictor_forward(fpc_predictor* p, const float* x_dev, int B
     FPC_REQUIRE(p && x_dev && h1_dev && h2_dev && y_dev, "fpc_predictor_forward: null argument");
     FPC_REQUIRE(B > 0 && L >= 0, "fpc_predictor_forward: bad shape B=%d L=%d", B, L);
     if (const int se = status_error(p, "fpc_predictor_forward")) return se;  // an earlier launch on the handle failed
+    if (ws_wanted(p)) {
+        WsArgs wa;
+        const int rcw = ws_args(p, B, static_cast<hipStream_t>(s), &wa);
+        if (rcw != FPC_OK) return rcw;
+        hipLaunchKernelGGL(k_forward_ws, dim3(ws_grid(wa)), dim3(NT), 0, static_cast<hipStream_t>(s), p->d, x_dev, L, h1_dev,
+                           h2_dev, y_dev, wa);
+        FPC_HIP(hipGetLastError());
+        return after_launch(p, static_cast<hipStream_t>(s));
+    }
     SplitArgs sp;
     const int rc = split_args(p, B, static_cast<hipStream_t>(s), &sp);
     if (rc != FPC_OK) return rc;
@@ -1911,6 +1969,14 @@ extern "C" int fpc_encode(fpc_predictor* p, const fpc_codebooks* cb, const float
     if (cb) cd = cb->d;
     EncArgs a{feat_dev, L,  l1, l2, qtz ? 1 : 0, c_in_dev, r_dev, r_qtz_dev, r_under_dev, ind1_dev, ind2_dev,
               idx_dev,  hist_dev};
+    if (ws_wanted(p)) {
+        WsArgs wa;
+        const int rcw = ws_args(p, B, static_cast<hipStream_t>(s), &wa);
+        if (rcw != FPC_OK) return rcw;
+        hipLaunchKernelGGL(k_encode_ws, dim3(ws_grid(wa)), dim3(NT), 0, static_cast<hipStream_t>(s), p->d, cd, a, wa);
+        FPC_HIP(hipGetLastError());
+        return after_launch(p, static_cast<hipStream_t>(s));
+    }
     SplitArgs sp;
     const int rc = split_args(p, B, static_cast<hipStream_t>(s), &sp);
     if (rc != FPC_OK) return rc;
@@ -1944,9 +2010,16 @@ extern "C" int fpc_decode_features(fpc_predictor* p, const fpc_codebooks* cb, co
     // check itself needs this stream's result, so the call still ends with a sync of this one stream
     FPC_HIP(hipMemsetAsync(p->flag.p, 0, sizeof(int), st));
     SplitArgs sp;
-    const int rc = split_args(p, B, st, &sp);
-    if (rc != FPC_OK) return rc;
-    if (two_roles())
+    sp.n = 1;
+    if (ws_wanted(p)) {
+        WsArgs wa;
+        const int rcw = ws_args(p, B, st, &wa);
+        if (rcw != FPC_OK) return rcw;
+        hipLaunchKernelGGL(k_decode_feat_ws, dim3(ws_grid(wa)), dim3(NT), 0, st, p->d, cb->d, pitch_dev, idx_dev, L, c_out_dev,
+                           p->flag.as<int>(), wa);
+    } else if (const int rc = split_args(p, B, st, &sp)) {
+        return rc;
+    } else if (two_roles())
         hipLaunchKernelGGL(k_decode_feat_df, dim3(B * sp.n), dim3(NT), 0, st, p->d, cb->d, pitch_dev, idx_dev, L, c_out_dev,
                            p->flag.as<int>(), sp);
     else
