@@ -148,6 +148,7 @@ struct CbDev {
     const double *vq_hi0, *vq_hi1, *vq_lo;     // transposed [17][N]
     const double *vq_hi0_r, *vq_hi1_r, *vq_lo_r;  // row-major [N][17] (entry fetch)
     const double *scl_hi, *scl_lo;
+    const double *vq_hi0_p, *vq_hi1_p, *vq_lo_p;  // coordinate pairs [9][N][2] (16-byte loads, one entry per lane; coordinate 17 = 0)
 };
 
 // workgroup barrier for data that changes hands through LDS only: __syncthreads also waits for the wave's outstanding
@@ -1723,6 +1724,17 @@ static bool ws_wanted(const fpc_predictor* p) {
         if (e[0] == '0') return false;
     return true;
 }
+struct fpc_codebooks {
+    CbDev d;
+    fpc::DevBuf buf[11];
+    int hist_size = 0;
+};
+// the encoder's frame tail of these kernels (ws_encode_tail) holds two entries of a stage per thread and the scalar codes in LDS
+static bool ws_codebooks_fit(const fpc_codebooks* cb) {
+    if (!cb) return true;
+    const CbDev& c = cb->d;
+    return c.N_hi0 <= 2 * NT && c.N_hi1 <= 2 * NT && c.N_lo <= 2 * NT && c.n_hi <= 256 && c.n_lo <= 256 && c.n_hi + c.n_lo <= SCLC;
+}
 // granule blocks zeroed on the stream, test hooks read; the grid is ws_grid(args) workgroups
 static int ws_args(fpc_predictor* p, int B, hipStream_t st, WsArgs* out) {
     out->B = B;
@@ -1754,6 +1766,18 @@ static int ws_args(fpc_predictor* p, int B, hipStream_t st, WsArgs* out) {
     out->g = p->wsg.as<u32x4>();
     return FPC_OK;
 }
+#ifdef FPC_WS_PROF
+// diagnostic builds: cycles per frame and stage of workgroup 5 of group 0 (thread 0 = foreground, thread 256 = background)
+static void ws_prof_print(fpc_predictor* p, const char* who, int B, hipStream_t st) {
+    (void)hipStreamSynchronize(st);
+    volatile unsigned* w = (volatile unsigned*)p->status_host;
+    fprintf(stderr, "%s B=%d cycles/frame FG: I %u waitA %u gates1 %u gather1 %u waitH1 %u C %u waitB %u gates2 %u gather2 %u waitH2 %u "
+            "fc %u out %u tail %u | rendezvous %u frame-tail %u hop3 %u | BG wave 1: waitP1 %u gather1 %u waitH1 %u A %u waitC %u (unused %u) "
+            "toRendezvous %u rest %u | tail: loads+scalar %u dist1+min %u bound+append %u rank %u survivors %u stage2 %u final %u\n", who, B, w[1], w[2], w[3], w[4], w[5], w[6], w[7], w[8], w[9], w[10], w[11], w[12], w[13],
+            w[21], w[22], w[23], w[14], w[15], w[16], w[17], w[18], w[19], w[20], w[24], w[26], w[27], w[28], w[29], w[30], w[31], w[32]);
+    for (int k = 1; k < 40; ++k) w[k] = 0;
+}
+#endif
 // 32 workgroups per group, the groups dealt over the XCDs (ws_role): 256 workgroups per round of 8 groups
 static unsigned ws_grid(const WsArgs& a) { return 8u * WNS * (unsigned)((a.ngroups + 7) / 8); }
 
@@ -1768,11 +1792,6 @@ static void predictor_unref(fpc_predictor* p) {
     if (p && p->refs.fetch_sub(1) <= 1) delete p;
 }
 
-struct fpc_codebooks {
-    CbDev d;
-    fpc::DevBuf buf[8];
-    int hist_size = 0;
-};
 
 static std::vector<float> transpose_f(const float* src, int rows, int cols) {
     std::vector<float> t((size_t)rows * cols);
@@ -1823,9 +1842,9 @@ extern "C" int fpc_predictor_create(const fpc_predictor_weights* w, fpc_predicto
     FPC_HIP(p->flag.alloc(sizeof(int)));
     {
         void* hp = nullptr;
-        FPC_HIP(hipHostMalloc(&hp, 64, hipHostMallocMapped));
+        FPC_HIP(hipHostMalloc(&hp, 256, hipHostMallocMapped));
         p->status_host = static_cast<unsigned*>(hp);
-        memset(hp, 0, 64);
+        memset(hp, 0, 256);
         void* dp = nullptr;
         FPC_HIP(hipHostGetDevicePointer(&dp, hp, 0));
         p->status_dev = static_cast<unsigned*>(dp);
@@ -1854,6 +1873,9 @@ extern "C" int fpc_predictor_forward(fpc_predictor* p, const float* x_dev, int B
         hipLaunchKernelGGL(k_forward_ws, dim3(ws_grid(wa)), dim3(NT), 0, static_cast<hipStream_t>(s), p->d, x_dev, L, h1_dev,
                            h2_dev, y_dev, wa);
         FPC_HIP(hipGetLastError());
+#ifdef FPC_WS_PROF
+        ws_prof_print(p, "k_forward_ws", B, static_cast<hipStream_t>(s));
+#endif
         return after_launch(p, static_cast<hipStream_t>(s));
     }
     SplitArgs sp;
@@ -1920,21 +1942,28 @@ extern "C" int fpc_codebooks_create(const double* vq_hi, int S_hi, const int* N_
     c->d.N_lo = N_lo;
     c->d.n_hi = n_hi;
     c->d.n_lo = n_lo;
-    auto up_cb = [&](int slot, const double* src, int N, const double** dT, const double** dR) -> hipError_t {
-        std::vector<double> t((size_t)N * NDIM), r(src, src + (size_t)N * NDIM);
+    auto up_cb = [&](int slot, int pslot, const double* src, int N, const double** dT, const double** dR,
+                     const double** dP) -> hipError_t {
+        std::vector<double> t((size_t)N * NDIM), r(src, src + (size_t)N * NDIM), pr((size_t)(NDIM + 1) * N, 0.0);
         for (int e = 0; e < N; ++e)
-            for (int d = 0; d < NDIM; ++d) t[(size_t)d * N + e] = src[(size_t)e * NDIM + d];
+            for (int d = 0; d < NDIM; ++d) {
+                t[(size_t)d * N + e] = src[(size_t)e * NDIM + d];
+                pr[((size_t)(d / 2) * N + e) * 2 + (d & 1)] = src[(size_t)e * NDIM + d];
+            }
         hipError_t e1 = c->buf[slot].upload(t);
         if (e1 != hipSuccess) return e1;
         *dT = c->buf[slot].as<double>();
         e1 = c->buf[slot + 1].upload(r);
+        if (e1 != hipSuccess) return e1;
         *dR = c->buf[slot + 1].as<double>();
+        e1 = c->buf[pslot].upload(pr);
+        *dP = c->buf[pslot].as<double>();
         return e1;
     };
-    FPC_HIP(up_cb(0, vq_hi, N_hi[0], &c->d.vq_hi0, &c->d.vq_hi0_r));
+    FPC_HIP(up_cb(0, 8, vq_hi, N_hi[0], &c->d.vq_hi0, &c->d.vq_hi0_r, &c->d.vq_hi0_p));
     if (S_hi == 2)
-        FPC_HIP(up_cb(2, vq_hi + (size_t)N_hi[0] * NDIM, N_hi[1], &c->d.vq_hi1, &c->d.vq_hi1_r));
-    if (vq_lo) FPC_HIP(up_cb(4, vq_lo, N_lo, &c->d.vq_lo, &c->d.vq_lo_r));
+        FPC_HIP(up_cb(2, 9, vq_hi + (size_t)N_hi[0] * NDIM, N_hi[1], &c->d.vq_hi1, &c->d.vq_hi1_r, &c->d.vq_hi1_p));
+    if (vq_lo) FPC_HIP(up_cb(4, 10, vq_lo, N_lo, &c->d.vq_lo, &c->d.vq_lo_r, &c->d.vq_lo_p));
     {
         std::vector<double> v(scl_hi, scl_hi + n_hi);
         FPC_HIP(c->buf[6].upload(v));
@@ -1969,12 +1998,15 @@ extern "C" int fpc_encode(fpc_predictor* p, const fpc_codebooks* cb, const float
     if (cb) cd = cb->d;
     EncArgs a{feat_dev, L,  l1, l2, qtz ? 1 : 0, c_in_dev, r_dev, r_qtz_dev, r_under_dev, ind1_dev, ind2_dev,
               idx_dev,  hist_dev};
-    if (ws_wanted(p)) {
+    if (ws_wanted(p) && ws_codebooks_fit(cb)) {
         WsArgs wa;
         const int rcw = ws_args(p, B, static_cast<hipStream_t>(s), &wa);
         if (rcw != FPC_OK) return rcw;
         hipLaunchKernelGGL(k_encode_ws, dim3(ws_grid(wa)), dim3(NT), 0, static_cast<hipStream_t>(s), p->d, cd, a, wa);
         FPC_HIP(hipGetLastError());
+#ifdef FPC_WS_PROF
+        ws_prof_print(p, qtz ? "k_encode_ws qtz=1" : "k_encode_ws qtz=0", B, static_cast<hipStream_t>(s));
+#endif
         return after_launch(p, static_cast<hipStream_t>(s));
     }
     SplitArgs sp;

@@ -6,11 +6,11 @@
 // for 170 MFLOP.  Here a GROUP of 16 utterances (= the M dimension of one v_mfma_f32_16x16x4_f32 tile) runs on the 32
 // workgroups of one XCD (one per CU; 8 groups = 128 utterances fill the chip), and workgroup s keeps 1/32 of every
 // matrix for the whole launch:
-//   GRU1 units 12 s .. 12 s + 11  -> 36 gate rows of W1h (384 x 36, 55 kB) in the REGISTERS of the four background waves
-//                                    (wave w holds input segment w: 24 k-steps x 3 gate tiles = 72 B-operand registers),
-//                                    36 rows of W1i (20 x 36) in LDS,
-//   GRU2 units  4 s ..  4 s + 3   -> 12 gate rows of W2i (384 x 12) and W2h (128 x 12) in LDS,
-//   the output layer (128 x 18)   -> in LDS, evaluated by every workgroup (its 64 MFMAs cost less than a hop).
+//   GRU1 units 12 s .. 12 s + 11  -> 36 gate rows of W1h (384 x 36, 55 kB) and of W1i (20 x 36),
+//   GRU2 units  4 s ..  4 s + 3   -> 12 gate rows of W2i (384 x 12) and W2h (128 x 12),
+//   the output layer (128 x 18)   -> whole, evaluated by the workgroups that own an utterance (64 MFMAs: less than a hop),
+// all in LDS (92 kB of weights in rows of 12 floats, so that the four k of an MFMA step read disjoint banks; registers
+// would hold W1h as well -- 72 per lane of the background waves -- but the encoder's float64 searches need them).
 // Per frame a workgroup evaluates its gate rows for all 16 utterances at once: A operand = the state image in LDS
 // ([k][utterance]: lane l of k-step j reads image[64 j + l]), B operand = the weights, one wave per INPUT SEGMENT, the
 // accumulator initialised with the bias for segment 0 and with 0 for the others, segment sums added as a balanced tree by the
@@ -49,7 +49,7 @@ constexpr int WOFF_HELLO = 0, WOFF_H1 = WNS, WOFF_H2 = WOFF_H1 + WNS * WQ1, WOFF
               WGRANULES = WOFF_X + WG * WQX;  // 2 880 granules = 46 080 bytes
 static_assert(NT == 512, "predictor_ws.h is written for 8 waves per workgroup");
 static_assert(WH1 / 4 == 96 && WH2 / 2 == 64 && WFC == NDIM + 1, "production shape");
-enum { WSIG_A = 0, WSIG_B, WSIG_H1, WSIG_H2, WSIG_P1, WSIG_FG, WNSIG };
+enum { WSIG_A = 0, WSIG_B, WSIG_H1, WSIG_H2, WSIG_P1, WSIG_P2, WSIG_C, WSIG_FG, WNSIG };
 
 struct WsArgs {
     int B, ngroups;
@@ -68,17 +68,59 @@ struct __attribute__((aligned(16))) WsLds : SearchLds {
     float pA[4][3][256];      // [segment][gate][...]
     float pC[4][256];         // [segment][(gate * 4 + unit) * 16 + utterance]
     float pB[2][256];
-    float pF[8][2][256];      // [segment][tile][row in tile * 16 + utterance]
+    float pF[8][2][16];       // [segment][tile][row in tile]: the owned utterance only
     float fo[WG][WIN];        // predictions [utterance][row < 18]
     float xn[MAX_IN];         // the owner's next input row
-    float w1i[WIN * 3 * WU1];  // [k][gate * 12 + unit]
+    float w1h[3 * WH1 * WU1];  // [gate][k][unit]: rows of 12 floats, so the four k of an MFMA step sit in disjoint banks
+    float w1i[3 * WIN * WU1];  // [gate][k][unit]
     float w2i[WH1 * 3 * WU2];  // [k][gate * 4 + unit]
     float w2h[WH2 * 3 * WU2];
     float fcw[WH2 * WFC];      // [k][row]
     int sig[WNSIG];
     int dead;
     int same_xcd;
+    // scratch of the frame tail's searches (ws_encode_tail)
+    double cand_d[64];           // first-stage entries at or below the bound, in arrival order
+    int cand_i[64];
+    int ncand;
+    double wmin[NW];             // per-wave smallest first-stage distance
+    double ent[SURV][NDIM + 1];  // the survivors' first-stage entries
+    int sv[SURV];                // the survivors
+    double od2[SURV];            // best second-stage entry per survivor
+    int oi2[SURV];
+#ifdef FPC_WS_PROF
+    long long wprof[32], wlast, wlast_bg;  // diagnostic builds: cycles per stage, foreground [0..13) + [19..24), background [13..19)
+#endif
 };
+#ifdef FPC_WS_PROF
+#define WSTAMP(k)                                            \
+    if (threadIdx.x == 0) {                                  \
+        const long long now_ = __builtin_readcyclecounter(); \
+        L.wprof[k] += now_ - L.wlast;                        \
+        L.wlast = now_;                                      \
+    }
+#define WBSTAMP(k)                                           \
+    if (threadIdx.x == WFGT + 64) {                          \
+        const long long now_ = __builtin_readcyclecounter(); \
+        L.wprof[k] += now_ - L.wlast_bg;                     \
+        L.wlast_bg = now_;                                   \
+    }
+#define WPROF_INIT()                                              \
+    if (threadIdx.x == 0) {                                       \
+        for (int k_ = 0; k_ < 32; ++k_) L.wprof[k_] = 0;          \
+        L.wlast = L.wlast_bg = __builtin_readcyclecounter();      \
+    }                                                             \
+    __syncthreads();
+#define WPROF_DUMP(frames)                                                                             \
+    __syncthreads();                                                                                   \
+    if (threadIdx.x < 32 && blockIdx.x == 8 * 5)                                                        \
+        S.err[1 + threadIdx.x] = (unsigned)(L.wprof[threadIdx.x] / ((frames) > 0 ? (frames) : 1));
+#else
+#define WSTAMP(k)
+#define WBSTAMP(k)
+#define WPROF_INIT()
+#define WPROF_DUMP(frames)
+#endif
 
 struct WsCtx {
     __amdgpu_buffer_rsrc_t rs;  // this group's granule block
@@ -88,6 +130,14 @@ struct WsCtx {
     bool fast, withhold;
 };
 
+// a zero the compiler cannot see through: added to a lane index at the top of a frame's role function, it keeps the frame's
+// address arithmetic inside the frame loop (hoisted out of it, the per-lane offsets of every unrolled access stay live across
+// the encoder's searches and spill)
+__device__ __forceinline__ int ws_opaque_zero() {
+    int z = 0;
+    asm volatile("" : "+v"(z));
+    return z;
+}
 __device__ __forceinline__ bool ws_dead(WsLds& L) {
     return __hip_atomic_load(&L.dead, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0;
 }
@@ -145,8 +195,7 @@ __device__ __forceinline__ bool ws_role(int ngroups, int& group, int& slice) {
 
 // per-wave constants of the matrix products (registers for the whole launch)
 struct WsRegs {
-    float wA[3][24];   // background wave w: W1h rows of this workgroup, input segment w, as MFMA B operands
-    float bA[3];       // (segment 0 only) b_hh of GRU1
+    float bA[3];       // background wave 1 (input segment 0): b_hh of GRU1
     float bB;          // b_hh of GRU2 (background wave 0)
     float bI;          // foreground wave w < 3: b_ih of GRU1, gate w
     float bC;          // foreground wave 0: b_ih of GRU2
@@ -155,9 +204,13 @@ struct WsRegs {
 
 // copies this workgroup's weight slices to LDS / registers (all threads; no barrier inside)
 __device__ __forceinline__ void ws_load_weights(const PredDev& P, WsLds& L, WsRegs& R, int slice, int tid) {
-    const int wave = tid >> 6, lane = tid & 63, c = lane & 15, q = lane >> 4;
-    for (int i = tid; i < WIN * 36; i += NT) {
-        const int k = i / 36, r = i - k * 36, g = r / WU1, u = r - g * WU1;
+    const int wave = tid >> 6, lane = tid & 63, c = lane & 15;
+    for (int i = tid; i < 3 * WH1 * WU1; i += NT) {
+        const int g = i / (WH1 * WU1), r = i - g * WH1 * WU1, k = r / WU1, u = r - k * WU1;
+        L.w1h[i] = P.w1h[(size_t)k * 3 * WH1 + g * WH1 + WU1 * slice + u];
+    }
+    for (int i = tid; i < 3 * WIN * WU1; i += NT) {
+        const int g = i / (WIN * WU1), r = i - g * WIN * WU1, k = r / WU1, u = r - k * WU1;
         L.w1i[i] = P.w1i[(size_t)k * 3 * WH1 + g * WH1 + WU1 * slice + u];
     }
     for (int i = tid; i < WH1 * 12; i += NT) {
@@ -170,23 +223,13 @@ __device__ __forceinline__ void ws_load_weights(const PredDev& P, WsLds& L, WsRe
     }
     for (int i = tid; i < WH2 * WFC; i += NT) L.fcw[i] = P.fcw[i];
     const int fw = wave, bw = wave - WFG;
-#pragma unroll
-    for (int g = 0; g < 3; ++g) {
-        R.bA[g] = 0.0f;
-#pragma unroll
-        for (int j = 0; j < 24; ++j) R.wA[g][j] = 0.0f;
-    }
+    R.bA[0] = R.bA[1] = R.bA[2] = 0.0f;
     R.bB = R.bI = R.bC = 0.0f;
     R.bF[0] = R.bF[1] = 0.0f;
     if (wave >= WFG) {
-        if (c < WU1) {
+        if (bw == 1 && c < WU1) {  // (input segment 0)
 #pragma unroll
-            for (int g = 0; g < 3; ++g) {
-                if (bw == 0) R.bA[g] = P.b1h[g * WH1 + WU1 * slice + c];
-#pragma unroll
-                for (int j = 0; j < 24; ++j)
-                    R.wA[g][j] = P.w1h[(size_t)(96 * bw + 4 * j + q) * 3 * WH1 + g * WH1 + WU1 * slice + c];
-            }
+            for (int g = 0; g < 3; ++g) R.bA[g] = P.b1h[g * WH1 + WU1 * slice + c];
         }
         if (bw == 0 && c < 12) R.bB = P.b2h[(c / WU2) * WH2 + WU2 * slice + (c % WU2)];
     } else {
@@ -194,7 +237,7 @@ __device__ __forceinline__ void ws_load_weights(const PredDev& P, WsLds& L, WsRe
         if (fw == 0) {
             if (c < 12) R.bC = P.b2i[(c / WU2) * WH2 + WU2 * slice + (c % WU2)];
             R.bF[0] = P.fcb[c];
-            if (c < WFC - 16) R.bF[1] = P.fcb[16 + c];
+            R.bF[1] = P.fcb[16 + (lane & 1)];  // (rows 16, 17 are evaluated by lanes 0-15: row = 16 + (lane & 1))
         }
     }
 }
@@ -228,90 +271,162 @@ __device__ __forceinline__ f32x4ws ws_mfma(float a, float b, f32x4ws c) { return
 __device__ __forceinline__ void ws_put(float* p, int lane, const f32x4ws& acc) {
     *reinterpret_cast<f32x4ws*>(&p[(lane & 15) * 16 + 4 * (lane >> 4)]) = acc;  // utterances 4 q .. 4 q + 3 of column c
 }
-// A = W1h h1: background wave bw = input segment, three gate tiles from register weights
+// A = W1h h1 on the background waves 1-3 (wave 0 of the role does no matrix work: it shares its SIMD with the foreground
+// wave that evaluates the GRU2 gates and polls the hops).  The f32 MFMA runs at the vector ALU's rate and keeps the SIMD's
+// vector issue busy while it does -- whatever else runs on that SIMD meanwhile takes 3-8x as long (measured: the chain's own
+// product 1.0k -> 3.4k cycles, the gates 0.8k -> 2.7k, a poll loop 1.4k -> 3.3k) -- so the 12 (segment, gate tile) units of
+// this product go to three SIMDs, 4 units = 96 MFMAs each: wave bw takes the three gate tiles of input segment bw - 1 and gate
+// tile bw - 1 of segment 3, four independent accumulators per k-step, state operands read up front, weights one step ahead.
 __device__ __forceinline__ void ws_A(WsLds& L, const WsRegs& R, int bw, int lane) {
-    f32x4ws acc[3];
+    const int c = lane & 15, q = lane >> 4, cc = c < WU1 ? c : WU1 - 1;
+    const int sg = bw - 1;  // 0..2
+    f32x4ws acc[4];
 #pragma unroll
     for (int g = 0; g < 3; ++g) acc[g] = f32x4ws{R.bA[g], R.bA[g], R.bA[g], R.bA[g]};
-    const float* hs = L.h1 + 96 * bw * WG + lane;
+    acc[3] = f32x4ws{0.f, 0.f, 0.f, 0.f};
+    const float* hs = L.h1 + 96 * sg * WG + lane;
+    const float* h3 = L.h1 + 96 * 3 * WG + lane;
+    const float* ws = L.w1h + (96 * sg + q) * WU1 + cc;
+    const float* w3 = L.w1h + sg * WH1 * WU1 + (96 * 3 + q) * WU1 + cc;  // gate tile sg of segment 3
+    float a[24], b[24], w[4], wn[4];
 #pragma unroll
     for (int j = 0; j < 24; ++j) {
-        const float a = hs[64 * j];
-#pragma unroll
-        for (int g = 0; g < 3; ++g) acc[g] = ws_mfma(a, R.wA[g][j], acc[g]);
+        a[j] = hs[64 * j];
+        b[j] = h3[64 * j];
     }
 #pragma unroll
-    for (int g = 0; g < 3; ++g) ws_put(L.pA[bw][g], lane, acc[g]);
+    for (int g = 0; g < 3; ++g) w[g] = ws[g * WH1 * WU1];
+    w[3] = w3[0];
+#pragma unroll
+    for (int j = 0; j < 24; ++j) {
+        if (j + 1 < 24) {
+#pragma unroll
+            for (int g = 0; g < 3; ++g) wn[g] = ws[g * WH1 * WU1 + 4 * WU1 * (j + 1)];
+            wn[3] = w3[4 * WU1 * (j + 1)];
+        }
+#pragma unroll
+        for (int g = 0; g < 3; ++g) acc[g] = ws_mfma(a[j], w[g], acc[g]);
+        acc[3] = ws_mfma(b[j], w[3], acc[3]);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) w[g] = wn[g];
+        __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);  // the next step's four weight reads
+        __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);  // this step's four MFMAs
+    }
+#pragma unroll
+    for (int g = 0; g < 3; ++g) ws_put(L.pA[sg][g], lane, acc[g]);
+    ws_put(L.pA[3][sg], lane, acc[3]);
 }
-// B = W2h h2: background waves 0, 1 = input segments of 64
-__device__ __forceinline__ void ws_B(WsLds& L, const WsRegs& R, int bw, int lane) {
+// B(t) = W2h h2(t-1), both input segments of 64 (two independent chains), by background wave 0 while hop 1 is in the air:
+// its SIMD partner, the foreground's wave 0, only sleeps on a counter then
+__device__ __forceinline__ void ws_B(WsLds& L, const WsRegs& R, int lane) {
     const int c = lane & 15, q = lane >> 4, cc = c < 12 ? c : 11;
-    f32x4ws acc = {R.bB, R.bB, R.bB, R.bB};
-    const float* hs = L.h2 + 64 * bw * WG + lane;
-    const float* ws = L.w2h + (64 * bw + q) * 12 + cc;
+    f32x4ws a0 = {R.bB, R.bB, R.bB, R.bB}, a1 = {0.f, 0.f, 0.f, 0.f};
+    const float* hs = L.h2 + lane;
+    const float* ws = L.w2h + q * 12 + cc;
+    float h0[16], h1[16];
 #pragma unroll
-    for (int j = 0; j < 16; ++j) acc = ws_mfma(hs[64 * j], ws[48 * j], acc);
-    ws_put(L.pB[bw], lane, acc);
+    for (int j = 0; j < 16; ++j) {
+        h0[j] = hs[64 * j];
+        h1[j] = hs[64 * (16 + j)];
+    }
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        a0 = ws_mfma(h0[j], ws[48 * j], a0);
+        a1 = ws_mfma(h1[j], ws[48 * (16 + j)], a1);
+    }
+    ws_put(L.pB[0], lane, a0);
+    ws_put(L.pB[1], lane, a1);
 }
-// I = W1i x: foreground wave fw < 3 = gate tile (one segment of 20 inputs)
-__device__ __forceinline__ void ws_I(WsLds& L, const WsRegs& R, int fw, int lane) {
+// I = W1i x (one segment of 20 inputs): gate tile `g` = foreground wave (no background matrix work runs at the start of a frame)
+__device__ __forceinline__ void ws_I(WsLds& L, const WsRegs& R, int g, int lane) {
+    const float bias = R.bI;
     const int c = lane & 15, q = lane >> 4, cc = c < WU1 ? c : WU1 - 1;
-    f32x4ws acc = {R.bI, R.bI, R.bI, R.bI};
+    f32x4ws acc = {bias, bias, bias, bias};
     const float* xs = L.x + lane;
-    const float* ws = L.w1i + q * 36 + fw * WU1 + cc;
+    const float* ws = L.w1i + (g * WIN + q) * WU1 + cc;
 #pragma unroll
-    for (int j = 0; j < WIN / 4; ++j) acc = ws_mfma(xs[64 * j], ws[144 * j], acc);
-    ws_put(L.pI[fw], lane, acc);
+    for (int j = 0; j < WIN / 4; ++j) acc = ws_mfma(xs[64 * j], ws[4 * WU1 * j], acc);
+    ws_put(L.pI[g], lane, acc);
 }
-// C = W2i h1: foreground wave fw = input segment of 96
+// C = W2i h1: foreground wave fw = input segment of 96 (one chain of 24 dependent MFMAs: operands read ahead)
 __device__ __forceinline__ void ws_C(WsLds& L, const WsRegs& R, int fw, int lane) {
     const int c = lane & 15, q = lane >> 4, cc = c < 12 ? c : 11;
     f32x4ws acc = {R.bC, R.bC, R.bC, R.bC};
     const float* hs = L.h1 + 96 * fw * WG + lane;
     const float* ws = L.w2i + (96 * fw + q) * 12 + cc;
+    float a[24], w[24];
 #pragma unroll
-    for (int j = 0; j < 24; ++j) acc = ws_mfma(hs[64 * j], ws[48 * j], acc);
+    for (int j = 0; j < 24; ++j) {
+        a[j] = hs[64 * j];
+        w[j] = ws[48 * j];
+    }
+#pragma unroll
+    for (int j = 0; j < 24; ++j) acc = ws_mfma(a[j], w[j], acc);
     ws_put(L.pC[fw], lane, acc);
 }
-// output layer on relu(h2): foreground wave fw = input segments 2 fw, 2 fw + 1 (16 inputs each), two row tiles
-__device__ __forceinline__ void ws_F(WsLds& L, const WsRegs& R, int fw, int lane) {
-    const int c = lane & 15, q = lane >> 4, c1 = c < WFC - 16 ? 16 + c : 16;
+// output layer on relu(h2) for the owned utterance: rows 0-15 as one MFMA tile (foreground wave fw = input segments 2 fw,
+// 2 fw + 1 of 16 inputs; the other 15 utterances of the M tile come for free and are dropped), rows 16, 17 as fmaf chains
+// on 16 lanes of wave 0 (a second tile would double the MFMAs for two rows; an f32 MFMA accumulates exactly such a chain)
+__device__ __forceinline__ void ws_F(WsLds& L, const WsRegs& R, int fw, int lane, int own) {
+    const int c = lane & 15, q = lane >> 4;
+    float hv[2][4], wv[2][4];  // (all operands first: two chains of four dependent MFMAs, not eight LDS round trips)
 #pragma unroll
     for (int s2 = 0; s2 < 2; ++s2) {
         const int sg = 2 * fw + s2;
-        const float b0 = sg == 0 ? R.bF[0] : 0.0f, b1 = sg == 0 ? R.bF[1] : 0.0f;
-        f32x4ws a0 = {b0, b0, b0, b0}, a1 = {b1, b1, b1, b1};
-        const float* hs = L.h2 + 16 * sg * WG + lane;
-        const float* ws = L.fcw + (16 * sg + q) * WFC;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const float hv = hs[64 * j];
-            const float a = hv > 0.0f ? hv : 0.0f;  // (the rectified state, formed in the chain)
-            a0 = ws_mfma(a, ws[4 * WFC * j + c], a0);
-            a1 = ws_mfma(a, ws[4 * WFC * j + c1], a1);
+            const float h = L.h2[(16 * sg + 4 * j) * WG + lane];
+            hv[s2][j] = h > 0.0f ? h : 0.0f;  // (the rectified state, formed in the chain)
+            wv[s2][j] = L.fcw[(16 * sg + 4 * j + q) * WFC + c];
         }
-        ws_put(L.pF[sg][0], lane, a0);
-        ws_put(L.pF[sg][1], lane, a1);
+    }
+    float rh[16], rw[16];
+    const int row = 16 + (lane & 1), rsg = (lane >> 1) & 7;
+    if (fw == 0) {
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            rh[k] = L.h2[(16 * rsg + k) * WG + own];
+            rw[k] = L.fcw[(16 * rsg + k) * WFC + row];
+        }
+    }
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+        const int sg = 2 * fw + s2;
+        const float b0 = sg == 0 ? R.bF[0] : 0.0f;
+        f32x4ws a0 = {b0, b0, b0, b0};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) a0 = ws_mfma(hv[s2][j], wv[s2][j], a0);
+        if (q == (own >> 2)) {  // (C/D layout: this lane holds utterances 4 q .. 4 q + 3 of row c)
+            const int r = own & 3;
+            L.pF[sg][0][c] = r == 0 ? a0[0] : (r == 1 ? a0[1] : (r == 2 ? a0[2] : a0[3]));
+        }
+    }
+    if (fw == 0 && lane < 2 * 8) {
+        float a = rsg == 0 ? R.bF[1] : 0.0f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) a = fmaf(rh[k] > 0.0f ? rh[k] : 0.0f, rw[k], a);
+        L.pF[rsg][1][row - 16] = a;
     }
 }
 
-// hop 1 gather, this wave's share: wave wv of 8 takes the slices wv, wv + 8, wv + 16, wv + 24 (lane = granule)
-__device__ __forceinline__ bool ws_gather1(const WsCtx& X, WsLds& L, int wv, int lane, unsigned epoch, bool guard_A, int t) {
-    int gi[4];
+// hop 1 gather by six waves (foreground 1-3, background 1-3): p < 384, six granules each; the waves of SIMD 0 have other
+// work meanwhile (background wave 0 computes B(t), the foreground's wave 0 must not take issue slots from it)
+__device__ __forceinline__ bool ws_gather1(const WsCtx& X, WsLds& L, int p, unsigned epoch, bool guard_A, int t) {
+    constexpr int NG = (WNS * WQ1 + 383) / 384;
+    int gi[NG];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int s = wv + 8 * j;
-        gi[j] = s == X.slice ? -1 : WOFF_H1 + s * WQ1 + lane;
+    for (int j = 0; j < NG; ++j) {
+        const int i = p + 384 * j;
+        gi[j] = (i < WNS * WQ1 && i / WQ1 != X.slice) ? WOFF_H1 + i : -1;
     }
-    u32x4 v[4];
-    if (!ws_poll<4>(X, L, gi, epoch, v)) return false;
+    u32x4 v[NG];
+    if (!ws_poll<NG>(X, L, gi, epoch, v)) return false;
     // (a background wave may be here before its neighbours have finished A(t) on the old image)
-    if (guard_A && !df_wait(&L.sig[WSIG_A], WBG * (t + 1), &L.dead)) return false;
+    if (guard_A && !df_wait(&L.sig[WSIG_A], 3 * (t + 1), &L.dead)) return false;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int s = wv + 8 * j;
-        if (s != X.slice) {
-            float* d = L.h1 + s * WV1 + 3 * lane;
+    for (int j = 0; j < NG; ++j) {
+        if (gi[j] >= 0) {
+            float* d = L.h1 + 3 * (gi[j] - WOFF_H1);  // granule e of slice s holds values 3 e .. 3 e + 2 of that slice
             d[0] = __uint_as_float(v[j].y);
             d[1] = __uint_as_float(v[j].z);
             d[2] = __uint_as_float(v[j].w);
@@ -319,20 +434,21 @@ __device__ __forceinline__ bool ws_gather1(const WsCtx& X, WsLds& L, int wv, int
     }
     return true;
 }
-// hop 2 gather by the 256 foreground threads
-__device__ __forceinline__ bool ws_gather2(const WsCtx& X, WsLds& L, int ft, unsigned epoch) {
-    int gi[3], sl[3], e[3];
+// hop 2 gather by the two waves of SIMD 0 (foreground wave 0 and background wave 0): p < 128, six granules each
+__device__ __forceinline__ bool ws_gather2(const WsCtx& X, WsLds& L, int p, unsigned epoch) {
+    constexpr int NG = (WNS * WQ2 + 127) / 128;
+    int gi[NG], sl[NG], e[NG];
 #pragma unroll
-    for (int j = 0; j < 3; ++j) {
-        const int i = ft + WFGT * j;
+    for (int j = 0; j < NG; ++j) {
+        const int i = p + 128 * j;
         sl[j] = i / WQ2;
         e[j] = i - sl[j] * WQ2;
         gi[j] = (i < WNS * WQ2 && sl[j] != X.slice) ? WOFF_H2 + i : -1;
     }
-    u32x4 v[3];
-    if (!ws_poll<3>(X, L, gi, epoch, v)) return false;
+    u32x4 v[NG];
+    if (!ws_poll<NG>(X, L, gi, epoch, v)) return false;
 #pragma unroll
-    for (int j = 0; j < 3; ++j) {
+    for (int j = 0; j < NG; ++j) {
         if (gi[j] >= 0) {
             float* d = L.h2 + sl[j] * WV2 + 3 * e[j];
             d[0] = __uint_as_float(v[j].y);
@@ -343,13 +459,17 @@ __device__ __forceinline__ bool ws_gather2(const WsCtx& X, WsLds& L, int ft, uns
     return true;
 }
 
-// FOREGROUND, frame t: L.x = x(t) -> L.fo (all 16 utterances), states in L.h1 / L.h2; false: the launch is dead
-__device__ __forceinline__ bool ws_foreground(const WsCtx& X, WsLds& L, const WsRegs& R, int t, int ft, int& fg_epoch) {
-    const int fw = ft >> 6, lane = ft & 63;
+// FOREGROUND, frame t: L.x = x(t) -> L.fo[slice] on the owners (written by threads ft < 18: a reader in another wave needs a
+// barrier first), states in L.h1 / L.h2; false: the launch is dead
+__device__ __forceinline__ bool ws_foreground(const WsCtx& X, WsLds& L, const WsRegs& R, int t, int ft0, int& fg_epoch) {
+    const int ft = ft0 + ws_opaque_zero();
+    const int fw = ft0 >> 6, lane = ft & 63;
     const unsigned epoch = (unsigned)t + 1u;
     if (fw < 3) ws_I(L, R, fw, lane);
     ws_fg_sync(L, fg_epoch);
-    if (!df_wait(&L.sig[WSIG_A], WBG * (t + 1), &L.dead)) return false;  // A(t): prologue, then one round per frame
+    WSTAMP(0)
+    if (!df_wait(&L.sig[WSIG_A], 3 * (t + 1), &L.dead)) return false;  // A(t): prologue, then one round per frame
+    WSTAMP(1)
     // ---- GRU1 gates of this workgroup's 12 units x 16 utterances: 48 values per wave; torch.nn.GRU rows [r; z; n]
     {
         const int base = X.slice * WV1 + 48 * fw;
@@ -371,12 +491,20 @@ __device__ __forceinline__ bool ws_foreground(const WsCtx& X, WsLds& L, const Ws
         }
     }
     df_signal(&L.sig[WSIG_P1]);  // (the background starts polling now, not before)
-    if (!ws_gather1(X, L, fw, lane, epoch, false, t)) return false;
-    df_signal(&L.sig[WSIG_H1]);
-    if (!df_wait(&L.sig[WSIG_H1], NW * (t + 1), &L.dead)) return false;  // h1(t) whole in LDS
+    WSTAMP(2)
+    if (fw != 0) {
+        if (!ws_gather1(X, L, ft - 64, epoch, false, t)) return false;
+        df_signal(&L.sig[WSIG_H1]);
+    }
+    WSTAMP(3)
+    if (!df_wait(&L.sig[WSIG_H1], 6 * (t + 1), &L.dead)) return false;  // h1(t) whole in LDS
+    WSTAMP(4)
     ws_C(L, R, fw, lane);
+    df_signal(&L.sig[WSIG_C]);  // (A(t+1) starts behind C(t): side by side on one matrix pipe the chain's product took 3.4k cycles)
     ws_fg_sync(L, fg_epoch);
-    if (!df_wait(&L.sig[WSIG_B], 2 * (t + 1), &L.dead)) return false;  // B(t)
+    WSTAMP(5)
+    if (!df_wait(&L.sig[WSIG_B], t + 1, &L.dead)) return false;  // B(t)
+    WSTAMP(6)
     if (fw == 0) {  // GRU2 gates: 4 units x 16 utterances
         const int base = X.slice * WV2;
         const int v = lane;
@@ -395,37 +523,56 @@ __device__ __forceinline__ bool ws_foreground(const WsCtx& X, WsLds& L, const Ws
             const int i0 = 3 * lane, i1 = i0 + 1 < WV2 ? i0 + 1 : WV2 - 1, i2 = i0 + 2 < WV2 ? i0 + 2 : WV2 - 1;
             ws_store(X, WOFF_H2 + X.slice * WQ2 + lane, epoch, L.h2[base + i0], L.h2[base + i1], L.h2[base + i2]);
         }
+        df_signal(&L.sig[WSIG_P2]);
     }
-    if (!ws_gather2(X, L, ft, epoch)) return false;
-    df_signal(&L.sig[WSIG_H2]);
-    if (!df_wait(&L.sig[WSIG_H2], WFG * (t + 1), &L.dead)) return false;  // h2(t) whole in LDS
-    ws_F(L, R, fw, lane);
-    ws_fg_sync(L, fg_epoch);
-    for (int i = ft; i < WFC * WG; i += WFGT) {
-        const int row = i >> 4, u = i & 15, tile = row >> 4, o = ((row & 15) << 4) + u;
-        const float acc = ((L.pF[0][tile][o] + L.pF[1][tile][o]) + (L.pF[2][tile][o] + L.pF[3][tile][o])) +
-                          ((L.pF[4][tile][o] + L.pF[5][tile][o]) + (L.pF[6][tile][o] + L.pF[7][tile][o]));
-        const float tt = fpc_tanhf(acc);
-        L.fo[u][row] = tt + tt;  // the "dual" FC is the same Linear summed twice (wavernn.py:89-92)
+    WSTAMP(7)
+    if (fw == 0) {
+        if (!ws_gather2(X, L, lane, epoch)) return false;
+        df_signal(&L.sig[WSIG_H2]);
     }
-    ws_fg_sync(L, fg_epoch);
+    WSTAMP(8)
+    if (!df_wait(&L.sig[WSIG_H2], 2 * (t + 1), &L.dead)) return false;  // h2(t) whole in LDS
+    WSTAMP(9)
+    // the output layer: only the workgroup that owns an utterance needs its prediction (the other rows of the tile come for free)
+    if (X.slice < X.nu) {
+        ws_F(L, R, fw, lane, X.slice);
+        ws_fg_sync(L, fg_epoch);
+        WSTAMP(10)
+        if (ft < WFC) {
+            const int row = ft, tile = row >> 4, o = row & 15;
+            const float acc = ((L.pF[0][tile][o] + L.pF[1][tile][o]) + (L.pF[2][tile][o] + L.pF[3][tile][o])) +
+                              ((L.pF[4][tile][o] + L.pF[5][tile][o]) + (L.pF[6][tile][o] + L.pF[7][tile][o]));
+            const float tt = fpc_tanhf(acc);
+            L.fo[X.slice][row] = tt + tt;  // the "dual" FC is the same Linear summed twice (wavernn.py:89-92)
+        }
+    }
+    WSTAMP(11)
     return !ws_dead(L);
 }
 
-// BACKGROUND, frame t: half of hop 1's gather, then A(t+1) and B(t+1)
+// BACKGROUND, frame t: wave 0: B(t) and half of hop 2's gather; waves 1-3: half of hop 1's gather, then A(t+1)
 __device__ __forceinline__ bool ws_background(const WsCtx& X, WsLds& L, const WsRegs& R, int t, bool last, int bt) {
-    const int bw = bt >> 6, lane = bt & 63;
+    const int bw = bt >> 6, lane = (bt + ws_opaque_zero()) & 63;
     if (!df_wait(&L.sig[WSIG_P1], WFG * (t + 1), &L.dead)) return false;
-    if (!ws_gather1(X, L, WFG + bw, lane, (unsigned)t + 1u, true, t)) return false;
+    WBSTAMP(13)
+    if (bw == 0) {  // the two waves of SIMD 0 run no matrix product beside the chain: B(t) under hop 1, then hop 2's gather
+        ws_B(L, R, lane);
+        df_signal(&L.sig[WSIG_B]);
+        if (!df_wait(&L.sig[WSIG_P2], t + 1, &L.dead)) return false;
+        if (!ws_gather2(X, L, 64 + lane, (unsigned)t + 1u)) return false;
+        df_signal(&L.sig[WSIG_H2]);
+        return true;
+    }
+    if (!ws_gather1(X, L, 192 + 64 * (bw - 1) + lane, (unsigned)t + 1u, true, t)) return false;
     df_signal(&L.sig[WSIG_H1]);
-    if (!df_wait(&L.sig[WSIG_H1], NW * (t + 1), &L.dead)) return false;
+    WBSTAMP(14)
+    if (!df_wait(&L.sig[WSIG_H1], 6 * (t + 1), &L.dead)) return false;
+    WBSTAMP(15)
+    if (!df_wait(&L.sig[WSIG_C], WFG * (t + 1), &L.dead)) return false;  // (behind C(t): the chain's product comes first)
+    WBSTAMP(17)
     if (!last) ws_A(L, R, bw, lane);
     df_signal(&L.sig[WSIG_A]);
-    if (bw < 2) {
-        if (!df_wait(&L.sig[WSIG_H2], WFG * (t + 1), &L.dead)) return false;
-        if (!last) ws_B(L, R, bw, lane);
-        df_signal(&L.sig[WSIG_B]);
-    }
+    WBSTAMP(16)
     return true;
 }
 
@@ -439,11 +586,9 @@ __device__ __forceinline__ void ws_prologue(const PredDev& P, WsCtx& X, WsLds& L
     ws_hello(X, L, S, tid);
     if (tid >= WFGT) {
         const int bw = (tid - WFGT) >> 6, lane = tid & 63;
-        ws_A(L, R, bw, lane);
-        df_signal(&L.sig[WSIG_A]);
-        if (bw < 2) {
-            ws_B(L, R, bw, lane);
-            df_signal(&L.sig[WSIG_B]);
+        if (bw >= 1) {
+            ws_A(L, R, bw, lane);
+            df_signal(&L.sig[WSIG_A]);
         }
     }
     __syncthreads();
@@ -485,6 +630,7 @@ __global__ __launch_bounds__(NT) void k_forward_ws(const PredDev P, const float*
     __syncthreads();
     ws_prologue(P, X, L, R, S, tid);
     const bool owner = slice < X.nu;  // this workgroup stores the outputs of utterance `slice` of the group
+    WPROF_INIT()
     if (tid < WFGT) {
         __builtin_amdgcn_s_setprio(FPC_FG_PRIO);
         int fg_epoch = 0;
@@ -507,12 +653,14 @@ __global__ __launch_bounds__(NT) void k_forward_ws(const PredDev P, const float*
                 }
                 ws_fg_sync(L, fg_epoch);
             }
+            WSTAMP(12)
         }
         __builtin_amdgcn_s_setprio(0);
     } else {
         for (int tb = 0; tb < Lf; ++tb)
             if (!ws_background(X, L, R, tb, tb + 1 == Lf, tid - WFGT)) break;
     }
+    WPROF_DUMP(Lf)
     __syncthreads();
     // new states of this workgroup's units; a launch that gave up fails loudly: NaN outputs and states, FPC_ERR_TIMEOUT
     const bool dead = ws_dead(L);
@@ -548,6 +696,348 @@ __device__ __forceinline__ void ws_publish_x(const WsCtx& X, WsLds& L, int lane,
     if (lane < WIN) L.x[lane * WG + X.slice] = L.xn[lane];
 }
 
+
+// ---- the encoder's frame tail on the workgroup that owns the utterance (wavernn.py:196-252) ------------------------------
+// encode_frame (predictor.hip) restated for a tail that EVERY frame of the group now waits for (the slowest of 16
+// utterances sets the pace, and one of them is almost always above the threshold): same results bit for bit -- every
+// distance is the float64 sum in numpy's pairwise order (vq_func.py:18), every choice the smallest (distance, index) -- in
+// fewer steps on the critical path:
+//   * an entry's coordinates arrive as nine 16-byte loads (pair layout [9][N][2]) instead of seventeen 8-byte ones, issued
+//     before anything else; the scalar search (one wave, codes in LDS) runs in their shadow;
+//   * first stage of a 2-stage search: instead of five rounds of wave-wide arg-min networks per wave and five more to merge
+//     them, a BOUND -- the fifth smallest of the eight per-wave minima, at or below which at least five entries lie -- picks
+//     the few candidates (about seven), which one wave ranks by counting; the second stage's entries are loaded meanwhile;
+//   * the winners' coordinates are written by the threads that hold them (no L2 round trip for the quantized vector).
+// Anything outside the fast path's limits (more than 1 024 entries per stage, more than 256 scalar codes or codes not in
+// LDS, more than 64 candidates at the bound: a degenerate codebook) runs encode_frame itself.
+__device__ __forceinline__ void ws_load_entry(const double* __restrict__ cbP, int N, int e, bool has, double (&c)[NDIM + 1]) {
+#pragma unroll
+    for (int j = 0; j < (NDIM + 1) / 2; ++j) {
+        double2 v = make_double2(0.0, 0.0);
+        if (has) v = reinterpret_cast<const double2*>(cbP)[(size_t)j * N + e];
+        c[2 * j] = v.x;
+        c[2 * j + 1] = v.y;
+    }
+}
+__device__ __forceinline__ double ws_dist(const double* x, const double (&c)[NDIM + 1]) {
+    double r[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const double d = x[j] - c[j];
+        r[j] = d * d;
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const double d = x[8 + j] - c[8 + j];
+        const double dd = d * d;
+        r[j] = r[j] + dd;
+    }
+    double res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+    const double d = x[16] - c[16];
+    const double dd = d * d;
+    res = res + dd;
+    return res;
+}
+__device__ __forceinline__ double wave_min_f64(double d) {  // every lane gets the wave's smallest value
+    double m = d;
+    m = min_f64(m, dpp_mov_f64<0xB1, 0xf, false>(m));
+    m = min_f64(m, dpp_mov_f64<0x4E, 0xf, false>(m));
+    m = min_f64(m, dpp_mov_f64<0x141, 0xf, false>(m));
+    m = min_f64(m, dpp_mov_f64<0x140, 0xf, false>(m));
+    m = min_f64(m, dpp_mov_f64<0x142, 0xa, false>(m));
+    m = min_f64(m, dpp_mov_f64<0x143, 0xc, false>(m));
+    const unsigned long long b = (unsigned long long)__double_as_longlong(m);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)b, 63);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(b >> 32), 63);
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+// scl_quantize (vq_func.py:167-185) by one wave, n <= 256 codes in LDS (scl_search_lds without its barriers)
+__device__ __forceinline__ void ws_scl_wave(WsLds& L, float xv, int off, int n, int lane) {
+    double bd = INFINITY;
+    int bi = 0x7fffffff;
+    const double v = (double)xv;
+    for (int c = lane; c < n; c += 64) {
+        const double df = v - L.sclc[off + c];
+        const double d = df * df;
+        if (d < bd) {
+            bd = d;
+            bi = c;
+        }
+    }
+    wave_argmin(bd, bi);
+    if (lane == 0) {
+        L.res_i[2] = bi;
+        L.qs = L.sclc[off + bi];
+    }
+}
+__device__ __forceinline__ void ws_encode_tail(WsLds& L, const float* fo, float* xn, const PredDev& P, const CbDev& C,
+                                               const EncArgs& A, unsigned* err, size_t fi, float fv, int tid0, bool scl_in_lds,
+                                               int rot) {
+    const int wave = tid0 >> 6, tid = tid0 + ws_opaque_zero(), lane = tid & 63;
+    const int Cc = WIN, F = WFC;
+    const int off_sl = C.n_hi, off_v0 = off_sl + C.n_lo, off_v1 = off_v0 + C.N_hi0,
+              off_vl = off_v1 + (C.S_hi == 2 ? C.N_hi1 : 0);
+    if (tid < F) L.rs[tid] = fv - fo[tid];  // :196
+    if (tid == 0) L.ncand = 0;
+    lds_barrier();
+    float sabs = 0.0f;
+    for (int d = 1; d < F; ++d) sabs += fabsf(L.rs[d]);
+    const int i1 = fabsf(L.rs[0]) > A.l1;  // :202
+    const int i2 = sabs > A.l2;            // :206
+    const bool nonfinite = !(fabsf(L.rs[0]) <= 3.0e38f) || !(sabs <= 3.0e38f);
+    const bool do_scl = A.qtz && !nonfinite && (i1 || C.scl_lo);
+    const bool do_vq = A.qtz && !nonfinite && (i2 || C.vq_lo);
+    const int S = i2 ? C.S_hi : 1, N0 = i2 ? C.N_hi0 : C.N_lo, N1 = (i2 && C.S_hi == 2) ? C.N_hi1 : 0;
+    // (the host launches this kernel only within the tail's limits -- ws_codebooks_fit in predictor.hip: at most 2 NT entries
+    //  per stage, at most 256 codes per scalar codebook, all of them in LDS)
+    if (nonfinite && A.qtz && tid == 0) status_or(err, FPC_ST_NONFINITE);
+    // a thread owns entries e0 and e0 + NT; which ones rotates with the workgroup, so that the 16 owners of an XCD, which
+    // sweep the same codebook at the same time, ask different L2 channels at any moment (any assignment gives the same
+    // result: the choices below are minima over (distance, index))
+    const int e0 = (tid + 64 * (rot & (NW - 1))) & (NT - 1), e1 = e0 + NT;
+    if (do_vq) {
+        const double* p0 = i2 ? C.vq_hi0_p : C.vq_lo_p;
+        const double* cb0R = i2 ? C.vq_hi0_r : C.vq_lo_r;
+        double c0[NDIM + 1], c1[NDIM + 1];
+        const bool h0 = e0 < N0, h1 = e1 < N0;
+        ws_load_entry(p0, N0, e0, h0, c0);
+        ws_load_entry(p0, N0, e1, h1, c1);
+        if (tid < NDIM) L.xq[0][tid] = (double)L.rs[1 + tid];
+        if (do_scl && wave == NW - 1) ws_scl_wave(L, L.rs[0], i1 ? 0 : C.n_hi, i1 ? C.n_hi : C.n_lo, lane);
+        lds_barrier();
+        WSTAMP(25)
+        const double d0 = h0 ? ws_dist(L.xq[0], c0) : INFINITY, d1 = h1 ? ws_dist(L.xq[0], c1) : INFINITY;
+        double db = d0;
+        int eb = h0 ? e0 : 0x7fffffff;
+        if (d1 < db) {  // ascending entries: strict < keeps the lower index
+            db = d1;
+            eb = e1;
+        }
+        if (S == 1) {  // the nearest entry is all a 1-stage search returns (vq_func.py:93-95)
+            wave_argmin(db, eb);
+            if (lane == 0) {
+                L.wd[0][wave][0] = db;
+                L.wi[0][wave][0] = eb;
+            }
+            lds_barrier();
+            double gd = L.wd[0][0][0];
+            int gi = L.wi[0][0][0];
+#pragma unroll
+            for (int w = 1; w < NW; ++w) take_min(gd, gi, L.wd[0][w][0], L.wi[0][w][0]);
+            if (gi == e0 || gi == e1) {  // the winner's thread holds its coordinates
+#pragma unroll
+                for (int d = 0; d < NDIM; ++d) L.qv[d] = gi == e0 ? c0[d] : c1[d];
+                L.res_i[0] = gi;
+                L.res_i[1] = -1;
+            }
+        } else {
+            // ---- first stage: the five smallest by (distance, index) (vq_quantize_mbest, vq_func.py:10-24) ----
+            const double wm = wave_min_f64(db);
+            if (lane == 0) L.wmin[wave] = wm;
+            // the second stage's entries replace the first stage's in the registers while the survivors are sorted out
+            const bool g0 = e0 < N1, g1 = e1 < N1;
+            ws_load_entry(C.vq_hi1_p, N1, e0, g0, c0);
+            ws_load_entry(C.vq_hi1_p, N1, e1, g1, c1);
+            lds_barrier();
+            WSTAMP(26)
+            double T;  // the fifth smallest per-wave minimum: at least five entries are at or below it, so the five
+            {          // smallest entries are, and everything at or below it is ranked
+                const int j = lane & (NW - 1);
+                const double m = L.wmin[j];
+                int cnt = 0;
+#pragma unroll
+                for (int k = 0; k < NW; ++k) {
+                    const double mk = L.wmin[k];
+                    cnt += (mk < m) | ((mk == m) & (k < j));
+                }
+                const unsigned long long pick = __ballot(cnt == SURV - 1 && lane < NW);
+                const int src = __builtin_ctzll(pick);
+                const unsigned long long b = (unsigned long long)__double_as_longlong(m);
+                const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)b, src);
+                const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(b >> 32), src);
+                T = __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+            }
+            if (h0 && d0 <= T) {
+                const int pos = __hip_atomic_fetch_add(&L.ncand, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (pos < 64) {
+                    L.cand_d[pos] = d0;
+                    L.cand_i[pos] = e0;
+                }
+            }
+            if (h1 && d1 <= T) {
+                const int pos = __hip_atomic_fetch_add(&L.ncand, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (pos < 64) {
+                    L.cand_d[pos] = d1;
+                    L.cand_i[pos] = e1;
+                }
+            }
+            lds_barrier();
+            WSTAMP(27)
+            const int n = L.ncand;
+            if (n <= 64) {  // (workgroup-uniform) rank by counting: the candidates are few
+                if (wave == 0 && lane < n) {
+                    const double dj = L.cand_d[lane];
+                    const int ij = L.cand_i[lane];
+                    int rank = 0;
+                    for (int k = 0; k < n; ++k) {
+                        const double dk = L.cand_d[k];
+                        const int ik = L.cand_i[k];
+                        rank += (dk < dj) | ((dk == dj) & (ik < ij));
+                    }
+                    if (rank < SURV) L.sv[rank] = ij;
+                }
+                lds_barrier();
+            } else {  // many entries at the bound (a degenerate codebook): five rounds of arg-min, each winner struck out
+                bool x0 = !h0, x1 = !h1;
+#pragma unroll 1
+                for (int r = 0; r < SURV; ++r) {
+                    double d = INFINITY;
+                    int e = 0x7fffffff;
+                    if (!x0) {
+                        d = d0;
+                        e = e0;
+                    }
+                    if (!x1 && (x0 || d1 < d)) {
+                        d = d1;
+                        e = e1;
+                    }
+                    wave_argmin(d, e);
+                    if (lane == 0) {
+                        L.wd[0][wave][0] = d;
+                        L.wi[0][wave][0] = e;
+                    }
+                    lds_barrier();
+                    double gd = L.wd[0][0][0];
+                    int gi = L.wi[0][0][0];
+#pragma unroll
+                    for (int w = 1; w < NW; ++w) take_min(gd, gi, L.wd[0][w][0], L.wi[0][w][0]);
+                    if (gi == e0) x0 = true;
+                    if (gi == e1) x1 = true;
+                    if (tid == 0) L.sv[r] = gi;
+                    lds_barrier();
+                }
+            }
+            WSTAMP(28)
+            // ---- second stage: residual of every survivor (vq_func.py:103-108); total errors compared ----
+            if (tid < SURV * NDIM) {
+                const int k = tid / NDIM, d = tid - k * NDIM;
+                const double en = cb0R[(size_t)L.sv[k] * NDIM + d];
+                L.ent[k][d] = en;
+                L.xq[k][d] = (double)L.rs[1 + d] - en;
+            }
+            lds_barrier();
+            WSTAMP(29)
+#pragma unroll 1
+            for (int k = 0; k < SURV; ++k) {
+                const double q0 = g0 ? ws_dist(L.xq[k], c0) : INFINITY, q1 = g1 ? ws_dist(L.xq[k], c1) : INFINITY;
+                double qb = q0;
+                int qe = g0 ? e0 : 0x7fffffff;
+                if (q1 < qb) {
+                    qb = q1;
+                    qe = e1;
+                }
+                wave_argmin(qb, qe);
+                if (lane == 0) {
+                    L.wd[k][wave][0] = qb;
+                    L.wi[k][wave][0] = qe;
+                }
+            }
+            lds_barrier();
+            WSTAMP(30)
+            if (tid < SURV) {
+                double d = L.wd[tid][0][0];
+                int ix = L.wi[tid][0][0];
+                for (int w = 1; w < NW; ++w) take_min(d, ix, L.wd[tid][w][0], L.wi[tid][w][0]);
+                L.od2[tid] = d;
+                L.oi2[tid] = ix;
+            }
+            lds_barrier();
+            // head of the merge-insert of candidate paths (vq_func.py:110-125): a later survivor replaces the running best
+            // only if its total error is strictly smaller
+            int bk = 0;
+            double g = L.od2[0];
+#pragma unroll
+            for (int k = 1; k < SURV; ++k) {
+                const double gk = L.od2[k];
+                if (gk < g) {
+                    g = gk;
+                    bk = k;
+                }
+            }
+            const int w1 = L.oi2[bk];
+            if (w1 == e0 || w1 == e1) {
+#pragma unroll
+                for (int d = 0; d < NDIM; ++d) L.qv[d] = L.ent[bk][d] + (w1 == e0 ? c0[d] : c1[d]);  // :127-129
+                L.res_i[0] = L.sv[bk];
+                L.res_i[1] = w1;
+            }
+        }
+        lds_barrier();
+    } else if (do_scl) {
+        if (wave == 0) ws_scl_wave(L, L.rs[0], i1 ? 0 : C.n_hi, i1 ? C.n_hi : C.n_lo, lane);
+        lds_barrier();
+    }
+    WSTAMP(31)
+    // ---- the frame's outputs and the next input row (encode_frame's last part) ----
+    float rq = 0.0f;
+    int ix0 = -1, ix1 = -1, ix2 = -1, ix3 = -1;
+    if (nonfinite) ix0 = ix1 = ix2 = ix3 = -2;
+    if (do_scl && tid == 0) {
+        rq = (float)L.qs;
+        ix0 = L.res_i[2] + (i1 ? 0 : C.n_hi);
+        if (A.hist) atomicAdd(&A.hist[(i1 ? 0 : off_sl) + L.res_i[2]], 1ull);
+    }
+    if (do_vq) {
+        if (tid >= 1 && tid < F) rq = (float)L.qv[tid - 1];
+        if (tid == 0) {
+            if (i2) {
+                ix1 = L.res_i[0];
+                ix2 = L.res_i[1];
+                if (A.hist) {
+                    atomicAdd(&A.hist[off_v0 + ix1], 1ull);
+                    if (C.S_hi == 2) atomicAdd(&A.hist[off_v1 + ix2], 1ull);
+                }
+            } else {
+                ix3 = L.res_i[0];
+                if (A.hist) atomicAdd(&A.hist[off_vl + ix3], 1ull);
+            }
+        }
+    }
+    if (tid < F) {
+        const float rs = L.rs[tid];
+        const int ind = tid == 0 ? i1 : i2;
+        float rv, ru, cn;
+        if (A.qtz) {
+            rv = rs;  // un-thresholded residual (:197)
+            ru = 0.0f;
+            cn = fo[tid] + rq;  // :242
+        } else {                  // :244-252
+            ru = rs * (float)(1 - ind);
+            rv = rs * (float)ind;
+            cn = fo[tid] + rv;
+        }
+        A.r[fi * F + tid] = rv;
+        A.r_qtz[fi * F + tid] = rq;
+        A.r_under[fi * F + tid] = ru;
+        A.c_in[fi * Cc + tid] = cn;
+        xn[tid] = cn;
+    } else if (tid < Cc) {  // pitch columns pass through (:178)
+        A.c_in[fi * Cc + tid] = fv;
+        xn[tid] = fv;
+    }
+    if (tid == 0) {
+        A.ind1[fi] = (float)i1;
+        A.ind2[fi] = (float)i2;
+        if (A.idx) {
+            A.idx[fi * 4 + 0] = ix0;
+            A.idx[fi * 4 + 1] = ix1;
+            A.idx[fi * 4 + 2] = ix2;
+            A.idx[fi * 4 + 3] = ix3;
+        }
+    }
+    lds_barrier();  // (the next input row is in LDS; the frame's global stores need not have landed)
+}
+
 __global__ __launch_bounds__(NT) void k_encode_ws(const PredDev P, const CbDev C, const EncArgs A, const WsArgs S) {
     __shared__ WsLds L;
     const int tid = threadIdx.x;
@@ -569,6 +1059,7 @@ __global__ __launch_bounds__(NT) void k_encode_ws(const PredDev P, const CbDev C
     const int b = X.b0 + slice;  // the owned utterance
     int fg_epoch = 0;
     int i = 0;
+    WPROF_INIT()
     for (; i < A.Lf; ++i) {
         const unsigned epoch = (unsigned)i + 1u;
         // this frame's feature row of the owned utterance (one column per thread), and the pitch columns of every
@@ -586,11 +1077,14 @@ __global__ __launch_bounds__(NT) void k_encode_ws(const PredDev P, const CbDev C
         } else {
             (void)ws_background(X, L, R, i, i + 1 == A.Lf, tid - WFGT);
         }
+        WBSTAMP(19)
         if (__syncthreads_or(ws_dead(L))) break;  // both roles meet: the searches take the whole workgroup
+        WSTAMP(20)
         if (owner) {
-            encode_frame(L, L.fo[slice], L.xn, P, C, A, S.err, (size_t)b * A.Lf + i, fv, true, tid, scl_in_lds);
+            ws_encode_tail(L, L.fo[slice], L.xn, P, C, A, S.err, (size_t)b * A.Lf + i, fv, tid, scl_in_lds, slice);
             if (tid < 64) ws_publish_x(X, L, tid, epoch);
         }
+        WSTAMP(21)
         if (tid < (WIN - WFC) * WG) {
             const int u = tid / (WIN - WFC), k = WFC + tid % (WIN - WFC);
             if (!(owner && u == slice)) L.x[k * WG + u] = pv;
@@ -598,7 +1092,10 @@ __global__ __launch_bounds__(NT) void k_encode_ws(const PredDev P, const CbDev C
         bool ok = true;
         if (tid < 128) ok = ws_gather3(X, L, tid, epoch);
         if (__syncthreads_or(!ok)) break;
+        WSTAMP(22)
+        WBSTAMP(23)
     }
+    WPROF_DUMP(A.Lf)
     if (i < A.Lf && owner) encode_poison(P, A, b, i, tid);
 }
 

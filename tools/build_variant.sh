@@ -1,14 +1,17 @@
 #!/bin/bash
-# build_variants/lib_<name>.so with extra -D flags for lpcnet.hip (kernel experiments; never shipped)
-#   tools/build_variant.sh name "-DFPC_DRAW_WAVE=3 ..."
+# build_variants/lib_<name>.so = the library with extra compiler flags (diagnostic / tuning builds; FPC_LIB_PATH selects one)
+#   bash tools/build_variant.sh ws_prof -DFPC_WS_PROF
 set -e
-cd "$(dirname "$0")/../feature-predictor-for-speech-codec_amd/csrc"
-make -s
 name=$1; shift
-out=../../build_variants
+root=$(cd "$(dirname "$0")/.." && pwd)
+src=$root/feature-predictor-for-speech-codec_amd/csrc
+out=$root/build_variants/obj_$name
 mkdir -p $out
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fvisibility=hidden \
-    -I../../include -Wno-unused-function $* -c lpcnet.hip -o $out/lpcnet_$name.o
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $out/lib_$name.so api.o predictor.o ceps2lpc.o cb_train.o $out/lpcnet_$name.o
-rm -f $out/lpcnet_$name.o
-echo built $out/lib_$name.so
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fvisibility=hidden -I$root/include -I$src -Wall -Wno-unused-function"
+for f in api lpcnet predictor ceps2lpc cb_train; do
+  if [ "$f" = predictor ] || [ ! -f $out/$f.o ]; then
+    /opt/rocm/bin/hipcc $FLAGS "$@" -c $src/$f.hip -o $out/$f.o 2>&1 | grep -v 'argument unused' || true
+  fi
+done
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $root/build_variants/lib_$name.so $out/*.o
+echo built build_variants/lib_$name.so
