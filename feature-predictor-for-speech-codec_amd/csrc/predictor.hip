@@ -1624,6 +1624,7 @@ struct fpc_predictor {
     fpc::DevBuf flag;  // one int: "a symbol lay outside its codebook" (fpc_decode_features), allocated once per handle
     fpc::DevBuf xg;    // row-split exchange granules [B][2][h1 + h2] x 8 bytes, grown on demand
     fpc::DevBuf wsg;   // weights-stationary form (predictor_ws.h): granule blocks [groups][WGRANULES] x 16 bytes
+    fpc::DevBuf wsidx; // ... and the symbols of an encode call whose caller passes no idx buffer (the histograms are counted from them)
     // status word: host-mapped pinned memory the kernels OR failure bits into (FPC_ST_*); sticky until
     // fpc_predictor_status() clears it; read by the host without a synchronisation at the start of every call
     unsigned* status_host = nullptr;
@@ -2002,8 +2003,26 @@ extern "C" int fpc_encode(fpc_predictor* p, const fpc_codebooks* cb, const float
         WsArgs wa;
         const int rcw = ws_args(p, B, static_cast<hipStream_t>(s), &wa);
         if (rcw != FPC_OK) return rcw;
+        if (!a.idx) {  // (the kernel always writes the symbols; the caller may not want them)
+            const size_t need = (size_t)B * L * 4 * sizeof(int);
+            if (p->wsidx.bytes < need) {
+                if (p->wsidx.p) {
+                    FPC_HIP(hipDeviceSynchronize());
+                    (void)hipFree(p->wsidx.p);
+                    p->wsidx.p = nullptr;
+                }
+                FPC_HIP(p->wsidx.alloc(need));
+            }
+            a.idx = p->wsidx.as<int>();
+        }
         hipLaunchKernelGGL(k_encode_ws, dim3(ws_grid(wa)), dim3(NT), 0, static_cast<hipStream_t>(s), p->d, cd, a, wa);
         FPC_HIP(hipGetLastError());
+        if (hist_dev && qtz) {
+            const size_t frames = (size_t)B * L;
+            hipLaunchKernelGGL(k_hist_symbols, dim3((unsigned)((frames + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(s), cd,
+                               a.idx, frames, hist_dev);
+            FPC_HIP(hipGetLastError());
+        }
 #ifdef FPC_WS_PROF
         ws_prof_print(p, qtz ? "k_encode_ws qtz=1" : "k_encode_ws qtz=0", B, static_cast<hipStream_t>(s));
 #endif

@@ -45,8 +45,9 @@ constexpr int WQX = WFC / 3;                     // granules of an utterance's n
 constexpr int WFG = 4, WBG = 4;                  // waves per role
 constexpr int WFGT = WFG * 64;
 // granule block of a group, in 16-byte units: hello | h1 | h2 | next input
+// | the pairs' search results [utterance][half][stage][5]: {tag, distance (2 dwords), index}
 constexpr int WOFF_HELLO = 0, WOFF_H1 = WNS, WOFF_H2 = WOFF_H1 + WNS * WQ1, WOFF_X = WOFF_H2 + WNS * WQ2,
-              WGRANULES = WOFF_X + WG * WQX;  // 2 880 granules = 46 080 bytes
+              WOFF_PAIR = WOFF_X + WG * WQX, WGRANULES = WOFF_PAIR + WG * 2 * 2 * SURV;  // 3 200 granules = 51 200 bytes
 static_assert(NT == 512, "predictor_ws.h is written for 8 waves per workgroup");
 static_assert(WH1 / 4 == 96 && WH2 / 2 == 64 && WFC == NDIM + 1, "production shape");
 enum { WSIG_A = 0, WSIG_B, WSIG_H1, WSIG_H2, WSIG_P1, WSIG_P2, WSIG_C, WSIG_FG, WNSIG };
@@ -78,6 +79,7 @@ struct __attribute__((aligned(16))) WsLds : SearchLds {
     float fcw[WH2 * WFC];      // [k][row]
     int sig[WNSIG];
     int dead;
+    int dead_latch;  // the value every thread acts on at the end of a frame (read once, between two barriers)
     int same_xcd;
     // scratch of the frame tail's searches (ws_encode_tail)
     double cand_d[64];           // first-stage entries at or below the bound, in arrival order
@@ -88,6 +90,8 @@ struct __attribute__((aligned(16))) WsLds : SearchLds {
     int sv[SURV];                // the survivors
     double od2[SURV];            // best second-stage entry per survivor
     int oi2[SURV];
+    double loc_d[2][SURV];       // first-stage lists of the two halves of a pair (this workgroup's, the partner's)
+    int loc_i[2][SURV];
 #ifdef FPC_WS_PROF
     long long wprof[32], wlast, wlast_bg;  // diagnostic builds: cycles per stage, foreground [0..13) + [19..24), background [13..19)
 #endif
@@ -99,12 +103,16 @@ struct __attribute__((aligned(16))) WsLds : SearchLds {
         L.wprof[k] += now_ - L.wlast;                        \
         L.wlast = now_;                                      \
     }
+#ifdef FPC_WS_PROF_TAIL
+#define WBSTAMP(k)
+#else
 #define WBSTAMP(k)                                           \
     if (threadIdx.x == WFGT + 64) {                          \
         const long long now_ = __builtin_readcyclecounter(); \
         L.wprof[k] += now_ - L.wlast_bg;                     \
         L.wlast_bg = now_;                                   \
     }
+#endif
 #define WPROF_INIT()                                              \
     if (threadIdx.x == 0) {                                       \
         for (int k_ = 0; k_ < 32; ++k_) L.wprof[k_] = 0;          \
@@ -125,11 +133,21 @@ struct __attribute__((aligned(16))) WsLds : SearchLds {
 struct WsCtx {
     __amdgpu_buffer_rsrc_t rs;  // this group's granule block
     int slice, nu, b0;          // this workgroup's slice, valid utterances of the group, first utterance
+    int own;                    // utterance of the group whose prediction this workgroup needs (-1: none)
     unsigned* err;
     unsigned long long limit;
     bool fast, withhold;
 };
 
+// The end of a frame in the closed-loop kernels: has any wait of this frame been given up?  Every poll that fails sets
+// L.dead first; the answer must be the same for every thread (they leave the frame loop together), so one thread latches
+// the flag between two barriers (__syncthreads_or costs three barriers and a cross-lane reduction: ~900 cycles per use).
+__device__ __forceinline__ bool ws_frame_dead(WsLds& L, int tid) {
+    lds_barrier();
+    if (tid == 0) L.dead_latch = __hip_atomic_load(&L.dead, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    lds_barrier();
+    return L.dead_latch != 0;
+}
 // a zero the compiler cannot see through: added to a lane index at the top of a frame's role function, it keeps the frame's
 // address arithmetic inside the frame loop (hoisted out of it, the per-lane offsets of every unrolled access stay live across
 // the encoder's searches and spill)
@@ -534,8 +552,8 @@ __device__ __forceinline__ bool ws_foreground(const WsCtx& X, WsLds& L, const Ws
     if (!df_wait(&L.sig[WSIG_H2], 2 * (t + 1), &L.dead)) return false;  // h2(t) whole in LDS
     WSTAMP(9)
     // the output layer: only the workgroup that owns an utterance needs its prediction (the other rows of the tile come for free)
-    if (X.slice < X.nu) {
-        ws_F(L, R, fw, lane, X.slice);
+    if (X.own >= 0) {
+        ws_F(L, R, fw, lane, X.own);
         ws_fg_sync(L, fg_epoch);
         WSTAMP(10)
         if (ft < WFC) {
@@ -543,7 +561,7 @@ __device__ __forceinline__ bool ws_foreground(const WsCtx& X, WsLds& L, const Ws
             const float acc = ((L.pF[0][tile][o] + L.pF[1][tile][o]) + (L.pF[2][tile][o] + L.pF[3][tile][o])) +
                               ((L.pF[4][tile][o] + L.pF[5][tile][o]) + (L.pF[6][tile][o] + L.pF[7][tile][o]));
             const float tt = fpc_tanhf(acc);
-            L.fo[X.slice][row] = tt + tt;  // the "dual" FC is the same Linear summed twice (wavernn.py:89-92)
+            L.fo[X.own][row] = tt + tt;  // the "dual" FC is the same Linear summed twice (wavernn.py:89-92)
         }
     }
     WSTAMP(11)
@@ -603,6 +621,7 @@ __device__ __forceinline__ WsCtx ws_ctx(const WsArgs& S, int group, int slice) {
     X.err = S.err;
     X.limit = S.limit;
     X.fast = false;
+    X.own = slice < X.nu ? slice : -1;  // (the encoder pairs workgroup s + 16 with s: k_encode_ws)
     X.withhold = S.withhold != 0 && group == 0 && slice == WNS - 1;
     return X;
 }
@@ -680,7 +699,7 @@ __global__ __launch_bounds__(NT) void k_forward_ws(const PredDev P, const float*
 // hop 3: the owners' next input rows (18 values = 6 granules each) -> x image; threads p < 96 of waves 0, 1
 __device__ __forceinline__ bool ws_gather3(const WsCtx& X, WsLds& L, int p, unsigned epoch) {
     const int u = p / WQX, e = p - u * WQX;
-    int gi[1] = {(p < WG * WQX && u < X.nu && u != X.slice) ? WOFF_X + p : -1};
+    int gi[1] = {(p < WG * WQX && u < X.nu && u != X.slice) ? WOFF_X + p : -1};  // (an owner has its own row already)
     u32x4 v[1];
     if (!ws_poll<1>(X, L, gi, epoch, v)) return false;
     if (gi[0] >= 0) {
@@ -770,16 +789,47 @@ __device__ __forceinline__ void ws_scl_wave(WsLds& L, float xv, int off, int n, 
         L.qs = L.sclc[off + bi];
     }
 }
-__device__ __forceinline__ void ws_encode_tail(WsLds& L, const float* fo, float* xn, const PredDev& P, const CbDev& C,
+// a list of up to five (distance, index) results goes to the partner workgroup / comes from it (lanes < 5 of one wave)
+__device__ __forceinline__ void ws_pair_put(const WsCtx& X, int u, int half, int stage, int k, unsigned epoch, double d, int ix) {
+    if (X.withhold) return;
+    const unsigned long long b = (unsigned long long)__double_as_longlong(d);
+    const u32x4 w = {epoch, (unsigned)b, (unsigned)(b >> 32), (unsigned)ix};
+    const int g = WOFF_PAIR + ((u * 2 + half) * 2 + stage) * SURV + k;
+    if (X.fast)
+        __builtin_amdgcn_raw_buffer_store_b128(w, X.rs, g * 16, 0, 0);
+    else
+        __builtin_amdgcn_raw_buffer_store_b128(w, X.rs, g * 16, 0, 16);
+}
+__device__ __forceinline__ bool ws_pair_get(const WsCtx& X, WsLds& L, int u, int half, int stage, int lane, unsigned epoch,
+                                            double& d, int& ix) {
+    int gi[1] = {lane < SURV ? WOFF_PAIR + ((u * 2 + half) * 2 + stage) * SURV + lane : -1};
+    u32x4 v[1];
+    if (!ws_poll<1>(X, L, gi, epoch, v)) return false;
+    d = __longlong_as_double((long long)(((unsigned long long)v[0].z << 32) | v[0].y));
+    ix = (int)v[0].w;
+    return true;
+}
+// The tail for utterance `u` of the group on its PAIR of workgroups: half 0 (workgroup u, the owner: scalar search, outputs,
+// next input row) and half 1 (workgroup u + 16, the helper).  Each half holds the entries [half NT, half NT + NT) of a stage,
+// one per thread: half of the loads, half of the float64 arithmetic, 36 registers of coordinates instead of 72.  A stage with
+// more than NT entries is searched by both halves and their results meet through 16-byte granules: after the first stage both
+// halves exchange their five best and rank the ten (so both know the survivors), after the second the helper hands its best
+// entry per survivor to the owner.  A stage that fits one half is searched by the owner alone.
+// false: an exchange was given up (the launch is dead).
+__device__ __forceinline__ bool ws_encode_tail(const WsCtx& X, WsLds& L, const float* fo, float* xn, const PredDev& P, const CbDev& C,
                                                const EncArgs& A, unsigned* err, size_t fi, float fv, int tid0, bool scl_in_lds,
-                                               int rot) {
+                                               int u, int half, unsigned epoch) {
     const int wave = tid0 >> 6, tid = tid0 + ws_opaque_zero(), lane = tid & 63;
     const int Cc = WIN, F = WFC;
-    const int off_sl = C.n_hi, off_v0 = off_sl + C.n_lo, off_v1 = off_v0 + C.N_hi0,
-              off_vl = off_v1 + (C.S_hi == 2 ? C.N_hi1 : 0);
+    const bool owner = half == 0;
     if (tid < F) L.rs[tid] = fv - fo[tid];  // :196
     if (tid == 0) L.ncand = 0;
+    if (tid < 2 * SURV) {
+        L.loc_d[tid / SURV][tid % SURV] = INFINITY;
+        L.loc_i[tid / SURV][tid % SURV] = 0x7fffffff;
+    }
     lds_barrier();
+    WSTAMP(13)
     float sabs = 0.0f;
     for (int d = 1; d < F; ++d) sabs += fabsf(L.rs[d]);
     const int i1 = fabsf(L.rs[0]) > A.l1;  // :202
@@ -788,32 +838,31 @@ __device__ __forceinline__ void ws_encode_tail(WsLds& L, const float* fo, float*
     const bool do_scl = A.qtz && !nonfinite && (i1 || C.scl_lo);
     const bool do_vq = A.qtz && !nonfinite && (i2 || C.vq_lo);
     const int S = i2 ? C.S_hi : 1, N0 = i2 ? C.N_hi0 : C.N_lo, N1 = (i2 && C.S_hi == 2) ? C.N_hi1 : 0;
+    WSTAMP(14)
     // (the host launches this kernel only within the tail's limits -- ws_codebooks_fit in predictor.hip: at most 2 NT entries
     //  per stage, at most 256 codes per scalar codebook, all of them in LDS)
-    if (nonfinite && A.qtz && tid == 0) status_or(err, FPC_ST_NONFINITE);
-    // a thread owns entries e0 and e0 + NT; which ones rotates with the workgroup, so that the 16 owners of an XCD, which
-    // sweep the same codebook at the same time, ask different L2 channels at any moment (any assignment gives the same
-    // result: the choices below are minima over (distance, index))
-    const int e0 = (tid + 64 * (rot & (NW - 1))) & (NT - 1), e1 = e0 + NT;
+    const bool pair0 = N0 > NT, pair1 = N1 > NT;  // stages that both halves search
+    if (!owner && !(do_vq && (pair0 || pair1))) return true;  // (workgroup-uniform) nothing for the helper in this frame
+    if (owner && nonfinite && A.qtz && tid == 0) status_or(err, FPC_ST_NONFINITE);
+    // which entry of its half a thread holds rotates with the utterance, so that the workgroups of an XCD, which sweep the
+    // same codebook at the same time, ask different L2 channels at any moment (any assignment gives the same result: every
+    // choice below is a minimum over (distance, index))
+    const int e = half * NT + ((tid + 64 * (u & (NW - 1))) & (NT - 1));
     if (do_vq) {
         const double* p0 = i2 ? C.vq_hi0_p : C.vq_lo_p;
         const double* cb0R = i2 ? C.vq_hi0_r : C.vq_lo_r;
-        double c0[NDIM + 1], c1[NDIM + 1];
-        const bool h0 = e0 < N0, h1 = e1 < N0;
-        ws_load_entry(p0, N0, e0, h0, c0);
-        ws_load_entry(p0, N0, e1, h1, c1);
+        double c[NDIM + 1];
+        const bool h0 = e < N0;
+        ws_load_entry(p0, N0, e, h0, c);
+        WSTAMP(15)
         if (tid < NDIM) L.xq[0][tid] = (double)L.rs[1 + tid];
-        if (do_scl && wave == NW - 1) ws_scl_wave(L, L.rs[0], i1 ? 0 : C.n_hi, i1 ? C.n_hi : C.n_lo, lane);
+        if (owner && do_scl && wave == NW - 1) ws_scl_wave(L, L.rs[0], i1 ? 0 : C.n_hi, i1 ? C.n_hi : C.n_lo, lane);
         lds_barrier();
         WSTAMP(25)
-        const double d0 = h0 ? ws_dist(L.xq[0], c0) : INFINITY, d1 = h1 ? ws_dist(L.xq[0], c1) : INFINITY;
-        double db = d0;
-        int eb = h0 ? e0 : 0x7fffffff;
-        if (d1 < db) {  // ascending entries: strict < keeps the lower index
-            db = d1;
-            eb = e1;
-        }
+        const double d0 = h0 ? ws_dist(L.xq[0], c) : INFINITY;
         if (S == 1) {  // the nearest entry is all a 1-stage search returns (vq_func.py:93-95)
+            double db = d0;
+            int eb = h0 ? e : 0x7fffffff;
             wave_argmin(db, eb);
             if (lane == 0) {
                 L.wd[0][wave][0] = db;
@@ -824,24 +873,46 @@ __device__ __forceinline__ void ws_encode_tail(WsLds& L, const float* fo, float*
             int gi = L.wi[0][0][0];
 #pragma unroll
             for (int w = 1; w < NW; ++w) take_min(gd, gi, L.wd[0][w][0], L.wi[0][w][0]);
-            if (gi == e0 || gi == e1) {  // the winner's thread holds its coordinates
+            if (pair0) {
+                if (!owner) {  // the helper's best goes to the owner: done
+                    if (tid == 0) ws_pair_put(X, u, 1, 0, 0, epoch, gd, gi);
+                    return true;
+                }
+                bool ok = true;
+                if (wave == 0) {
+                    double pd = INFINITY;
+                    int pi = 0x7fffffff;
+                    ok = ws_pair_get(X, L, u, 1, 0, lane < 1 ? lane : SURV, epoch, pd, pi);
+                    if (lane == 0) {
+                        L.loc_d[1][0] = pd;
+                        L.loc_i[1][0] = pi;
+                    }
+                }
+                (void)ok;  // (given up: the flag is set, the frame ends with the owner's own best and is thrown away)
+                lds_barrier();
+                take_min(gd, gi, L.loc_d[1][0], L.loc_i[1][0]);
+            }
+            if (gi == e && h0) {  // the winner's thread holds its coordinates
 #pragma unroll
-                for (int d = 0; d < NDIM; ++d) L.qv[d] = gi == e0 ? c0[d] : c1[d];
+                for (int d = 0; d < NDIM; ++d) L.qv[d] = c[d];
+            } else if (gi / NT != half && tid < NDIM) {  // (the helper's entry won)
+                L.qv[tid] = cb0R[(size_t)gi * NDIM + tid];
+            }
+            if (tid == 0) {
                 L.res_i[0] = gi;
                 L.res_i[1] = -1;
             }
         } else {
             // ---- first stage: the five smallest by (distance, index) (vq_quantize_mbest, vq_func.py:10-24) ----
-            const double wm = wave_min_f64(db);
+            const double wm = wave_min_f64(d0);
             if (lane == 0) L.wmin[wave] = wm;
-            // the second stage's entries replace the first stage's in the registers while the survivors are sorted out
-            const bool g0 = e0 < N1, g1 = e1 < N1;
-            ws_load_entry(C.vq_hi1_p, N1, e0, g0, c0);
-            ws_load_entry(C.vq_hi1_p, N1, e1, g1, c1);
+            // the second stage's entry replaces the first stage's in the registers while the survivors are sorted out
+            const bool g0 = e < N1;
+            ws_load_entry(C.vq_hi1_p, N1, e, g0, c);
             lds_barrier();
             WSTAMP(26)
-            double T;  // the fifth smallest per-wave minimum: at least five entries are at or below it, so the five
-            {          // smallest entries are, and everything at or below it is ranked
+            double T;  // the fifth smallest per-wave minimum: at least five of this half's entries are at or below it (or
+            {          // all of them, where it is infinite), so its five smallest are, and everything at or below it is ranked
                 const int j = lane & (NW - 1);
                 const double m = L.wmin[j];
                 int cnt = 0;
@@ -861,14 +932,7 @@ __device__ __forceinline__ void ws_encode_tail(WsLds& L, const float* fo, float*
                 const int pos = __hip_atomic_fetch_add(&L.ncand, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 if (pos < 64) {
                     L.cand_d[pos] = d0;
-                    L.cand_i[pos] = e0;
-                }
-            }
-            if (h1 && d1 <= T) {
-                const int pos = __hip_atomic_fetch_add(&L.ncand, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                if (pos < 64) {
-                    L.cand_d[pos] = d1;
-                    L.cand_i[pos] = e1;
+                    L.cand_i[pos] = e;
                 }
             }
             lds_barrier();
@@ -884,39 +948,65 @@ __device__ __forceinline__ void ws_encode_tail(WsLds& L, const float* fo, float*
                         const int ik = L.cand_i[k];
                         rank += (dk < dj) | ((dk == dj) & (ik < ij));
                     }
-                    if (rank < SURV) L.sv[rank] = ij;
+                    if (rank < SURV) {
+                        L.loc_d[0][rank] = dj;
+                        L.loc_i[0][rank] = ij;
+                    }
                 }
                 lds_barrier();
             } else {  // many entries at the bound (a degenerate codebook): five rounds of arg-min, each winner struck out
-                bool x0 = !h0, x1 = !h1;
+                bool x0 = !h0;
 #pragma unroll 1
                 for (int r = 0; r < SURV; ++r) {
-                    double d = INFINITY;
-                    int e = 0x7fffffff;
-                    if (!x0) {
-                        d = d0;
-                        e = e0;
-                    }
-                    if (!x1 && (x0 || d1 < d)) {
-                        d = d1;
-                        e = e1;
-                    }
-                    wave_argmin(d, e);
+                    double d = x0 ? INFINITY : d0;
+                    int ee = x0 ? 0x7fffffff : e;
+                    wave_argmin(d, ee);
                     if (lane == 0) {
                         L.wd[0][wave][0] = d;
-                        L.wi[0][wave][0] = e;
+                        L.wi[0][wave][0] = ee;
                     }
                     lds_barrier();
                     double gd = L.wd[0][0][0];
                     int gi = L.wi[0][0][0];
 #pragma unroll
                     for (int w = 1; w < NW; ++w) take_min(gd, gi, L.wd[0][w][0], L.wi[0][w][0]);
-                    if (gi == e0) x0 = true;
-                    if (gi == e1) x1 = true;
-                    if (tid == 0) L.sv[r] = gi;
+                    if (gi == e) x0 = true;
+                    if (tid == 0) {
+                        L.loc_d[0][r] = gd;
+                        L.loc_i[0][r] = gi;
+                    }
                     lds_barrier();
                 }
             }
+            // this half's five best are in loc[0] (fewer: padded with infinite distances); the two halves exchange theirs
+            if (wave == 0) {
+                bool ok = true;
+                if (pair0 || pair1) {
+                    if (lane < SURV) ws_pair_put(X, u, half, 0, lane, epoch, L.loc_d[0][lane], L.loc_i[0][lane]);
+                    double pd = INFINITY;
+                    int pi = 0x7fffffff;
+                    ok = ws_pair_get(X, L, u, half ^ 1, 0, lane, epoch, pd, pi);
+                    if (lane < SURV) {
+                        L.loc_d[1][lane] = pd;
+                        L.loc_i[1][lane] = pi;
+                    }
+                }
+                (void)ok;
+                // rank the ten (the same on both halves): the survivors
+                if (lane < 2 * SURV) {
+                    const double dj = L.loc_d[lane / SURV][lane % SURV];
+                    const int ij = L.loc_i[lane / SURV][lane % SURV];
+                    int rank = 0;
+#pragma unroll
+                    for (int k = 0; k < 2 * SURV; ++k) {
+                        const double dk = L.loc_d[k / SURV][k % SURV];
+                        const int ik = L.loc_i[k / SURV][k % SURV];
+                        rank += (dk < dj) | ((dk == dj) & (ik < ij));
+                    }
+                    if (rank < SURV && ij != 0x7fffffff) L.sv[rank] = ij;
+                }
+            }
+            lds_barrier();
             WSTAMP(28)
             // ---- second stage: residual of every survivor (vq_func.py:103-108); total errors compared ----
             if (tid < SURV * NDIM) {
@@ -929,13 +1019,8 @@ __device__ __forceinline__ void ws_encode_tail(WsLds& L, const float* fo, float*
             WSTAMP(29)
 #pragma unroll 1
             for (int k = 0; k < SURV; ++k) {
-                const double q0 = g0 ? ws_dist(L.xq[k], c0) : INFINITY, q1 = g1 ? ws_dist(L.xq[k], c1) : INFINITY;
-                double qb = q0;
-                int qe = g0 ? e0 : 0x7fffffff;
-                if (q1 < qb) {
-                    qb = q1;
-                    qe = e1;
-                }
+                double qb = g0 ? ws_dist(L.xq[k], c) : INFINITY;
+                int qe = g0 ? e : 0x7fffffff;
                 wave_argmin(qb, qe);
                 if (lane == 0) {
                     L.wd[k][wave][0] = qb;
@@ -948,9 +1033,19 @@ __device__ __forceinline__ void ws_encode_tail(WsLds& L, const float* fo, float*
                 double d = L.wd[tid][0][0];
                 int ix = L.wi[tid][0][0];
                 for (int w = 1; w < NW; ++w) take_min(d, ix, L.wd[tid][w][0], L.wi[tid][w][0]);
+                if (pair1) {
+                    if (!owner) {
+                        ws_pair_put(X, u, 1, 1, tid, epoch, d, ix);
+                    } else {
+                        double pd = INFINITY;
+                        int pi = 0x7fffffff;
+                        if (ws_pair_get(X, L, u, 1, 1, tid, epoch, pd, pi)) take_min(d, ix, pd, pi);
+                    }
+                }
                 L.od2[tid] = d;
                 L.oi2[tid] = ix;
             }
+            if (!owner) return true;  // (the helper's part ends here)
             lds_barrier();
             // head of the merge-insert of candidate paths (vq_func.py:110-125): a later survivor replaces the running best
             // only if its total error is strictly smaller
@@ -965,9 +1060,13 @@ __device__ __forceinline__ void ws_encode_tail(WsLds& L, const float* fo, float*
                 }
             }
             const int w1 = L.oi2[bk];
-            if (w1 == e0 || w1 == e1) {
+            if (w1 == e && g0) {  // :127-129; the winner's thread holds its coordinates
 #pragma unroll
-                for (int d = 0; d < NDIM; ++d) L.qv[d] = L.ent[bk][d] + (w1 == e0 ? c0[d] : c1[d]);  // :127-129
+                for (int d = 0; d < NDIM; ++d) L.qv[d] = L.ent[bk][d] + c[d];
+            } else if (w1 / NT != half && tid < NDIM) {  // (the helper's entry won)
+                L.qv[tid] = L.ent[bk][tid] + C.vq_hi1_r[(size_t)w1 * NDIM + tid];
+            }
+            if (tid == 0) {
                 L.res_i[0] = L.sv[bk];
                 L.res_i[1] = w1;
             }
@@ -982,10 +1081,11 @@ __device__ __forceinline__ void ws_encode_tail(WsLds& L, const float* fo, float*
     float rq = 0.0f;
     int ix0 = -1, ix1 = -1, ix2 = -1, ix3 = -1;
     if (nonfinite) ix0 = ix1 = ix2 = ix3 = -2;
+    // (the usage histograms are counted from the frame's symbols by k_hist_symbols after this kernel: an atomic here costs the
+    //  closed loop a memory round trip per frame)
     if (do_scl && tid == 0) {
         rq = (float)L.qs;
         ix0 = L.res_i[2] + (i1 ? 0 : C.n_hi);
-        if (A.hist) atomicAdd(&A.hist[(i1 ? 0 : off_sl) + L.res_i[2]], 1ull);
     }
     if (do_vq) {
         if (tid >= 1 && tid < F) rq = (float)L.qv[tid - 1];
@@ -993,13 +1093,8 @@ __device__ __forceinline__ void ws_encode_tail(WsLds& L, const float* fo, float*
             if (i2) {
                 ix1 = L.res_i[0];
                 ix2 = L.res_i[1];
-                if (A.hist) {
-                    atomicAdd(&A.hist[off_v0 + ix1], 1ull);
-                    if (C.S_hi == 2) atomicAdd(&A.hist[off_v1 + ix2], 1ull);
-                }
             } else {
                 ix3 = L.res_i[0];
-                if (A.hist) atomicAdd(&A.hist[off_vl + ix3], 1ull);
             }
         }
     }
@@ -1028,14 +1123,12 @@ __device__ __forceinline__ void ws_encode_tail(WsLds& L, const float* fo, float*
     if (tid == 0) {
         A.ind1[fi] = (float)i1;
         A.ind2[fi] = (float)i2;
-        if (A.idx) {
-            A.idx[fi * 4 + 0] = ix0;
-            A.idx[fi * 4 + 1] = ix1;
-            A.idx[fi * 4 + 2] = ix2;
-            A.idx[fi * 4 + 3] = ix3;
-        }
+        *reinterpret_cast<int4*>(&A.idx[fi * 4]) = make_int4(ix0, ix1, ix2, ix3);  // (never null here: fpc_encode)
     }
+    WSTAMP(17)
     lds_barrier();  // (the next input row is in LDS; the frame's global stores need not have landed)
+    WSTAMP(18)
+    return true;
 }
 
 __global__ __launch_bounds__(NT) void k_encode_ws(const PredDev P, const CbDev C, const EncArgs A, const WsArgs S) {
@@ -1044,6 +1137,10 @@ __global__ __launch_bounds__(NT) void k_encode_ws(const PredDev P, const CbDev C
     int group, slice;
     if (!ws_role(S.ngroups, group, slice)) return;
     WsCtx X = ws_ctx(S, group, slice);
+    // utterance u of the group is coded by workgroups u (owner) and u + 16 (helper): both need its prediction
+    const int u = slice & (WG - 1), half = slice / WG;
+    const bool member = u < X.nu, owner = member && half == 0;
+    X.own = member ? u : -1;
     WsRegs R;
     for (int i = tid; i < WH1 * WG; i += NT) L.h1[i] = 0.0f;  // h = None -> zeros (wavernn.py:182)
     for (int i = tid; i < WH2 * WG; i += NT) L.h2[i] = 0.0f;
@@ -1055,20 +1152,19 @@ __global__ __launch_bounds__(NT) void k_encode_ws(const PredDev P, const CbDev C
     }
     __syncthreads();
     ws_prologue(P, X, L, R, S, tid);
-    const bool owner = slice < X.nu;
-    const int b = X.b0 + slice;  // the owned utterance
+    const int b = X.b0 + u;  // the pair's utterance
     int fg_epoch = 0;
     int i = 0;
     WPROF_INIT()
     for (; i < A.Lf; ++i) {
         const unsigned epoch = (unsigned)i + 1u;
-        // this frame's feature row of the owned utterance (one column per thread), and the pitch columns of every
+        // this frame's feature row of the pair's utterance (one column per thread), and the pitch columns of every
         // utterance of the group, which pass through to the next input (wavernn.py:178): fetched before the step
-        const float fv = (owner && tid < WIN) ? A.feat[((size_t)b * A.Lf + i) * WIN + tid] : 0.0f;
+        const float fv = (member && tid < WIN) ? A.feat[((size_t)b * A.Lf + i) * WIN + tid] : 0.0f;
         float pv = 0.0f;
         if (tid < (WIN - WFC) * WG) {
-            const int u = tid / (WIN - WFC), k = WFC + tid % (WIN - WFC);
-            if (u < X.nu) pv = A.feat[((size_t)(X.b0 + u) * A.Lf + i) * WIN + k];
+            const int uu = tid / (WIN - WFC), k = WFC + tid % (WIN - WFC);
+            if (uu < X.nu) pv = A.feat[((size_t)(X.b0 + uu) * A.Lf + i) * WIN + k];
         }
         if (tid < WFGT) {
             __builtin_amdgcn_s_setprio(FPC_FG_PRIO);
@@ -1078,20 +1174,21 @@ __global__ __launch_bounds__(NT) void k_encode_ws(const PredDev P, const CbDev C
             (void)ws_background(X, L, R, i, i + 1 == A.Lf, tid - WFGT);
         }
         WBSTAMP(19)
-        if (__syncthreads_or(ws_dead(L))) break;  // both roles meet: the searches take the whole workgroup
+        lds_barrier();  // both roles meet: the searches take the whole workgroup
         WSTAMP(20)
-        if (owner) {
-            ws_encode_tail(L, L.fo[slice], L.xn, P, C, A, S.err, (size_t)b * A.Lf + i, fv, tid, scl_in_lds, slice);
-            if (tid < 64) ws_publish_x(X, L, tid, epoch);
+        // (a launch that is dead by now runs the frame to its end on whatever the chain left behind -- every index stays inside
+        //  its codebook, a missing partner counts as "no entry" -- and leaves the loop below)
+        if (member) {
+            (void)ws_encode_tail(X, L, L.fo[u], L.xn, P, C, A, S.err, (size_t)b * A.Lf + i, fv, tid, scl_in_lds, u, half, epoch);
+            if (owner && tid < 64) ws_publish_x(X, L, tid, epoch);
         }
         WSTAMP(21)
         if (tid < (WIN - WFC) * WG) {
-            const int u = tid / (WIN - WFC), k = WFC + tid % (WIN - WFC);
-            if (!(owner && u == slice)) L.x[k * WG + u] = pv;
+            const int uu = tid / (WIN - WFC), k = WFC + tid % (WIN - WFC);
+            if (!(owner && uu == u)) L.x[k * WG + uu] = pv;
         }
-        bool ok = true;
-        if (tid < 128) ok = ws_gather3(X, L, tid, epoch);
-        if (__syncthreads_or(!ok)) break;
+        if (tid < 128) (void)ws_gather3(X, L, tid, epoch);
+        if (ws_frame_dead(L, tid)) break;
         WSTAMP(22)
         WBSTAMP(23)
     }
@@ -1131,7 +1228,7 @@ __global__ __launch_bounds__(NT) void k_decode_feat_ws(const PredDev P, const Cb
         } else {
             (void)ws_background(X, L, R, i, i + 1 == Lf, tid - WFGT);
         }
-        if (__syncthreads_or(ws_dead(L))) break;
+        lds_barrier();
         if (owner && tid < 64) {  // the residual is a lookup: one wave rebuilds the owned utterance's next input row
             decode_frame(L.fo[slice], L.xn, P, C, pitch, idx, c_out, bad, (size_t)b * Lf + i, true, tid);
             ws_publish_x(X, L, tid, epoch);
@@ -1140,12 +1237,26 @@ __global__ __launch_bounds__(NT) void k_decode_feat_ws(const PredDev P, const Cb
             const int u = tid / (WIN - WFC), k = WFC + tid % (WIN - WFC);
             if (!(owner && u == slice)) L.x[k * WG + u] = pv;
         }
-        bool ok = true;
-        if (tid >= 64 && tid < 192) ok = ws_gather3(X, L, tid - 64, epoch);
-        if (__syncthreads_or(!ok)) break;
+        if (tid >= 64 && tid < 192) (void)ws_gather3(X, L, tid - 64, epoch);
+        if (ws_frame_dead(L, tid)) break;
     }
     if (i < Lf && owner) {  // fail loudly: NaN from this frame on; the host reports FPC_ERR_TIMEOUT
         const float qnan = __uint_as_float(0x7fc00000u);
         for (size_t k = (size_t)i * WIN + tid; k < (size_t)Lf * WIN; k += NT) c_out[(size_t)b * Lf * WIN + k] = qnan;
     }
+}
+
+// the codebook-usage histograms of an encode call (cb_tot of Wavernn.encoder, wavernn.py:221-240) from its symbols
+// idx [frames][4] = {scalar code (+ n_hi when from the below-threshold book), stage 1, stage 2, below-threshold entry};
+// -1 = not coded, -2 = frame refused or poisoned (not counted)
+__global__ __launch_bounds__(256) void k_hist_symbols(const CbDev C, const int* __restrict__ idx, size_t frames,
+                                                      unsigned long long* hist) {
+    const size_t f = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (f >= frames) return;
+    const int4 s = *reinterpret_cast<const int4*>(&idx[f * 4]);
+    const int off_sl = C.n_hi, off_v0 = off_sl + C.n_lo, off_v1 = off_v0 + C.N_hi0, off_vl = off_v1 + (C.S_hi == 2 ? C.N_hi1 : 0);
+    if (s.x >= 0) atomicAdd(&hist[s.x], 1ull);  // (codes of the below-threshold book follow the others: same slot arithmetic)
+    if (s.y >= 0) atomicAdd(&hist[off_v0 + s.y], 1ull);
+    if (s.z >= 0 && C.S_hi == 2) atomicAdd(&hist[off_v1 + s.z], 1ull);
+    if (s.w >= 0) atomicAdd(&hist[off_vl + s.w], 1ull);
 }
