@@ -1011,7 +1011,9 @@ __device__ __forceinline__ bool ws_encode_tail(const WsCtx& X, WsLds& L, const f
             // ---- second stage: residual of every survivor (vq_func.py:103-108); total errors compared ----
             if (tid < SURV * NDIM) {
                 const int k = tid / NDIM, d = tid - k * NDIM;
-                const double en = cb0R[(size_t)L.sv[k] * NDIM + d];
+                // (a launch that is already dead may get here without five survivors: the index stays inside the book)
+                const int sk = L.sv[k] < 0 ? 0 : (L.sv[k] < N0 ? L.sv[k] : N0 - 1);
+                const double en = cb0R[(size_t)sk * NDIM + d];
                 L.ent[k][d] = en;
                 L.xq[k][d] = (double)L.rs[1 + d] - en;
             }

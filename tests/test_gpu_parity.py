@@ -1072,3 +1072,129 @@ def test_vocoder_long_utterance_parity(torch_cuda, vocoder, synth, oracle):
     nz = np.nonzero(pcm[0] != ref)[0]
     assert nz.size == 0, f"first mismatch at sample {nz[:5]}"
     assert int(np.abs(pcm[0].astype(np.int32)).max()) > 100  # a live signal, not silence
+
+
+# ---- the weights-stationary predictor kernels (csrc/predictor_ws.h): the shipped form for the production shape ----
+def _ws_cfgs(cb_paths, tmp):
+    """codebook configurations: the reference's four books, only the above-threshold ones, a 1-stage book, ragged stages, and a
+    degenerate first stage (300 copies of one entry: far more than 64 candidates at the bound, ties decided by index)"""
+    full = dict(scl_cb_path=cb_paths["scl_hi"], cb_path=cb_paths["vq_hi"], bl_scl_cb_path=cb_paths["scl_lo"],
+                bl_cb_path=cb_paths["vq_lo"])
+    hi = dict(full, bl_scl_cb_path="", bl_cb_path="")
+    one = dict(full, cb_path=cb_paths["vq_lo"], bl_cb_path="")
+    rag = dict(full, cb_path=cb_paths["ragged"])
+    c = np.load(cb_paths["vq_hi"]).copy()
+    c[0, 100:400] = c[0, 7]
+    c[1, 600:700] = c[1, 3]
+    p = os.path.join(tmp, "degenerate.npy")
+    np.save(p, c)
+    deg = dict(full, cb_path=p)
+    return {"full": full, "hi_only": hi, "one_stage": one, "ragged": rag, "degenerate": deg}
+
+
+def test_weights_stationary_kernels_equal_row_split_forms(torch_cuda, model, synth, oracle, cb_paths, monkeypatch, tmp_path):
+    """the shipped predictor kernels for the production shape (groups of 16 utterances on the 32 workgroups of an XCD, weights
+    resident in LDS, gate rows on f32 MFMA, 16-byte granule hops, the encoder's tail on owner + helper pairs) against the
+    phase-after-phase kernels (FPC_PRED_WS=0, FPC_PRED_DF=0, one workgroup per utterance) and the oracle: forward incl.
+    carried states, encoder with and without quantisation incl. symbols and histograms, receiver -- bit for bit, for 1 / 7 /
+    16 / 33 / 128 / 200 utterances (partly filled groups, two rounds of groups), on BOTH hop paths (FPC_FAST_HOP=0: write-through
+    stores, the path a placement on several XCDs takes) and for five codebook configurations"""
+    torch = torch_cuda
+    cfgs = _ws_cfgs(cb_paths, str(tmp_path))
+
+    def run(feat, cfg):
+        y, h1, h2 = model.forward(feat)
+        y2, h1b, h2b = model.forward(feat[:, :5], h1, h2)
+        enc = model.encoder(cfg, feat, None, 0.09, 0.28, qtz=True, return_indices=True)
+        enc2 = model.encoder(cfg, feat, None, 0.09, 0.28, qtz=False)
+        dec = model.decode_indices(cfg, enc[7], feat[:, :, 18:].contiguous())
+        torch.cuda.synchronize()
+        return ([t.cpu().numpy() for t in (y, h1, h2, y2, h1b, h2b)] + [t.cpu().numpy() for t in enc[:6]] + list(enc[6]) +
+                [enc[7].cpu().numpy()] + [t.cpu().numpy() for t in enc2[:6]] + [dec.cpu().numpy()])
+
+    for B, L, names in ((1, 30, ("full",)), (7, 40, ("full", "hi_only", "one_stage", "ragged", "degenerate")), (16, 33, ("full",)),
+                        (33, 25, ("full", "ragged")), (128, 60, ("full",)), (200, 20, ("full", "degenerate"))):
+        feat = torch.from_numpy(synth.predictor_features(B, L, utt0=7000)).cuda()
+        for name in names:
+            cfg = cfgs[name]
+            monkeypatch.setenv("FPC_PRED_WS", "0")
+            monkeypatch.setenv("FPC_PRED_SPLIT", "0")
+            monkeypatch.setenv("FPC_PRED_DF", "0")
+            ref = run(feat, cfg)
+            monkeypatch.delenv("FPC_PRED_WS")
+            monkeypatch.delenv("FPC_PRED_SPLIT")
+            monkeypatch.delenv("FPC_PRED_DF")
+            for fast in ("1", "0"):
+                monkeypatch.setenv("FPC_FAST_HOP", fast)
+                got = run(feat, cfg)
+                assert len(got) == len(ref)
+                for k, (a, b) in enumerate(zip(ref, got)):
+                    assert np.array_equal(a, b), (B, L, name, fast, k)
+            monkeypatch.delenv("FPC_FAST_HOP")
+    # ... and the oracle itself (one partly filled group, the reference's four codebooks)
+    feat = synth.predictor_features(5, 50, utt0=7100)
+    c = synth.codebooks()
+    CB = oracle.Codebooks(c["vq_hi"], c["scl_hi"], c["vq_lo"], c["scl_lo"])
+    o = oracle.Predictor(synth.predictor_state_dict()).encode(feat, CB, 0.09, 0.28, True)
+    enc = model.encoder(cfgs["full"], torch.from_numpy(feat).cuda(), None, 0.09, 0.28, qtz=True, return_indices=True)
+    assert np.array_equal(enc[0].cpu().numpy(), o["c_in"]) and np.array_equal(enc[2].cpu().numpy(), o["r_qtz"])
+    assert np.array_equal(enc[7].cpu().numpy(), o["idx"])
+
+
+def test_weights_stationary_timeout_is_an_error_not_garbage(torch_cuda, synth, cb_paths, monkeypatch):
+    """the give-up path of the weights-stationary kernels: the last workgroup of group 0 never publishes
+    (FPC_TEST_WITHHOLD_PUBLISH), its 31 partners time out once (20 ms instead of 1 s) -- the launch is accepted, every output
+    of the group is NaN / -2 (never finite-but-wrong), the handle reports FPC_ERR_TIMEOUT until the status call has cleared it,
+    and the next launch is bit-identical to an undisturbed one; a second group of the same launch is untouched"""
+    from fpcodec_amd import _lib
+    from fpcodec_amd._lib import FpcError
+    from fpcodec_amd.wavernn import Wavernn
+    torch = torch_cuda
+    m = Wavernn(20, 384, 128, 18)
+    m.load_state_dict(synth.predictor_state_dict())
+    cfg = dict(scl_cb_path=cb_paths["scl_hi"], cb_path=cb_paths["vq_hi"], bl_scl_cb_path=cb_paths["scl_lo"],
+               bl_cb_path=cb_paths["vq_lo"])
+    B, L = 20, 12  # two groups: 16 + 4 utterances
+    feat = torch.from_numpy(synth.predictor_features(B, L, utt0=5300)).cuda()
+    good = m.encoder(cfg, feat, None, 0.09, 0.28, qtz=True, return_indices=True)
+    yg, h1g, _ = m.forward(feat)
+    dg = m.decode_indices(cfg, good[7], feat[:, :, 18:].contiguous())
+    torch.cuda.synchronize()
+    monkeypatch.setenv("FPC_TEST_WITHHOLD_PUBLISH", "1")
+    monkeypatch.setenv("FPC_SPIN_LIMIT_US", "20000")
+    with pytest.raises(FpcError, match="timed out"):
+        m.encoder(cfg, feat, None, 0.09, 0.28, qtz=True, return_indices=True)
+    yb, h1b, _ = m.forward(feat)  # (status cleared by the raise: accepted, fails again)
+    with pytest.raises(FpcError, match="timed out"):
+        m.check()
+    h1b, h1g = h1b.reshape(B, -1), h1g.reshape(B, -1)
+    assert torch.isnan(yb[:16]).all() and torch.isnan(h1b[:16]).all()
+    assert torch.equal(yb[16:], yg[16:]) and torch.equal(h1b[16:], h1g[16:])  # the other group never waited for anybody
+    with pytest.raises(FpcError, match="timed out"):
+        m.decode_indices(cfg, good[7], feat[:, :, 18:].contiguous())
+    # the raw ABI: poison in the encoder's outputs of group 0, the symbols -2
+    L_ = _lib.lib()
+    from fpcodec_amd.vq_func import load_codebooks
+    cb = load_codebooks(cfg["cb_path"], cfg["scl_cb_path"], cfg["bl_cb_path"], cfg["bl_scl_cb_path"])
+    bufs = [torch.zeros(B, L, n, device="cuda") for n in (20, 18, 18, 18, 1, 1)]
+    idx = torch.zeros(B, L, 4, device="cuda", dtype=torch.int32)
+    hist = torch.zeros(cb.hist_size, device="cuda", dtype=torch.int64)
+    assert L_.fpc_predictor_status(m._handle()) in (0, -5)  # (whatever the failed decode left: cleared)
+    rc = L_.fpc_encode(m._handle(), cb.handle, feat.data_ptr(), B, L, 0.09, 0.28, 1, *[b.data_ptr() for b in bufs],
+                       idx.data_ptr(), hist.data_ptr(), _lib.stream_ptr())
+    assert rc == 0
+    torch.cuda.synchronize()
+    assert torch.isnan(bufs[0][:16]).all() and torch.isnan(bufs[1][:16]).all() and (idx[:16] == -2).all()
+    assert torch.equal(bufs[0][16:], good[0][16:]) and torch.equal(idx[16:], good[7][16:])
+    assert int(hist.sum()) == int((idx[16:] >= 0).sum())  # only the healthy group's symbols were counted
+    assert L_.fpc_predictor_status(m._handle()) == -5 and L_.fpc_predictor_status(m._handle()) == 0
+    monkeypatch.delenv("FPC_TEST_WITHHOLD_PUBLISH")
+    monkeypatch.delenv("FPC_SPIN_LIMIT_US")
+    again = m.encoder(cfg, feat, None, 0.09, 0.28, qtz=True, return_indices=True)
+    ya, _, _ = m.forward(feat)
+    da = m.decode_indices(cfg, again[7], feat[:, :, 18:].contiguous())
+    m.check()
+    for a, b in zip(good[:6] + (good[7], yg, dg), again[:6] + (again[7], ya, da)):
+        assert torch.equal(a, b)
+    for a, b in zip(good[6], again[6]):
+        assert np.array_equal(a, b)

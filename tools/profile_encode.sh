@@ -10,7 +10,7 @@ for c in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD"
   timeout -k 10 200 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $o/$tag -o r -- python3 tools/time_encode_split.py > /dev/null 2> $o/$tag.err || echo "FAILED $c"
 done
 python3 - <<'PY'
-import csv, glob, os, collections
+import csv, glob, os, collections, re
 o = os.environ.get("TAG", "r02")
 base = f"gpurun_out/{o}/enc_prof"
 out = open(f"{base}/summary.txt", "w")
@@ -24,9 +24,9 @@ for d in sorted(glob.glob(f"{base}/*/")):
     for f in glob.glob(d + "**/*counter_collection.csv", recursive=True):
         acc = collections.defaultdict(lambda: collections.defaultdict(list))
         for row in csv.DictReader(open(f)):
-            k = row.get("Kernel_Name", "")
-            if "k_encode" in k or "k_forward" in k:
-                acc[k.split("(")[0][-40:]][row["Counter_Name"]].append(float(row["Counter_Value"]))
+            m = re.search(r"(k_(?:encode|forward|hist|decode_feat)\w*)", row.get("Kernel_Name", ""))
+            if m:
+                acc[m.group(1)][row["Counter_Name"]].append(float(row["Counter_Value"]))
         for k, cs in acc.items():
             for c, v in cs.items():
                 p(f"{k:42s} {c:24s} launches {len(v):3d}  mean {sum(v)/len(v):.4g}  max {max(v):.4g}")
