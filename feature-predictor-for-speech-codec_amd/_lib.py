@@ -9,7 +9,7 @@ LIB_PATH = os.environ.get("FPC_LIB_PATH") or os.path.join(_HERE, "libfpcodec.so"
 _lib = None
 
 SYMBOLS = [
-    "fpc_last_error", "fpc_abi_version", "fpc_device_count",
+    "fpc_last_error", "fpc_abi_version", "fpc_build_info", "fpc_device_count",
     "fpc_predictor_create", "fpc_predictor_destroy", "fpc_predictor_forward", "fpc_predictor_status",
     "fpc_predictor_set_split",
     "fpc_codebooks_create", "fpc_codebooks_destroy", "fpc_codebooks_hist_size",
@@ -66,6 +66,7 @@ def lib():
                 "(python -c 'import __graft_entry__ as g; g.build()'); there is no CPU fallback")
         L = C.CDLL(LIB_PATH)
         L.fpc_last_error.restype = C.c_char_p
+        L.fpc_build_info.restype = C.c_char_p
         L.fpc_lpcnet_workspace_bytes.restype = C.c_longlong
         L.fpc_lpcnet_workspace_bytes.argtypes = [C.c_void_p, C.c_int, C.c_int]
         L.fpc_lpcnet_last_decode_ms.restype = C.c_float

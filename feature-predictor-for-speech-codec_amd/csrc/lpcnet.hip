@@ -17,6 +17,7 @@
 //                    table and the partial sums of the sparse product live in LDS, HBM is touched only
 //                    for the per-frame conditioning vectors, the embedding-table rows and the PCM output.
 #include "fpc_common.h"
+#include <string>
 #include <algorithm>
 #include <memory>
 
@@ -127,6 +128,22 @@ __global__ __launch_bounds__(256) void k_frame_mfma(const float* __restrict__ x,
 // =====================================================================================
 // host side
 // =====================================================================================
+// compile-time tunables of this translation unit that differ from the shipped defaults (fpc_build_info, api.hip)
+namespace fpc {
+void lpcnet_build_info(std::string& out) {
+    char b[64];
+#define FPC_TUNE(name, value, dflt)                            \
+    if ((value) != (dflt)) {                                   \
+        snprintf(b, sizeof b, " " name "=%d", (int)(value));   \
+        out += b;                                              \
+    }
+    FPC_TUNE("FPC_PRIO", FPC_PRIO, 3)
+    FPC_TUNE("FPC_NA", FPC_NA, 6)
+    FPC_TUNE("FPC_NB", FPC_NB, 4)
+    FPC_TUNE("FPC_PCM_WHERE", FPC_PCM_WHERE, 0)
+#undef FPC_TUNE
+}
+}  // namespace fpc
 struct fpc_lpcnet {
     int device = 0;
     fpc::DevBuf embed_pitch, conv1_k, conv1_b, conv2_k, conv2_b, d1_k, d1_b, d2_k, d2_b;

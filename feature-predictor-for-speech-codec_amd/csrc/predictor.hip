@@ -17,6 +17,7 @@
 // oracle bit for bit and the reference's indices exactly.
 #include "fpc_common.h"
 #include <atomic>
+#include <string>
 #include <memory>
 #include <cmath>
 
@@ -69,6 +70,7 @@ struct SplitCtx {
     bool dead = false;              // a spin gave up: no further waiting in this workgroup
     bool withhold = false;          // test hook (FPC_TEST_WITHHOLD_PUBLISH=1): this workgroup never publishes
     bool fast = false;              // every workgroup of the utterance reported the same XCD: plain stores (predictor_df.h)
+    bool no_fast = false;           // ... unless FPC_FAST_HOP=0 forbids them
 };
 constexpr unsigned FPC_ST_TIMEOUT = 1u, FPC_ST_NONFINITE = 2u;
 typedef __attribute__((address_space(1))) unsigned gu32;
@@ -887,6 +889,7 @@ struct SplitArgs {
     unsigned* err;            // the handle's status word (host-mapped, sticky; always valid)
     unsigned long long limit; // give-up bound of one spin, s_memrealtime ticks
     int withhold;             // test hook: the last slice of utterance 0 never publishes
+    int no_fast;              // FPC_FAST_HOP=0: the write-through exchange even when every slice sits on one XCD (tests run both)
 };
 __device__ __forceinline__ SplitCtx split_ctx(const SplitArgs& S, const PredDev& P, int b, int half) {
     SplitCtx X;
@@ -895,6 +898,7 @@ __device__ __forceinline__ SplitCtx split_ctx(const SplitArgs& S, const PredDev&
     X.err = S.err;
     X.limit = S.limit;
     X.withhold = S.withhold != 0 && b == 0 && half == S.n - 1 && S.n > 1;
+    X.no_fast = S.no_fast != 0;
     // a handle whose status word is already set (an earlier launch failed and the host has not cleared it yet)
     // does not wait for anybody: its outputs are poison anyway
     X.dead = S.n > 1 && (status_load(S.err) & FPC_ST_TIMEOUT) != 0u;
@@ -1618,6 +1622,38 @@ __global__ void k_adam(float* __restrict__ p, float* __restrict__ m, float* __re
 // =====================================================================================
 // host side
 // =====================================================================================
+// compile-time tunables of this translation unit that differ from the shipped defaults (fpc_build_info, api.hip)
+namespace fpc {
+void predictor_build_info(std::string& out) {
+    char b[64];
+#define FPC_TUNE(name, value, dflt)                            \
+    if ((value) != (dflt)) {                                   \
+        snprintf(b, sizeof b, " " name "=%d", (int)(value));   \
+        out += b;                                              \
+    }
+    FPC_TUNE("FPC_NT", FPC_NT, 512)
+    FPC_TUNE("FPC_CD", FPC_CD, 16)
+    FPC_TUNE("FPC_DFW", FPC_DFW, 16)
+    FPC_TUNE("FPC_FG_PRIO", FPC_FG_PRIO, 2)
+    FPC_TUNE("FPC_BSTAMP_WAVE", FPC_BSTAMP_WAVE, 0)
+#undef FPC_TUNE
+#ifdef FPC_WAVES_EU
+    out += " FPC_WAVES_EU";
+#endif
+#ifdef FPC_XCHG_NOSLEEP
+    out += " FPC_XCHG_NOSLEEP";
+#endif
+#ifdef FPC_PRED_PROF
+    out += " FPC_PRED_PROF";
+#endif
+#ifdef FPC_VQ_PROF
+    out += " FPC_VQ_PROF";
+#endif
+#ifdef FPC_WS_PROF
+    out += " FPC_WS_PROF";
+#endif
+}
+}  // namespace fpc
 struct fpc_predictor {
     PredDev d;
     fpc::DevBuf buf[10];
@@ -1677,11 +1713,13 @@ static int split_args(fpc_predictor* p, int B, hipStream_t st, SplitArgs* out) {
     out->err = p->status_dev;
     out->limit = 100000000ull;  // 1 s of s_memrealtime (100 MHz)
     out->withhold = 0;
+    out->no_fast = 0;
     if (const char* lim = getenv("FPC_SPIN_LIMIT_US")) {  // test hook: a shorter give-up bound
         const long us = atol(lim);
         if (us > 0) out->limit = (unsigned long long)us * 100ull;
     }
     if (const char* wh = getenv("FPC_TEST_WITHHOLD_PUBLISH")) out->withhold = wh[0] == '1';  // test hook
+    if (const char* fh = getenv("FPC_FAST_HOP")) out->no_fast = fh[0] == '0';  // the write-through exchange everywhere
     const char* env = getenv("FPC_PRED_SPLIT");  // 0: never; 2/4/8: exactly that many (tests); unset: as many as leave
     int n = 1;                                    // every workgroup a CU of its own, up to 8
     for (int c = 2; c <= 8; c *= 2)

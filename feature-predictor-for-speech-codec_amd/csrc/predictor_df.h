@@ -232,10 +232,7 @@ __device__ __forceinline__ void df_hello(SplitCtx& X, int tid) {
     bool same = true, gave_up = false;
     if (tid < X.n && tid != X.half) same = __float_as_uint(await_granule(&X.g3[tid], tag, X, gave_up)) == xcc;
     if (__syncthreads_or(gave_up)) X.dead = true;
-    X.fast = __syncthreads_and(same) != 0 && !X.dead;
-#ifdef FPC_NO_FAST_HOP
-    X.fast = false;
-#endif
+    X.fast = __syncthreads_and(same) != 0 && !X.dead && !X.no_fast;  // (FPC_FAST_HOP=0: the general path, for the tests)
 }
 
 // one hop by the foreground threads: this workgroup's slice goes out under a new epoch, the others come in

@@ -42,6 +42,10 @@ typedef void* fpc_stream; /* hipStream_t */
 
 FPC_API const char* fpc_last_error(void);
 FPC_API int fpc_abi_version(void);
+/* "fpcodec abi <n> gfx950" followed by every compile-time tunable (-DFPC_...) that differs from the shipped default and
+ * every diagnostic switch the library was built with: a non-default build identifies itself (the reference has no
+ * counterpart: its scripts are the build). */
+FPC_API const char* fpc_build_info(void);
 /* number of visible HIP devices (0 on a CPU-only host); never fails */
 FPC_API int fpc_device_count(void);
 
@@ -74,15 +78,38 @@ FPC_API int fpc_predictor_create(const fpc_predictor_weights* w, fpc_predictor**
 /* drops the caller's reference; a live fpc_trainer built on the handle keeps the device weights alive */
 FPC_API void fpc_predictor_destroy(fpc_predictor* p);
 
-/* Row split: fpc_predictor_forward, fpc_encode, fpc_decode_features and fpc_trainer_step run one utterance on 2, 4 or
- * 8 workgroups (one CU each) while the batch leaves CUs idle (B x n <= number of CUs); the slices of the recurrent
- * state change hands through a block of tagged 8-byte words that belongs to the predictor handle and is cleared on the
- * stream before each launch.  Results are bit-identical to the one-workgroup form.
- *  - ASSUMPTION: the process owns the GPU.  The automatic choice of n counts on every workgroup of a group being
- *    dispatched at once; a co-tenant kernel that occupies CUs for longer than the bound below makes a split launch
- *    fail.  Shared-GPU deployments pin n = 1 with fpc_predictor_set_split(p, 1) (or FPC_PRED_SPLIT=0).
+/* Kernel forms of the predictor.  All give the same bits (every row is evaluated in the canonical order of
+ * oracle/fpc_oracle.c, matvec_seg); the tests compare them with each other and with the oracle.
+ *
+ * (1) Weights-stationary (csrc/predictor_ws.h) -- what fpc_predictor_forward, fpc_encode and fpc_decode_features run for the
+ *     reference's production shape (20 -> 384 -> 128 -> 18) on a whole MI355X (>= 256 CUs) unless a row split is pinned
+ *     (below) or the codebooks exceed the limits of its search (more than 1 024 entries in a stage, more than 256 codes in
+ *     a scalar book).  Utterances are taken in GROUPS of 16 (= the M dimension of one f32 MFMA tile); a group runs on 32
+ *     workgroups, which the launch arranges to be the 32 CUs of one XCD (8 groups = 128 utterances fill the chip; more
+ *     groups follow as workgroups retire; a partly filled last group costs what a full one does).  Each workgroup keeps
+ *     1/32 of every weight matrix in LDS for the whole launch; the new state values go round as 16-byte granules
+ *     {epoch, 3 values} in a block that belongs to the predictor handle and is cleared on the stream before each launch.
+ * (2) Row split (csrc/predictor.hip, predictor_df.h) -- every other shape, FPC_PRED_WS=0, a pinned split, and the training
+ *     step: one utterance on 1, 2, 4 or 8 workgroups (one CU each) while the batch leaves CUs idle (B x n <= number of
+ *     CUs), the slices of the recurrent state exchanged as tagged 8-byte words; weights streamed from L2 every frame.
+ *     Two-role kernels (three waves walk a frame's latency chain, the others stream the recurrent products; LDS counters
+ *     instead of workgroup barriers), or with FPC_PRED_DF=0 the phase-after-phase kernels (the tests' reference form); the
+ *     training step's forward follows the same switch.
+ * Common to (1) and (2):
+ *  - ASSUMPTION: the process owns the GPU.  Both forms count on every workgroup of a group being dispatched at once; a
+ *    co-tenant kernel that occupies CUs for longer than the bound below makes such a launch fail.  Shared-GPU
+ *    deployments pin one workgroup per utterance with fpc_predictor_set_split(p, 1) (or FPC_PRED_SPLIT=0).
+ *  - Placement is arranged for, checked, never assumed.  Blocks b and b + 8 are observed to land on one XCD (round-robin
+ *    dealing), so the workgroups of a group get block indices 8 apart; each reads its XCD id from the hardware register
+ *    (s_getreg_b32 HW_REG_XCC_ID), the ids go round once through the general path, and only if ALL agree the exchange uses
+ *    plain stores, which stay in that XCD's L2 where the partners' L1-bypassing (sc1) loads find them (measured:
+ *    tools/ubench/ub5.hip -- plain stores are seen by sc1 loads inside an XCD, never across XCDs).  Otherwise -- and always
+ *    with FPC_FAST_HOP=0, which the tests use to run this path on a one-XCD placement -- every exchanged value is written
+ *    through (sc1 stores).  A different dealing, or a wrong XCD id, therefore costs speed (1.35k against 2.0k cycles per
+ *    hop), never correctness: the general path assumes nothing about where a workgroup runs.
  *  - A spin that does not see its partner within 1 s of wall clock gives up, never hangs: the launch stores NaN (floats)
- *    and -2 (symbols) from that frame on, touches the histograms no further, the training step skips its Adam update,
+ *    and -2 (symbols) for the utterance (row split: from that frame on; weights-stationary: for the whole group from that
+ *    frame on), counts those frames in no histogram, the training step skips its Adam update,
  *    and the handle's sticky status word turns every later call on the handle -- and, at once, every call that
  *    synchronises anyway (fpc_decode_features, fpc_trainer_step with loss_host, fpc_trainer_export) -- into
  *    FPC_ERR_TIMEOUT with text in fpc_last_error(), until fpc_predictor_status() has reported and cleared it.
@@ -90,13 +117,10 @@ FPC_API void fpc_predictor_destroy(fpc_predictor* p);
  *    itself: a caller that consumes their outputs without another call on the handle asks fpc_predictor_status() first.
  *  - Launches of ONE handle may be issued on different streams: a call on another stream first waits (on the device)
  *    for the handle's previous launch.  Creating and destroying handles is thread-safe; calls on one handle are not.
- * Kernel form: fpc_predictor_forward, fpc_encode and fpc_decode_features run the two-role kernels (csrc/predictor_df.h:
- * three waves of a workgroup walk a frame's latency chain, the others stream the recurrent products; LDS counters
- * instead of workgroup barriers); FPC_PRED_DF=0 selects the phase-after-phase kernels, which give the same bits (the
- * tests' reference form); the training step's forward follows the same switch.
- * Environment: FPC_PRED_SPLIT=0 keeps one workgroup per utterance, 2|4|8 fixes the count (tests); FPC_PRED_DF=0 see
- * above; FPC_SPIN_LIMIT_US / FPC_TEST_WITHHOLD_PUBLISH are test hooks (a shorter bound; the last slice of utterance 0
- * never publishes). */
+ * Environment: FPC_PRED_WS=0 never the weights-stationary kernels; FPC_PRED_SPLIT=0 one workgroup per utterance, 2|4|8
+ * exactly that many (either selects the row-split kernels); FPC_PRED_DF=0 the phase kernels; FPC_FAST_HOP=0 the
+ * write-through exchange everywhere; FPC_SPIN_LIMIT_US / FPC_TEST_WITHHOLD_PUBLISH are test hooks (a shorter bound; the
+ * last workgroup of utterance 0 / group 0 never publishes). */
 
 /* Synchronises the device and returns what the launches on the handle have reported: FPC_OK, FPC_ERR_TIMEOUT (a
  * row-split exchange gave up) or FPC_ERR_NONFINITE (a NaN / infinite residual reached a quantizer in fpc_encode: those

@@ -884,6 +884,8 @@ def test_row_split_timeout_is_an_error_not_garbage(torch_cuda, synth, cb_paths, 
     monkeypatch.setenv("FPC_PRED_SPLIT", "2")
     if two_roles == "0":
         monkeypatch.setenv("FPC_PRED_DF", "0")
+    if two_roles == "general_hop":  # the two-role kernels on the write-through exchange
+        monkeypatch.setenv("FPC_FAST_HOP", "0")
     good = m.encoder(cfg, feat, None, 0.09, 0.28, qtz=True, return_indices=True)
     yg, _, _ = m.forward(feat)
     torch.cuda.synchronize()

@@ -30,6 +30,8 @@ def test_abi_exports_every_declared_symbol(built):
     for s in declared:
         assert hasattr(L, s), s
     assert L.fpc_abi_version() == 1
+    # the shipped library is built without -D tunables and says so (a variant build lists them: tools/build_variant.sh)
+    assert L.fpc_build_info() == b"fpcodec abi 1 gfx950"
 
 
 def test_no_cpu_fallback(built):
