@@ -44,10 +44,11 @@ class Codebooks:
         self.vq_hi = [np.ascontiguousarray(s, np.float64) for s in vq_hi]
         if vq_lo is not None and len(vq_lo) != 1:
             # the reference runs quantize_mstage over ALL stages of the below-threshold file (wavernn.py:235-240,
-            # only the histogram uses the last one); the kernel and the C ABI search one stage there, which is what
-            # the production file (1 x 512 x 17) has.  Refuse anything else instead of coding different symbols.
-            raise ValueError(f"below-threshold VQ codebook has {len(vq_lo)} stages; only 1-stage files are supported "
-                             "(INTEGRATION.md, limitations)")
+            # only the histogram uses the last one); the fused kernels and the C ABI search one stage there, which is
+            # what the production file (1 x 512 x 17) has.  Wavernn.encoder serves a multi-stage file through its host
+            # loop (vq_quantize per frame); this device-resident set refuses it instead of coding different symbols.
+            raise ValueError(f"below-threshold VQ codebook has {len(vq_lo)} stages; the fused encoder takes 1-stage "
+                             "files (Wavernn.encoder serves the others frame by frame)")
         self.vq_lo = np.ascontiguousarray(vq_lo[-1], np.float64) if vq_lo is not None else None
         self.scl_hi = np.ascontiguousarray(np.asarray(scl_hi, np.float64).reshape(-1))
         self.scl_lo = np.ascontiguousarray(np.asarray(scl_lo, np.float64).reshape(-1)) if scl_lo is not None else None

@@ -170,10 +170,12 @@ class Wavernn:
         """workgroups per utterance: 0 automatic (the process owns the GPU), 1 never split (shared GPU), 2 / 4 / 8"""
         _lib.check(_lib.lib().fpc_predictor_set_split(self._handle(), int(n)), "fpc_predictor_set_split")
 
-    def _encoder_injected(self, cfg, feat, l1, l2, vq_quantize, scl_quantize):
-        """`encoder(..., qtz=True)` with quantizer callables that are not this package's own: the reference's loop
-        (wavernn.py:192-242) frame by frame -- the predictor step on the device, thresholds and the injected
-        callables on the host with exactly the rows, paths and accumulation of wavernn.py:217-240."""
+    def _encoder_host_loop(self, cfg, feat, mask, l1, l2, vq_quantize, scl_quantize, qtz):
+        """The reference's loop (wavernn.py:192-252) frame by frame for the cases the fused kernels do not cover:
+        quantizer callables that are not this package's own (:165), the input-mask mode (:209-211, `mask` of shape
+        (B, L, 2, 1): `mask[:, i, 0]` must index like the thresholds' (B, 1) indicator), and a below-threshold VQ file
+        with more than one stage (:235-240).  The predictor step runs on the device, indicators and the callables on the
+        host with exactly the rows, paths and accumulation of wavernn.py:217-252."""
         dev = self.device
         B, L, Cc = feat.shape
         c_in = torch.zeros(B, L + 1, Cc, device=dev)
@@ -184,59 +186,75 @@ class Wavernn:
         ind1_mask = torch.zeros(B, L, 1, device=dev)
         ind2_mask = torch.zeros(B, L, 1, device=dev)
         cb_tot = [0, 0, 0, 0, 0]
+        if mask is not None:
+            mask = torch.as_tensor(mask).to(dev)
+            if mask.dim() == 3:  # (B, L, 2): the shape the docstring suggests; the reference's indexing needs a 4th axis
+                mask = mask.unsqueeze(-1)
         h1 = h2 = None
         for i in range(L):
             f_out, h1, h2 = self.forward(c_in[:, i:i + 1, :], h1, h2)
             f_out = f_out[:, -1, :]
             r_s = feat[:, i, :-2] - f_out
             r[:, i, :] = r_s
-            ind1 = (abs(r_s[:, 0]) > l1).to(int).unsqueeze(1)
-            ind1_mask[:, i, :] = ind1
-            ind2 = (torch.sum(abs(r_s[:, 1:]), -1) > l2).to(int).unsqueeze(1)
-            ind2_mask[:, i, :] = ind2
-            r_host = r_s.cpu().numpy()
-            i1, i2 = ind1.cpu().numpy(), ind2.cpu().numpy()
-            for k in range(B):
-                if i1[k, 0]:
-                    rq, cb_t = scl_quantize(r_host[k:k + 1, 0:1], cfg['scl_cb_path'])
-                    r_qtz[k:k + 1, i, 0:1] = torch.as_tensor(np.asarray(rq), dtype=torch.float32).to(dev)
-                    cb_tot[0] = cb_tot[0] + cb_t
-                elif cfg.get('bl_scl_cb_path'):
-                    rq, cb_t = scl_quantize(r_host[k:k + 1, 0:1], cfg['bl_scl_cb_path'])
-                    r_qtz[k:k + 1, i, 0:1] = torch.as_tensor(np.asarray(rq), dtype=torch.float32).to(dev)
-                    cb_tot[1] = cb_tot[1] + cb_t
-            for k in range(B):
-                if i2[k, 0]:
-                    rq, cb_t = vq_quantize(r_host[k:k + 1, 1:], cfg['cb_path'])
-                    r_qtz[k:k + 1, i, 1:] = torch.as_tensor(np.asarray(rq), dtype=torch.float32).to(dev)
-                    cb_tot[2] = cb_tot[2] + cb_t[0]
-                    cb_tot[3] = cb_tot[3] + cb_t[1]
-                elif cfg.get('bl_cb_path'):
-                    rq, cb_t = vq_quantize(r_host[k:k + 1, 1:], cfg['bl_cb_path'])
-                    r_qtz[k:k + 1, i, 1:] = torch.as_tensor(np.asarray(rq), dtype=torch.float32).to(dev)
-                    cb_tot[4] = cb_tot[4] + cb_t[-1]
-            c_in[:, i + 1, :-2] = f_out + r_qtz[:, i, :]
+            if mask is None:  # thresholds (:201-207)
+                ind1 = (abs(r_s[:, 0]) > l1).to(int).unsqueeze(1)
+                ind1_mask[:, i, :] = ind1
+                ind2 = (torch.sum(abs(r_s[:, 1:]), -1) > l2).to(int).unsqueeze(1)
+                ind2_mask[:, i, :] = ind2
+            else:  # the input mask (:209-211; the indicator outputs stay zero there)
+                ind1 = mask[:, i, 0]
+                ind2 = mask[:, i, 1]
+            if qtz:
+                r_host = r_s.cpu().numpy()
+                i1, i2 = ind1.cpu().numpy(), ind2.cpu().numpy()
+                for k in range(B):
+                    if i1[k, 0]:
+                        rq, cb_t = scl_quantize(r_host[k:k + 1, 0:1], cfg['scl_cb_path'])
+                        r_qtz[k:k + 1, i, 0:1] = torch.as_tensor(np.asarray(rq), dtype=torch.float32).to(dev)
+                        cb_tot[0] = cb_tot[0] + cb_t
+                    elif cfg.get('bl_scl_cb_path'):
+                        rq, cb_t = scl_quantize(r_host[k:k + 1, 0:1], cfg['bl_scl_cb_path'])
+                        r_qtz[k:k + 1, i, 0:1] = torch.as_tensor(np.asarray(rq), dtype=torch.float32).to(dev)
+                        cb_tot[1] = cb_tot[1] + cb_t
+                for k in range(B):
+                    if i2[k, 0]:
+                        rq, cb_t = vq_quantize(r_host[k:k + 1, 1:], cfg['cb_path'])
+                        r_qtz[k:k + 1, i, 1:] = torch.as_tensor(np.asarray(rq), dtype=torch.float32).to(dev)
+                        cb_tot[2] = cb_tot[2] + cb_t[0]
+                        cb_tot[3] = cb_tot[3] + cb_t[1]
+                    elif cfg.get('bl_cb_path'):
+                        rq, cb_t = vq_quantize(r_host[k:k + 1, 1:], cfg['bl_cb_path'])
+                        r_qtz[k:k + 1, i, 1:] = torch.as_tensor(np.asarray(rq), dtype=torch.float32).to(dev)
+                        cb_tot[4] = cb_tot[4] + cb_t[-1]
+                c_in[:, i + 1, :-2] = f_out + r_qtz[:, i, :]
+            else:  # (:244-252)
+                r_under[:, i, 0:1] = r_s[:, 0:1] * (1 - ind1)
+                r_under[:, i, 1:] = r_s[:, 1:] * (1 - ind2)
+                r[:, i, 0:1] = r_s[:, 0:1] * ind1
+                r[:, i, 1:] = r_s[:, 1:] * ind2
+                c_in[:, i + 1, :-2] = f_out + r[:, i, :]
         self.check()
         return c_in[:, 1:, :], r, r_qtz, r_under, ind1_mask, ind2_mask, cb_tot
 
     # ---- Wavernn.encoder (wavernn.py:165-256) ----
     def encoder(self, cfg, feat, mask, l1, l2, vq_quantize=None, scl_quantize=None, qtz=True,
                 return_indices=False):
-        if mask is not None:
-            raise NotImplementedError("only the threshold mode (mask=None) is live in the reference")
         from . import vq_func as _vq
         own = (vq_quantize is None or vq_quantize is _vq.vq_quantize) and \
             (scl_quantize is None or scl_quantize is _vq.scl_quantize)
-        if qtz and not own:
-            # injected quantizers (wavernn.py:165: the reference calls whatever it is handed): honoured, frame by frame
+        # the fused kernels code the below-threshold residual with ONE stage (the production file, 1 x 512 x 17); a file with
+        # more stages takes the reference's own route: quantize_mstage over all of them (wavernn.py:235-240)
+        lo_stages = len(_vq.read_vq_file(cfg["bl_cb_path"])) if (qtz and cfg.get("bl_cb_path")) else 1
+        if mask is not None or (qtz and not own) or lo_stages > 1:
+            # served frame by frame (wavernn.py:165: the reference calls whatever it is handed; :209-211 the mask mode)
             if return_indices:
-                raise _lib.FpcError("Wavernn.encoder: return_indices needs the built-in quantizers (an injected "
-                                    "callable returns quantized values, not codebook symbols)")
-            if vq_quantize is None or scl_quantize is None:
+                raise _lib.FpcError("Wavernn.encoder: return_indices needs the fused path (thresholds, the built-in "
+                                    "quantizers, a 1-stage below-threshold book)")
+            if qtz and not own and (vq_quantize is None or scl_quantize is None):
                 raise _lib.FpcError("Wavernn.encoder: pass both vq_quantize and scl_quantize or neither "
                                     "(wavernn.py:219,230 call both)")
-            return self._encoder_injected(cfg, feat.to(self.device, torch.float32).contiguous(), l1, l2,
-                                          vq_quantize, scl_quantize)
+            return self._encoder_host_loop(cfg, feat.to(self.device, torch.float32).contiguous(), mask, l1, l2,
+                                           vq_quantize or _vq.vq_quantize, scl_quantize or _vq.scl_quantize, qtz)
         h = self._handle()
         feat = feat.to(self.device, torch.float32).contiguous()
         B, L, Cc = feat.shape

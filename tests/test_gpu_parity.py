@@ -1200,3 +1200,35 @@ def test_weights_stationary_timeout_is_an_error_not_garbage(torch_cuda, synth, c
         assert torch.equal(a, b)
     for a, b in zip(good[6], again[6]):
         assert np.array_equal(a, b)
+
+
+def test_encoder_mask_mode_and_multi_stage_lo_vs_reference_golden(torch_cuda, model, cb_paths, tmp_path):
+    """the two reference behaviours the fused kernels do not cover, served by the host loop of Wavernn.encoder (predictor step
+    and searches on the device, one frame at a time) against golden G12, generated by tests/golden/make_golden_modes.py from
+    the reference's own `encoder`: the input-mask mode (wavernn.py:209-211) with and without quantisation, and a 2-stage
+    below-threshold codebook (wavernn.py:235-240: quantize_mstage over both stages, cb_tot[4] += the last stage's histogram)"""
+    torch = torch_cuda
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "g12_encoder_modes.npz"))
+    import fpcodec_amd
+    synth = fpcodec_amd.synth
+    feat = synth.predictor_features(3, 30, utt0=40)
+    mask = (np.random.default_rng(1098).random((3, 30, 2, 1)) < 0.4).astype(np.float32)
+    rng = np.random.default_rng(1099)
+    lo2 = np.stack([rng.normal(0, 0.02, (512, 17)), rng.normal(0, 0.01, (512, 17))])
+    p_lo2 = os.path.join(str(tmp_path), "vq_lo2.npy")
+    np.save(p_lo2, lo2)
+    cfg = dict(scl_cb_path=cb_paths["scl_hi"], cb_path=cb_paths["vq_hi"], bl_scl_cb_path=cb_paths["scl_lo"],
+               bl_cb_path=cb_paths["vq_lo"])
+    runs = {"mask_qtz": (cfg, mask, True), "mask_raw": (cfg, mask, False), "lo2": (dict(cfg, bl_cb_path=p_lo2), None, True)}
+    for tag, (c, m, qtz) in runs.items():
+        out = model.encoder(c, torch.from_numpy(feat), None if m is None else torch.from_numpy(m), 0.09, 0.28, qtz=qtz)
+        for n, v in zip(["c_in", "r", "r_qtz", "r_under"], out[:4]):
+            assert np.abs(v.cpu().numpy() - g[f"{tag}_{n}"]).max() <= 1e-5, (tag, n)  # the north_star's tolerance
+        for n, v in zip(["ind1", "ind2"], out[4:6]):
+            assert np.array_equal(v.cpu().numpy(), g[f"{tag}_{n}"]), (tag, n)
+        for i, h in enumerate(out[6]):
+            assert np.array_equal(np.asarray(h, dtype=np.float64), g[f"{tag}_hist{i}"]), (tag, i)  # symbols: exact
+    # the mask mode leaves the indicator outputs at zero (the reference only fills them from the thresholds)
+    assert not g["mask_qtz_ind1"].any() and g["lo2_ind1"].any()
