@@ -97,7 +97,7 @@ __device__ __forceinline__ void publish_slice(const float* h, int H, SplitCtx& X
 __device__ __forceinline__ float await_granule(unsigned long long* g, unsigned epoch, SplitCtx& X, bool& gave_up) {
     unsigned long long x = 0x7fc00000ull;  // NaN unless the partner's value arrives: poisons everything downstream
     unsigned spins = 0;
-    unsigned long long t0 = 0;
+    unsigned long long t0 = 0, last = 0;
     while (!X.dead) {
         const unsigned long long v = __hip_atomic_load((gu64*)g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if ((unsigned)(v >> 32) == epoch) {
@@ -109,7 +109,10 @@ __device__ __forceinline__ float await_granule(unsigned long long* g, unsigned e
         // and loudly, never hang the GPU
         if ((++spins & 63u) == 0) {
             const unsigned long long now = __builtin_amdgcn_s_memrealtime();
-            if (t0 == 0) t0 = now;
+            // (two time reads are ~10-100 us apart while the wave runs; a much larger gap means the wave itself was
+            //  descheduled -- queue preemption, a debugger -- and says nothing about the partner: the clock starts again)
+            if (t0 == 0 || now - last > X.limit / 4) t0 = now;
+            last = now;
             if (now - t0 > X.limit || (status_load(X.err) & FPC_ST_TIMEOUT) != 0u) {
                 status_or(X.err, FPC_ST_TIMEOUT);
                 gave_up = true;
@@ -228,97 +231,51 @@ __device__ __forceinline__ float chain1(const float* __restrict__ wT, const floa
 // register is refilled with k + CD as soon as k has been used, so CD - 1 loads stay in flight for the whole chain
 // (a block that loads CD, waits for all and then computes pays one L2 round trip per block: 6 per 96-long chain,
 // measured 1 400-1 750 cycles each, and the CU's L2 port idles meanwhile).  Same k order: same bits.
+// Round 4: PLAIN loads, which the compiler counts itself, and scheduling group barriers that ask for the interleaving
+// (the fmaf's of the oldest window register, then its refill).  Rounds 2-3 wrote the loads and their waits as inline
+// assembly (global_load_dwordx4 + s_waitcnt vmcnt(N) tied to the register): faster at 576 threads, but the compiler
+// does not count such loads, and a window register that it copied between its load and its wait gave wrong results
+// when the surrounding code changed shape (profiles/r03_predictor_two_roles.txt).  The kernels that still used that
+// form -- the phase kernels (the tests' reference form) and the training step -- are correct by construction now.
 constexpr int CD = FPC_CD;  // k-steps of 16-byte loads in flight per thread (multiple of 4)
-// (the loads and their waits are written out: left to itself the scheduler gathers the window's loads behind one
-//  full wait again.  The compiler does not count these loads, so every use of a window register goes through
-//  landed<N>(): s_waitcnt vmcnt(N) with the register as an operand, N = the loads issued after the one awaited;
-//  loads return in order, and the compiler's own waits can only be stricter than it thinks.)
-typedef float v4f __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ v4f ld4(const float* q) {
-    v4f r;
-    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(r) : "v"(q));
-    return r;
-}
-// the same load, placed after the fmaf's that produced a (instruction selection is otherwise free to sink the
-// arithmetic below later loads and to keep a second set of window registers alive for it)
-__device__ __forceinline__ v4f ld4_after(const float* q, const float4& a) {
-    v4f r;
-    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(r) : "v"(q), "v"(a.x), "v"(a.y), "v"(a.z), "v"(a.w));
-    return r;
-}
-template <int N>
-__device__ __forceinline__ void landed(v4f& w) {
-    asm volatile("s_waitcnt vmcnt(%1)" : "+v"(w) : "n"(N));
-}
-__device__ __forceinline__ void fma4(float4& a, float hv, const v4f& w) {
+__device__ __forceinline__ void fma4(float4& a, float hv, const float4& w) {
     a.x = fmaf(hv, w.x, a.x);
     a.y = fmaf(hv, w.y, a.y);
     a.z = fmaf(hv, w.z, a.z);
     a.w = fmaf(hv, w.w, a.w);
 }
-constexpr int CT = 4;  // tail loads that go out before the last window is consumed (K = 20: 16 + 4)
-template <int J = 0>
-__device__ __forceinline__ void last_window(float4& a, const float (&hv)[CD], v4f (&w)[CD]) {
-    if constexpr (J < CD) {
-        landed<CD - 1 - J>(w[J]);  // (tail loads behind it only make the wait stricter)
-        fma4(a, hv[J], w[J]);
-        last_window<J + 1>(a, hv, w);
-    }
-}
-// a: the chain's start value, possibly still in flight (ld4 of the bias issued by the caller just before)
-__device__ __forceinline__ void chain4(const float* __restrict__ wT, const float* v, int K, int R, int r, v4f& a0,
-                                       float4& a) {
+// a: the chain's start value (bias or 0) on entry, the chain's sum on exit
+__device__ __forceinline__ void chain4(const float* __restrict__ wT, const float* v, int K, int R, int r, float4& a) {
     const float* q = wT + r;  // ONE running address, advanced by a row per load (the loads go out in k order)
-    const int nb = K / CD;
-    int rem = K - nb * CD;  // full windows, tail
-    v4f w[CD], wt[CT];
+    const int nb = K / CD, rem = K - nb * CD;
+    float4 w[CD];
     float hv[CD];
     if (nb > 0) {
 #pragma unroll
-        for (int j = 0; j < CD; ++j, q += R) w[j] = ld4(q);
+        for (int j = 0; j < CD; ++j, q += R) w[j] = *reinterpret_cast<const float4*>(q);
     }
-    if (nb > 0)
-        landed<CD - 1>(a0);  // (in order: the start value has landed when all but the youngest CD - 1 loads have)
-    else
-        landed<0>(a0);
-    a = make_float4(a0.x, a0.y, a0.z, a0.w);
     for (int b = 0; b + 1 < nb; ++b, v += CD) {
 #pragma unroll
         for (int j = 0; j < CD; ++j) hv[j] = v[j];
 #pragma unroll
         for (int j = 0; j < CD; ++j, q += R) {
-            landed<CD - 1>(w[j]);
             fma4(a, hv[j], w[j]);
-            w[j] = ld4_after(q, a);
+            w[j] = *reinterpret_cast<const float4*>(q);
+        }
+#pragma unroll
+        for (int j = 0; j < CD; ++j) {
+            __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);  // the step's arithmetic (4 fmaf + the address)
+            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);  // one load
         }
     }
-    const int t0 = rem < CT ? rem : CT;
-#pragma unroll
-    for (int j = 0; j < CT; ++j)
-        if (j < t0) wt[j] = ld4(q + (size_t)j * R);
-    q += (size_t)t0 * R;
     if (nb > 0) {
 #pragma unroll
         for (int j = 0; j < CD; ++j) hv[j] = v[j];
-        last_window(a, hv, w);
+#pragma unroll
+        for (int j = 0; j < CD; ++j) fma4(a, hv[j], w[j]);
         v += CD;
     }
-    while (rem > 0) {  // (more than CT left over: one round trip per further CT -- no shipped size has that)
-#pragma unroll
-        for (int j = 0; j < CT; ++j)
-            if (j < rem) {
-                landed<0>(wt[j]);
-                fma4(a, v[j], wt[j]);
-            }
-        rem -= CT;
-        v += CT;
-        if (rem > 0) {
-#pragma unroll
-            for (int j = 0; j < CT; ++j)
-                if (j < rem) wt[j] = ld4(q + (size_t)j * R);
-            q += (size_t)CT * R;
-        }
-    }
+    for (int k = 0; k < rem; ++k, q += R) fma4(a, v[k], *reinterpret_cast<const float4*>(q));
 }
 
 // Rows are evaluated in S contiguous segments of the input, one thread per (4 adjacent rows, segment): segment 0
@@ -351,10 +308,9 @@ __device__ __forceinline__ void gru_rows(const float* __restrict__ wiT, const fl
         const int q = j % Q, sg = j / Q;  // consecutive threads -> adjacent row quads: coalesced 16-byte loads
         const int gate = q / Qg, qq = q - gate * Qg;
         const int len = (is_h ? H : K) / (is_h ? Sh : Si), k0 = sg * len, r = gate * H + 4 * (half * Qg + qq);
-        v4f a0 = {0.f, 0.f, 0.f, 0.f};
-        if (sg == 0) a0 = ld4(&(is_h ? bh : bi)[r]);
-        float4 a;
-        chain4((is_h ? whT : wiT) + (size_t)k0 * R, (is_h ? h : x) + k0, len, R, r, a0, a);
+        float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (sg == 0) a = *reinterpret_cast<const float4*>(&(is_h ? bh : bi)[r]);
+        chain4((is_h ? whT : wiT) + (size_t)k0 * R, (is_h ? h : x) + k0, len, R, r, a);
         *reinterpret_cast<float4*>(&(is_h ? L.ph : L.pi)[sg][r]) = a;
     }
     __syncthreads();
@@ -1392,9 +1348,8 @@ __device__ __forceinline__ void tprod_items(const float* __restrict__ W, const f
     // (row split: this workgroup's slice of the output columns k; every chain is the one of the unsplit form)
     const int Qs = cols / 4 / nsplit, S = segments(rows), len = rows / S;
     const int q = half * Qs + item % Qs, sg = item / Qs;
-    v4f a0 = {0.f, 0.f, 0.f, 0.f};
-    float4 a;
-    chain4(W + (size_t)sg * len * cols, d + sg * len, len, cols, 4 * q, a0, a);
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+    chain4(W + (size_t)sg * len * cols, d + sg * len, len, cols, 4 * q, a);
     *reinterpret_cast<float4*>(&part[sg][4 * q]) = a;
 }
 __device__ __forceinline__ float tree4(const float (*p)[MAX_H1], int S, int k) {
@@ -1601,7 +1556,13 @@ __global__ void k_colsum(const GradJobs J, int N) {
 // torch.optim.Adam, single-tensor path (betas 0.9 / 0.999, eps 1e-8, no weight decay)
 // the handle's status word lives in host memory (one PCIe round trip per reader): one thread copies it into device memory
 // once per step, and the ten Adam launches read the copy
-__global__ void k_latch_status(const unsigned* status, unsigned* latch) { *latch = status_load(status); }
+// latch[0] = the status word, latch[1] = the number of steps whose update was applied (the host's step counter, and with it
+// Adam's bias corrections, follows this count after a failed step: fpc_trainer_step)
+__global__ void k_latch_status(const unsigned* status, unsigned* latch) {
+    const unsigned st = status_load(status);
+    latch[0] = st;
+    if (st == 0u) latch[1] += 1u;
+}
 __global__ void k_adam(float* __restrict__ p, float* __restrict__ m, float* __restrict__ v, const float* __restrict__ g,
                        size_t n, float step_size, float bc2_sqrt, const unsigned* __restrict__ latch) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1671,6 +1632,8 @@ struct fpc_predictor {
     bool launched = false;
     int forced_split = 0;  // fpc_predictor_set_split: 0 automatic, 1 off, 2/4/8 exactly that many workgroups per utterance
     int num_cus = 0;
+    int occ_df = 1, occ_phase = 1;  // workgroups of the two-role / phase kernels that one CU holds (LDS-bound: 1 / 2-3)
+    int fail_epoch = 0;    // failures reported and cleared by fpc_predictor_status so far (a trainer re-reads its step count)
     std::atomic<int> refs{1};  // the creator's handle + one per live fpc_trainer built on it (fpc_predictor_destroy only drops a reference)
     ~fpc_predictor() {
         if (last_ev) (void)hipEventDestroy(last_ev);
@@ -1707,6 +1670,7 @@ static int after_launch(fpc_predictor* p, hipStream_t st) {
 // Row split (2, 4 or 8 workgroups per utterance) while the batch leaves CUs idle; fpc_predictor_set_split or
 // FPC_PRED_SPLIT=0/1/2/4/8 force it off / to a count (tests run every form).  Prepares the zeroed granule block on the
 // stream.  The automatic choice assumes that this process owns the GPU (every workgroup of a group must be resident).
+static bool two_roles();
 static int split_args(fpc_predictor* p, int B, hipStream_t st, SplitArgs* out) {
     out->n = 1;
     out->g = nullptr;
@@ -1726,10 +1690,14 @@ static int split_args(fpc_predictor* p, int B, hipStream_t st, SplitArgs* out) {
         if (p->d.h1 % (4 * c) == 0 && p->d.h2 % (4 * c) == 0 && c * B <= p->num_cus) n = c;
     int f = p->forced_split;
     if (env && env[0] >= '0' && env[0] <= '8') f = env[0] == '0' ? 1 : env[0] - '0';
+    // (forced: every workgroup of the launch must be resident at once -- a group that straddles the residency boundary would
+    //  spin for workgroups that are not dispatched yet -- so the bound is what the chosen kernel form's LDS lets a CU hold:
+    //  one workgroup of the two-role kernels (~140 kB), two or three of the phase kernels)
+    const int occ = two_roles() ? p->occ_df : p->occ_phase;
     if (f == 1)
         n = 1;
-    else if ((f == 2 || f == 4 || f == 8) && p->d.h1 % (4 * f) == 0 && p->d.h2 % (4 * f) == 0 && f * B <= 2 * p->num_cus)
-        n = f;  // (forced: at most two workgroups per CU, still all resident)
+    else if ((f == 2 || f == 4 || f == 8) && p->d.h1 % (4 * f) == 0 && p->d.h2 % (4 * f) == 0 && f * B <= occ * p->num_cus)
+        n = f;
     {
         const int rc = before_launch(p, st);
         if (rc != FPC_OK) return rc;
@@ -1893,6 +1861,9 @@ extern "C" int fpc_predictor_create(const fpc_predictor_weights* w, fpc_predicto
         int dev = 0;
         FPC_HIP(hipGetDevice(&dev));
         FPC_HIP(hipDeviceGetAttribute(&p->num_cus, hipDeviceAttributeMultiprocessorCount, dev));
+        int o = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&o, k_encode_df, NT, 0) == hipSuccess && o > 0) p->occ_df = o;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&o, k_encode, NT, 0) == hipSuccess && o > 0) p->occ_phase = o;
     }
     *out = own.release();
     return FPC_OK;
@@ -1948,6 +1919,7 @@ extern "C" int fpc_predictor_status(fpc_predictor* p) {
     FPC_HIP(hipDeviceSynchronize());  // everything launched on the handle so far has reported
     const int rc = status_error(p, "fpc_predictor_status");
     *(volatile unsigned*)p->status_host = 0u;
+    if (rc != FPC_OK) p->fail_epoch += 1;
     return rc;
 }
 
@@ -2132,7 +2104,8 @@ struct fpc_trainer {
     fpc_predictor* p = nullptr;
     int maxB = 0, maxL = 0, step = 0;
     fpc::DevBuf ws, grad[10], m[10], v[10], lossb, wt[3], gpart[5];  // wt: torch-layout copies of w2i, w2h, w1h
-    fpc::DevBuf latch;  // device copy of the handle's status word, refreshed once per step (k_latch_status)
+    fpc::DevBuf latch;  // device copy of the handle's status word, refreshed once per step, + the count of applied updates
+    int seen_fail_epoch = 0;  // the handle's failure count when the step counter was last known to match the applied updates
     TrainBufs T;
     size_t sz[10];
 };
@@ -2166,7 +2139,9 @@ extern "C" int fpc_trainer_create(fpc_predictor* p, int max_B, int max_L, fpc_tr
     const size_t per = (size_t)6 * H1 + 7 * H2 + 2 * F + 6 * H1 + 6 * H2;
     FPC_HIP(t->ws.alloc(N * per * 4));
     FPC_HIP(t->lossb.alloc(sizeof(double) * (size_t)max_B));
-    FPC_HIP(t->latch.alloc(sizeof(unsigned)));
+    FPC_HIP(t->latch.alloc(2 * sizeof(unsigned)));
+    FPC_HIP(hipMemset(t->latch.p, 0, 2 * sizeof(unsigned)));
+    t->seen_fail_epoch = p->fail_epoch;
     {
         const int wi[5] = {0, 1, 4, 5, 8};
         for (int j = 0; j < 5; ++j) FPC_HIP(t->gpart[j].alloc(sz[wi[j]] * 4 * GSEG));
@@ -2207,6 +2182,14 @@ extern "C" int fpc_trainer_step(fpc_trainer* t, const float* feat_dev, int B, in
     hipStream_t st = static_cast<hipStream_t>(s);
     fpc_predictor* p = t->p;
     if (const int se = status_error(p, "fpc_trainer_step")) return se;  // an earlier launch on the handle failed
+    if (p->fail_epoch != t->seen_fail_epoch && t->step >= 0) {
+        // a failure has been reported and cleared since the last step: steps launched while the status word was set skipped
+        // their update (k_adam), so the step count -- Adam's bias corrections -- continues from the updates actually applied
+        unsigned applied = 0;
+        FPC_HIP(hipMemcpy(&applied, t->latch.as<unsigned>() + 1, sizeof applied, hipMemcpyDeviceToHost));  // (synchronises)
+        t->step = (int)applied;
+        t->seen_fail_epoch = p->fail_epoch;
+    }
     const PredDev& P = p->d;
     const int in = P.in, H1 = P.h1, H2 = P.h2, F = P.fc;
     const int N = B * L;

@@ -182,7 +182,7 @@ __device__ __forceinline__ void ws_store(const WsCtx& X, int granule, unsigned e
 template <int N>
 __device__ __forceinline__ bool ws_poll(const WsCtx& X, WsLds& L, const int (&gi)[N], unsigned epoch, u32x4 (&v)[N]) {
     unsigned spins = 0;
-    unsigned long long t0 = 0;
+    unsigned long long t0 = 0, last = 0;
     for (;;) {
         bool ok = true;
 #pragma unroll
@@ -193,7 +193,8 @@ __device__ __forceinline__ bool ws_poll(const WsCtx& X, WsLds& L, const int (&gi
         if (ws_dead(L)) return false;
         if ((++spins & 63u) == 0) {
             const unsigned long long now = __builtin_amdgcn_s_memrealtime();
-            if (t0 == 0) t0 = now;
+            if (t0 == 0 || now - last > X.limit / 4) t0 = now;  // (a gap that long: this wave was descheduled, await_granule)
+            last = now;
             if (now - t0 > X.limit || (status_load(X.err) & FPC_ST_TIMEOUT) != 0u) {
                 ws_give_up(X, L);
                 return false;

@@ -154,11 +154,21 @@ class Wavernn:
         s2 = torch.zeros(B, self.gru_units2, device=self.device) if h2 is None else \
             h2.to(self.device, torch.float32).reshape(B, self.gru_units2).clone()
         y = torch.empty(B, L, self.fc_units, device=self.device)
-        _lib.check(_lib.lib().fpc_predictor_forward(h, x.data_ptr(), B, L, s1.data_ptr(), s2.data_ptr(),
-                                                    y.data_ptr(), _lib.stream_ptr()), "fpc_predictor_forward")
+        self._pcheck(_lib.lib().fpc_predictor_forward(h, x.data_ptr(), B, L, s1.data_ptr(), s2.data_ptr(),
+                                                      y.data_ptr(), _lib.stream_ptr()), "fpc_predictor_forward")
         return y, s1.unsqueeze(0), s2.unsqueeze(0)
 
     __call__ = forward
+
+    def _pcheck(self, rc, what):
+        """_lib.check for calls on this model's handle: a sticky failure (a timed-out exchange, a non-finite residual) is
+        reported ONCE -- the status word is cleared as the exception is raised (fpc_predictor_status), so the next call
+        on the model is accepted again instead of raising until someone remembers check()"""
+        if rc in (-5, -6) and self._h is not None:
+            msg = _lib.lib().fpc_last_error().decode()
+            _lib.lib().fpc_predictor_status(self._h)
+            raise _lib.FpcError(f"{what} failed ({rc}): {msg}")
+        _lib.check(rc, what)
 
     def check(self):
         """synchronise and raise FpcError if a launch on this model's handle failed (a row-split exchange that
@@ -272,7 +282,7 @@ class Wavernn:
             cb = load_codebooks(cfg["cb_path"], cfg["scl_cb_path"], cfg.get("bl_cb_path") or None,
                                 cfg.get("bl_scl_cb_path") or None)
             hist = torch.zeros(cb.hist_size, device=dev, dtype=torch.int64)
-        _lib.check(_lib.lib().fpc_encode(
+        self._pcheck(_lib.lib().fpc_encode(
             h, cb.handle if cb else None, feat.data_ptr(), B, L, float(l1), float(l2), int(bool(qtz)),
             c_in.data_ptr(), r.data_ptr(), r_qtz.data_ptr(), r_under.data_ptr(), ind1.data_ptr(),
             ind2.data_ptr(), idx.data_ptr(), hist.data_ptr() if hist is not None else None,
@@ -297,6 +307,6 @@ class Wavernn:
         cb = load_codebooks(cfg["cb_path"], cfg["scl_cb_path"], cfg.get("bl_cb_path") or None,
                             cfg.get("bl_scl_cb_path") or None)
         c_out = torch.empty(B, L, 20, device=dev)
-        _lib.check(_lib.lib().fpc_decode_features(h, cb.handle, pitch.data_ptr(), idx.data_ptr(), B, L,
-                                                  c_out.data_ptr(), _lib.stream_ptr()), "fpc_decode_features")
+        self._pcheck(_lib.lib().fpc_decode_features(h, cb.handle, pitch.data_ptr(), idx.data_ptr(), B, L,
+                                                    c_out.data_ptr(), _lib.stream_ptr()), "fpc_decode_features")
         return c_out

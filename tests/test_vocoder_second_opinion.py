@@ -115,10 +115,11 @@ def test_long_trace_all_kernel_variant_weight_sets(oracle, synth):
         assert r["condition_max_abs_err"] < 2e-5
 
 
-def test_three_second_trace_all_kernel_variant_weight_sets(oracle, synth):
+def test_three_second_trace_all_kernel_variant_weight_sets(oracle, synth, tmp_path):
     """the 3-second version (300 frames, 47 983 draws per weight set, half of the frames voiced; ~1 min of CPU in all) as
-    a test, not a hand-kept record: the same bounds, and the file the docs quote (profiles/second_opinion_long.txt) is
-    rewritten from this run's numbers"""
+    a test, not a hand-kept record: the same bounds, and the file the docs quote (profiles/second_opinion_long.txt) must
+    equal what this run writes (to tmp_path: the test never touches the tracked file; tools/second_opinion_long.py
+    regenerates it)"""
     import importlib.util
     import os
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -133,4 +134,6 @@ def test_three_second_trace_all_kernel_variant_weight_sets(oracle, synth):
         assert r["differ"] <= max(1, int(1e-4 * r["samples"])), r
         assert all(mg < 1e-5 for mg in r["margins_of_differing_draws"]), r
         assert r["condition_max_abs_err"] < 2e-5
-    m.write_record(rows)
+    out = os.path.join(str(tmp_path), "second_opinion_long.txt")
+    m.write_record(rows, out)
+    assert open(out).read() == open(m.RECORD).read(), "profiles/second_opinion_long.txt is stale: python tools/second_opinion_long.py"
