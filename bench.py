@@ -34,6 +34,9 @@ HBM_BYTES_PER_SAMPLE = 2.9      # 2 B PCM out + 144 B features / 160 samples
 PEAK_F32_TFLOPS = 157.3         # MI355X_MICROARCH.md: FP32 vector peak (== f32 MFMA dense peak)
 PEAK_HBM_GBS = 8000.0
 E2E_PER_GPU = 128               # BASELINE config 5: 1024 utterances on 8 GPUs
+PRED_FLOP_PER_FRAME = 1328640.0  # 2 x 664 320 MAC per frame and utterance (GRU 20->384, 384->128, FC 128->18)
+VQ2_FLOP = 6 * 1024 * 17 * 3.0   # 2-stage search: 1 + 5 scans of 1 024 entries, (sub, mul, add) per coordinate
+VQ1_FLOP = 512 * 17 * 3.0        # below the threshold: one scan of 512 entries
 
 
 def _host_threads():
@@ -199,6 +202,21 @@ def e2e_config5(voc, torch, synth, parallel, rank, world, L=300):
     torch.cuda.synchronize()
     t4 = time.perf_counter()
     assert torch.equal(rec, enc[0]), "decoder output differs from the encoder's reconstruction"
+    # ---- the predictor kernels against THEIR roofline (f32 MFMA for the batched GRU rows): HIP events on the
+    # launch stream around one fpc_encode / one fpc_predictor_forward call of this share (weights-stationary kernels)
+    def ev_ms(fn):
+        fn()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        fn()
+        b.record()
+        b.synchronize()
+        return a.elapsed_time(b)
+    x20 = nm_d[:, :, :20].contiguous()
+    enc_ms = ev_ms(lambda: model.encoder(cfg, x20, None, cfg["l1"], cfg["l2"], qtz=True, return_indices=True))
+    fwd_ms = ev_ms(lambda: model.forward(x20))
+    coded = float(i2.sum())  # frames whose residual took the 2-stage search (the others: one stage of 512)
+    enc_flop = B * L * PRED_FLOP_PER_FRAME + coded * VQ2_FLOP + (B * L - coded) * VQ1_FLOP
     sizes = load_codebooks(cfg["cb_path"], cfg["scl_cb_path"], cfg["bl_cb_path"], cfg["bl_scl_cb_path"]).sizes
     # ---- the cross-rank record: max elapsed, total samples, summed histograms (+ flag and frame counts) ----
     flat = np.concatenate([np.asarray(h, np.float64).ravel() for h in cb_tot] +
@@ -215,7 +233,19 @@ def e2e_config5(voc, torch, synth, parallel, rank, world, L=300):
            "encode_ms": (t1 - t0) * 1e3, "decode_ms": (t2 - t1) * 1e3,
            "rtf_aggregate": rep["samples"] / rep["elapsed_s"] / 16000.0, "keep_rates": keep,
            "entropy_bits_per_symbol": ent, "bits_per_frame": bits_frame, "bitrate_bps": bits_frame * 100.0,
-           "decode_features_ms": (t4 - t3) * 1e3}
+           "decode_features_ms": (t4 - t3) * 1e3,
+           "predictor_roofline": {
+               "bound": "mfma", "unit": "TFLOP/s", "peak": PEAK_F32_TFLOPS, "kernel": "k_encode_ws",
+               "kernel_ms": enc_ms, "achieved": enc_flop / (enc_ms * 1e-3) / 1e12,
+               "frac": enc_flop / (enc_ms * 1e-3) / 1e12 / PEAK_F32_TFLOPS,
+               "forward_kernel": "k_forward_ws", "forward_ms": fwd_ms,
+               "forward_achieved": B * L * PRED_FLOP_PER_FRAME / (fwd_ms * 1e-3) / 1e12,
+               "forward_frac": B * L * PRED_FLOP_PER_FRAME / (fwd_ms * 1e-3) / 1e12 / PEAK_F32_TFLOPS,
+               "algorithmic_flop": enc_flop,
+               "note": "SURVEY 8(d): 1 328 640 FLOP per frame and utterance for the GRU rows and the output layer + the float64 "
+                       "searches (2 x 51 flop per entry and target: 1 + 5 scans of 1 024 entries above the threshold, one of 512 "
+                       "below it), against the dense f32 MFMA peak; HIP events on the launch stream around one call "
+                       "(memset + kernel + histogram kernel)"}}
     if rank == 0:  # framing figures on rank 0's share (the arithmetic coder is plain Python: a sample of it)
         idx_h = idx.cpu().numpy()
         fixed_bits = bitstream.bits_per_frame(idx_h, sizes)
