@@ -50,7 +50,7 @@ constexpr int WOFF_HELLO = 0, WOFF_H1 = WNS, WOFF_H2 = WOFF_H1 + WNS * WQ1, WOFF
               WOFF_PAIR = WOFF_X + WG * WQX, WGRANULES = WOFF_PAIR + WG * 2 * 2 * SURV;  // 3 200 granules = 51 200 bytes
 static_assert(NT == 512, "predictor_ws.h is written for 8 waves per workgroup");
 static_assert(WH1 / 4 == 96 && WH2 / 2 == 64 && WFC == NDIM + 1, "production shape");
-enum { WSIG_A = 0, WSIG_B, WSIG_H1, WSIG_H2, WSIG_P1, WSIG_P2, WSIG_C, WSIG_FG, WNSIG };
+enum { WSIG_A = 0, WSIG_B, WSIG_H1, WSIG_H2, WSIG_P1, WSIG_P2, WSIG_C, WSIG_I, WSIG_X, WSIG_FG, WNSIG };
 
 struct WsArgs {
     int B, ngroups;
@@ -65,7 +65,7 @@ struct __attribute__((aligned(16))) WsLds : SearchLds {
     float x[WIN * WG];        // state images [k][utterance]
     float h1[WH1 * WG];
     float h2[WH2 * WG];
-    float pI[3][256];         // segment sums as the MFMA leaves them: [gate][unit * 16 + utterance]
+    float pI[2][3][256];      // segment sums as the MFMA leaves them: [frame parity][gate][unit * 16 + utterance]
     float pA[4][3][256];      // [segment][gate][...]
     float pC[4][256];         // [segment][(gate * 4 + unit) * 16 + utterance]
     float pB[2][256];
@@ -217,6 +217,7 @@ struct WsRegs {
     float bA[3];       // background wave 1 (input segment 0): b_hh of GRU1
     float bB;          // b_hh of GRU2 (background wave 0)
     float bI;          // foreground wave w < 3: b_ih of GRU1, gate w
+    float bI3[3];      // background wave 0: all three gates (teacher-forced forward: I(t+1) off the chain)
     float bC;          // foreground wave 0: b_ih of GRU2
     float bF[2];       // foreground wave 0: output bias, tiles 0 and 1
 };
@@ -244,6 +245,7 @@ __device__ __forceinline__ void ws_load_weights(const PredDev& P, WsLds& L, WsRe
     const int fw = wave, bw = wave - WFG;
     R.bA[0] = R.bA[1] = R.bA[2] = 0.0f;
     R.bB = R.bI = R.bC = 0.0f;
+    R.bI3[0] = R.bI3[1] = R.bI3[2] = 0.0f;
     R.bF[0] = R.bF[1] = 0.0f;
     if (wave >= WFG) {
         if (bw == 1 && c < WU1) {  // (input segment 0)
@@ -251,6 +253,10 @@ __device__ __forceinline__ void ws_load_weights(const PredDev& P, WsLds& L, WsRe
             for (int g = 0; g < 3; ++g) R.bA[g] = P.b1h[g * WH1 + WU1 * slice + c];
         }
         if (bw == 0 && c < 12) R.bB = P.b2h[(c / WU2) * WH2 + WU2 * slice + (c % WU2)];
+        if (bw == 0 && c < WU1) {
+#pragma unroll
+            for (int g = 0; g < 3; ++g) R.bI3[g] = P.b1i[g * WH1 + WU1 * slice + c];
+        }
     } else {
         if (fw < 3 && c < WU1) R.bI = P.b1i[fw * WH1 + WU1 * slice + c];
         if (fw == 0) {
@@ -357,15 +363,14 @@ __device__ __forceinline__ void ws_B(WsLds& L, const WsRegs& R, int lane) {
     ws_put(L.pB[1], lane, a1);
 }
 // I = W1i x (one segment of 20 inputs): gate tile `g` = foreground wave (no background matrix work runs at the start of a frame)
-__device__ __forceinline__ void ws_I(WsLds& L, const WsRegs& R, int g, int lane) {
-    const float bias = R.bI;
+__device__ __forceinline__ void ws_I(WsLds& L, float bias, int g, int lane, int buf) {
     const int c = lane & 15, q = lane >> 4, cc = c < WU1 ? c : WU1 - 1;
     f32x4ws acc = {bias, bias, bias, bias};
     const float* xs = L.x + lane;
     const float* ws = L.w1i + (g * WIN + q) * WU1 + cc;
 #pragma unroll
     for (int j = 0; j < WIN / 4; ++j) acc = ws_mfma(xs[64 * j], ws[4 * WU1 * j], acc);
-    ws_put(L.pI[g], lane, acc);
+    ws_put(L.pI[buf][g], lane, acc);
 }
 // C = W2i h1: foreground wave fw = input segment of 96 (one chain of 24 dependent MFMAs: operands read ahead)
 __device__ __forceinline__ void ws_C(WsLds& L, const WsRegs& R, int fw, int lane) {
@@ -480,12 +485,18 @@ __device__ __forceinline__ bool ws_gather2(const WsCtx& X, WsLds& L, int p, unsi
 
 // FOREGROUND, frame t: L.x = x(t) -> L.fo[slice] on the owners (written by threads ft < 18: a reader in another wave needs a
 // barrier first), states in L.h1 / L.h2; false: the launch is dead
+// EARLY_I (the teacher-forced forward): I(t) has been computed one frame ahead by background wave 0 (k_forward_ws)
+template <bool EARLY_I = false>
 __device__ __forceinline__ bool ws_foreground(const WsCtx& X, WsLds& L, const WsRegs& R, int t, int ft0, int& fg_epoch) {
     const int ft = ft0 + ws_opaque_zero();
     const int fw = ft0 >> 6, lane = ft & 63;
     const unsigned epoch = (unsigned)t + 1u;
-    if (fw < 3) ws_I(L, R, fw, lane);
-    ws_fg_sync(L, fg_epoch);
+    if (EARLY_I) {
+        if (!df_wait(&L.sig[WSIG_I], t + 1, &L.dead)) return false;
+    } else {
+        if (fw < 3) ws_I(L, R.bI, fw, lane, t & 1);
+        ws_fg_sync(L, fg_epoch);
+    }
     WSTAMP(0)
     if (!df_wait(&L.sig[WSIG_A], 3 * (t + 1), &L.dead)) return false;  // A(t): prologue, then one round per frame
     WSTAMP(1)
@@ -497,9 +508,9 @@ __device__ __forceinline__ bool ws_foreground(const WsCtx& X, WsLds& L, const Ws
             const float ghr = (L.pA[0][0][v] + L.pA[1][0][v]) + (L.pA[2][0][v] + L.pA[3][0][v]);
             const float ghz = (L.pA[0][1][v] + L.pA[1][1][v]) + (L.pA[2][1][v] + L.pA[3][1][v]);
             const float ghn = (L.pA[0][2][v] + L.pA[1][2][v]) + (L.pA[2][2][v] + L.pA[3][2][v]);
-            const float r = fpc_sigmoidf(L.pI[0][v] + ghr);
-            const float z = fpc_sigmoidf(L.pI[1][v] + ghz);
-            const float n = fpc_tanhf(fmaf(r, ghn, L.pI[2][v]));
+            const float r = fpc_sigmoidf(L.pI[t & 1][0][v] + ghr);
+            const float z = fpc_sigmoidf(L.pI[t & 1][1][v] + ghz);
+            const float n = fpc_tanhf(fmaf(r, ghn, L.pI[t & 1][2][v]));
             const float hp = L.h1[base + lane];
             L.h1[base + lane] = fmaf(z, hp - n, n);
         }
@@ -570,6 +581,7 @@ __device__ __forceinline__ bool ws_foreground(const WsCtx& X, WsLds& L, const Ws
 }
 
 // BACKGROUND, frame t: wave 0: B(t) and half of hop 2's gather; waves 1-3: half of hop 1's gather, then A(t+1)
+template <bool EARLY_I = false>
 __device__ __forceinline__ bool ws_background(const WsCtx& X, WsLds& L, const WsRegs& R, int t, bool last, int bt) {
     const int bw = bt >> 6, lane = (bt + ws_opaque_zero()) & 63;
     if (!df_wait(&L.sig[WSIG_P1], WFG * (t + 1), &L.dead)) return false;
@@ -577,6 +589,14 @@ __device__ __forceinline__ bool ws_background(const WsCtx& X, WsLds& L, const Ws
     if (bw == 0) {  // the two waves of SIMD 0 run no matrix product beside the chain: B(t) under hop 1, then hop 2's gather
         ws_B(L, R, lane);
         df_signal(&L.sig[WSIG_B]);
+        if (EARLY_I) {  // the next frame's input product, still under hop 1 (x(t+1) has been in LDS since the frame began)
+            if (!df_wait(&L.sig[WSIG_X], WFG * (t + 1), &L.dead)) return false;
+            if (!last) {
+#pragma unroll
+                for (int g = 0; g < 3; ++g) ws_I(L, R.bI3[g], g, lane, (t + 1) & 1);
+            }
+            df_signal(&L.sig[WSIG_I]);
+        }
         if (!df_wait(&L.sig[WSIG_P2], t + 1, &L.dead)) return false;
         if (!ws_gather2(X, L, 64 + lane, (unsigned)t + 1u)) return false;
         df_signal(&L.sig[WSIG_H2]);
@@ -650,35 +670,44 @@ __global__ __launch_bounds__(NT) void k_forward_ws(const PredDev P, const float*
     __syncthreads();
     ws_prologue(P, X, L, R, S, tid);
     const bool owner = slice < X.nu;  // this workgroup stores the outputs of utterance `slice` of the group
+    // Teacher forcing: every input row is known in advance, so the input product I(t+1) = W1i x(t+1) leaves the chain -- the
+    // foreground puts x(t+1) into LDS as soon as frame t begins (I(t) has been taken from x(t) a frame earlier), background
+    // wave 0 computes I(t+1) under hop 1 of frame t.  I(0) here, by the foreground's waves 0-2.
+    if (tid < 3 * 64 && Lf > 0) ws_I(L, R.bI, tid >> 6, tid & 63, 0);
+    __syncthreads();
+    if (tid == 0) L.sig[WSIG_I] = 1;
+    __syncthreads();
     WPROF_INIT()
+    auto x_row = [&](int t, float (&xr)[2]) {  // this thread's two values of the input rows of frame t (0 beyond the end)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int i = tid + WFGT * j, u = i / WIN, k = i - u * WIN;
+            xr[j] = (t < Lf && i < WIN * WG && u < X.nu) ? x[((size_t)(X.b0 + u) * Lf + t) * WIN + k] : 0.0f;
+        }
+    };
     if (tid < WFGT) {
         __builtin_amdgcn_s_setprio(FPC_FG_PRIO);
         int fg_epoch = 0;
+        float xa[2];
+        x_row(1, xa);
         for (int t = 0; t < Lf; ++t) {
-            float xn[2] = {0.0f, 0.0f};  // (teacher forcing: the next input rows are fetched while this frame runs)
-            if (t + 1 < Lf) {
+            // x(t+1) into LDS (x(t) is not read any more: I(t) is done), then the row after it on its way
+            if (!df_wait(&L.sig[WSIG_I], t + 1, &L.dead)) break;
 #pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    const int i = tid + WFGT * j, u = i / WIN, k = i - u * WIN;
-                    if (i < WIN * WG && u < X.nu) xn[j] = x[((size_t)(X.b0 + u) * Lf + t + 1) * WIN + k];
-                }
+            for (int j = 0; j < 2; ++j) {
+                const int i = tid + WFGT * j, u = i / WIN, k = i - u * WIN;
+                if (i < WIN * WG) L.x[k * WG + u] = xa[j];
             }
-            if (!ws_foreground(X, L, R, t, tid, fg_epoch)) break;
+            df_signal(&L.sig[WSIG_X]);
+            x_row(t + 2, xa);
+            if (!ws_foreground<true>(X, L, R, t, tid, fg_epoch)) break;
             if (owner && tid < WFC) y[((size_t)(X.b0 + slice) * Lf + t) * WFC + tid] = L.fo[slice][tid];
-            if (t + 1 < Lf) {
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    const int i = tid + WFGT * j, u = i / WIN, k = i - u * WIN;
-                    if (i < WIN * WG) L.x[k * WG + u] = xn[j];
-                }
-                ws_fg_sync(L, fg_epoch);
-            }
             WSTAMP(12)
         }
         __builtin_amdgcn_s_setprio(0);
     } else {
         for (int tb = 0; tb < Lf; ++tb)
-            if (!ws_background(X, L, R, tb, tb + 1 == Lf, tid - WFGT)) break;
+            if (!ws_background<true>(X, L, R, tb, tb + 1 == Lf, tid - WFGT)) break;
     }
     WPROF_DUMP(Lf)
     __syncthreads();
