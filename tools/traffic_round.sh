@@ -4,7 +4,7 @@
 #   gpurun -- 'TAG=r03 bash tools/traffic_round.sh'
 set -e
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-TAG=${TAG:-r03}
+TAG=${TAG:-r04}
 out=gpurun_out/${TAG}_traffic; mkdir -p $out; rm -rf $out/*
 for c in FETCH_SIZE WRITE_SIZE; do
   timeout -k 10 300 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $out/$c -o runc -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-e2e > /dev/null 2> $out/$c.err || echo "FAILED $c"
