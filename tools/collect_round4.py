@@ -11,8 +11,8 @@ for f in glob.glob(os.path.join(o, "prof", "**", "*kernel_stats.csv"), recursive
 rows = []
 for f in glob.glob(os.path.join(o, "prof", "**", "*kernel_trace.csv"), recursive=True):
     for r in csv.DictReader(open(f)):
-        if "k_decode" in r["Kernel_Name"]:
-            rows.append((int(r["Start_Timestamp"]), (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6, r["Grid_Size"], r.get("VGPR_Count", ""), r.get("LDS_Block_Size", "")))
+        if "k_decode<" in r["Kernel_Name"]:
+            rows.append((int(r["Start_Timestamp"]), (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6, r.get("Grid_Size_X", ""), r.get("VGPR_Count", ""), r.get("LDS_Block_Size", "")))
 rows.sort()
 with open(os.path.join(P, "r04_kernel_trace_k_decode.txt"), "w") as f:
     f.write(f"rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline   (tree {head})\n")
