@@ -35,6 +35,9 @@
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4ws __attribute__((ext_vector_type(4)));
 
+#ifndef FPC_WS_POLL_DELAY
+#define FPC_WS_POLL_DELAY 0  // x 64 cycles before the first poll of a hop
+#endif
 constexpr int WG = 16;    // utterances per group (one MFMA M tile)
 constexpr int WNS = 32;   // workgroups per group (the CUs of one XCD)
 constexpr int WIN = 20, WH1 = 384, WH2 = 128, WFC = 18;
@@ -72,9 +75,9 @@ struct __attribute__((aligned(16))) WsLds : SearchLds {
     float pF[8][2][16];       // [segment][tile][row in tile]: the owned utterance only
     float fo[WG][WIN];        // predictions [utterance][row < 18]
     float xn[MAX_IN];         // the owner's next input row
-    float w1h[3 * WH1 * WU1];  // [gate][k][unit]: rows of 12 floats, so the four k of an MFMA step sit in disjoint banks
+    float w1h[3 * WH1 * WU1];  // [gate][k / 16][k % 4][unit][(k % 16) / 4]: one 16-byte read = a lane's B operands of 4 k-steps
     float w1i[3 * WIN * WU1];  // [gate][k][unit]
-    float w2i[WH1 * 3 * WU2];  // [k][gate * 4 + unit]
+    float w2i[WH1 * 3 * WU2];  // [k / 16][k % 4][gate * 4 + unit][(k % 16) / 4]
     float w2h[WH2 * 3 * WU2];
     float fcw[WH2 * WFC];      // [k][row]
     int sig[WNSIG];
@@ -183,6 +186,11 @@ template <int N>
 __device__ __forceinline__ bool ws_poll(const WsCtx& X, WsLds& L, const int (&gi)[N], unsigned epoch, u32x4 (&v)[N]) {
     unsigned spins = 0;
     unsigned long long t0 = 0, last = 0;
+#if FPC_WS_POLL_DELAY
+    // (a poll issued at once reads the L2 before the partners' stores have landed there and costs a second round trip: the
+    //  first poll waits for about the time a store takes to arrive)
+    __builtin_amdgcn_s_sleep(FPC_WS_POLL_DELAY);
+#endif
     for (;;) {
         bool ok = true;
 #pragma unroll
@@ -227,7 +235,8 @@ __device__ __forceinline__ void ws_load_weights(const PredDev& P, WsLds& L, WsRe
     const int wave = tid >> 6, lane = tid & 63, c = lane & 15;
     for (int i = tid; i < 3 * WH1 * WU1; i += NT) {
         const int g = i / (WH1 * WU1), r = i - g * WH1 * WU1, k = r / WU1, u = r - k * WU1;
-        L.w1h[i] = P.w1h[(size_t)k * 3 * WH1 + g * WH1 + WU1 * slice + u];
+        L.w1h[((g * (WH1 / 16) + k / 16) * 4 + (k & 3)) * (4 * WU1) + u * 4 + ((k & 15) >> 2)] =
+            P.w1h[(size_t)k * 3 * WH1 + g * WH1 + WU1 * slice + u];
     }
     for (int i = tid; i < 3 * WIN * WU1; i += NT) {
         const int g = i / (WIN * WU1), r = i - g * WIN * WU1, k = r / WU1, u = r - k * WU1;
@@ -235,7 +244,7 @@ __device__ __forceinline__ void ws_load_weights(const PredDev& P, WsLds& L, WsRe
     }
     for (int i = tid; i < WH1 * 12; i += NT) {
         const int k = i / 12, r = i - k * 12, g = r / WU2, u = r - g * WU2;
-        L.w2i[i] = P.w2i[(size_t)k * 3 * WH2 + g * WH2 + WU2 * slice + u];
+        L.w2i[((k / 16) * 4 + (k & 3)) * 48 + r * 4 + ((k & 15) >> 2)] = P.w2i[(size_t)k * 3 * WH2 + g * WH2 + WU2 * slice + u];
     }
     for (int i = tid; i < WH2 * 12; i += NT) {
         const int k = i / 12, r = i - k * 12, g = r / WU2, u = r - g * WU2;
@@ -311,31 +320,34 @@ __device__ __forceinline__ void ws_A(WsLds& L, const WsRegs& R, int bw, int lane
     acc[3] = f32x4ws{0.f, 0.f, 0.f, 0.f};
     const float* hs = L.h1 + 96 * sg * WG + lane;
     const float* h3 = L.h1 + 96 * 3 * WG + lane;
-    const float* ws = L.w1h + (96 * sg + q) * WU1 + cc;
-    const float* w3 = L.w1h + sg * WH1 * WU1 + (96 * 3 + q) * WU1 + cc;  // gate tile sg of segment 3
-    float a[24], b[24], w[4], wn[4];
+    // B operands: one 16-byte read serves this lane for 4 k-steps of a tile (6 blocks of 16 inputs per segment)
+    const f32x4ws* ws = reinterpret_cast<const f32x4ws*>(L.w1h) + (6 * sg * 4 + q) * WU1 + cc;        // + g * 24 * 48, + 48 per block
+    const f32x4ws* w3 = reinterpret_cast<const f32x4ws*>(L.w1h) + ((sg * 24 + 18) * 4 + q) * WU1 + cc;  // gate tile sg of segment 3
+    float a[24], b[24];
 #pragma unroll
     for (int j = 0; j < 24; ++j) {
         a[j] = hs[64 * j];
         b[j] = h3[64 * j];
     }
+    f32x4ws w[4], wn[4];
 #pragma unroll
-    for (int g = 0; g < 3; ++g) w[g] = ws[g * WH1 * WU1];
+    for (int g = 0; g < 3; ++g) w[g] = ws[g * 24 * 4 * WU1];
     w[3] = w3[0];
 #pragma unroll
-    for (int j = 0; j < 24; ++j) {
-        if (j + 1 < 24) {
+    for (int kb = 0; kb < 6; ++kb) {
+        if (kb + 1 < 6) {
 #pragma unroll
-            for (int g = 0; g < 3; ++g) wn[g] = ws[g * WH1 * WU1 + 4 * WU1 * (j + 1)];
-            wn[3] = w3[4 * WU1 * (j + 1)];
+            for (int g = 0; g < 3; ++g) wn[g] = ws[g * 24 * 4 * WU1 + 4 * WU1 * (kb + 1)];
+            wn[3] = w3[4 * WU1 * (kb + 1)];
         }
 #pragma unroll
-        for (int g = 0; g < 3; ++g) acc[g] = ws_mfma(a[j], w[g], acc[g]);
-        acc[3] = ws_mfma(b[j], w[3], acc[3]);
+        for (int jj = 0; jj < 4; ++jj) {
+#pragma unroll
+            for (int g = 0; g < 3; ++g) acc[g] = ws_mfma(a[4 * kb + jj], w[g][jj], acc[g]);
+            acc[3] = ws_mfma(b[4 * kb + jj], w[3][jj], acc[3]);
+        }
 #pragma unroll
         for (int g = 0; g < 4; ++g) w[g] = wn[g];
-        __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);  // the next step's four weight reads
-        __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);  // this step's four MFMAs
     }
 #pragma unroll
     for (int g = 0; g < 3; ++g) ws_put(L.pA[sg][g], lane, acc[g]);
@@ -377,15 +389,15 @@ __device__ __forceinline__ void ws_C(WsLds& L, const WsRegs& R, int fw, int lane
     const int c = lane & 15, q = lane >> 4, cc = c < 12 ? c : 11;
     f32x4ws acc = {R.bC, R.bC, R.bC, R.bC};
     const float* hs = L.h1 + 96 * fw * WG + lane;
-    const float* ws = L.w2i + (96 * fw + q) * 12 + cc;
-    float a[24], w[24];
+    const f32x4ws* ws = reinterpret_cast<const f32x4ws*>(L.w2i) + (6 * fw * 4 + q) * 12 + cc;  // + 48 per block of 16 inputs
+    float a[24];
+    f32x4ws w[6];
 #pragma unroll
-    for (int j = 0; j < 24; ++j) {
-        a[j] = hs[64 * j];
-        w[j] = ws[48 * j];
-    }
+    for (int kb = 0; kb < 6; ++kb) w[kb] = ws[48 * kb];
 #pragma unroll
-    for (int j = 0; j < 24; ++j) acc = ws_mfma(a[j], w[j], acc);
+    for (int j = 0; j < 24; ++j) a[j] = hs[64 * j];
+#pragma unroll
+    for (int j = 0; j < 24; ++j) acc = ws_mfma(a[j], w[j >> 2][j & 3], acc);
     ws_put(L.pC[fw], lane, acc);
 }
 // output layer on relu(h2) for the owned utterance: rows 0-15 as one MFMA tile (foreground wave fw = input segments 2 fw,
