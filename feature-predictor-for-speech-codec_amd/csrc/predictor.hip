@@ -1131,6 +1131,7 @@ __global__ __launch_bounds__(NT) FPC_OCC void k_decode_feat(const PredDev P, con
 
 #include "predictor_df.h"
 #include "predictor_ws.h"
+#include "predictor_wsd.h"
 
 // stand-alone quantizers: one workgroup per input row
 __global__ __launch_bounds__(NT) void k_vq(const CbDev C, int which, const float* __restrict__ r, double* qr,
@@ -1780,7 +1781,7 @@ static void ws_prof_print(fpc_predictor* p, const char* who, int B, hipStream_t 
     volatile unsigned* w = (volatile unsigned*)p->status_host;
     fprintf(stderr, "%s B=%d cycles/frame FG: I %u waitA %u gates1 %u gather1 %u waitH1 %u C %u waitB %u gates2 %u gather2 %u waitH2 %u "
             "fc %u out %u tail %u | rendezvous %u frame-tail %u hop3 %u | BG wave 1: waitP1 %u gather1 %u waitH1 %u A %u waitC %u (unused %u) "
-            "toRendezvous %u rest %u | tail: loads+scalar %u dist1+min %u bound+append %u rank %u survivors %u stage2 %u final %u\n", who, B, w[1], w[2], w[3], w[4], w[5], w[6], w[7], w[8], w[9], w[10], w[11], w[12], w[13],
+            "toRendezvous %u rest %u | tail stamps 25..31: %u %u %u %u %u %u %u\n", who, B, w[1], w[2], w[3], w[4], w[5], w[6], w[7], w[8], w[9], w[10], w[11], w[12], w[13],
             w[21], w[22], w[23], w[14], w[15], w[16], w[17], w[18], w[19], w[20], w[24], w[26], w[27], w[28], w[29], w[30], w[31], w[32]);
     for (int k = 1; k < 40; ++k) w[k] = 0;
 }
@@ -2025,7 +2026,12 @@ extern "C" int fpc_encode(fpc_predictor* p, const fpc_codebooks* cb, const float
             }
             a.idx = p->wsidx.as<int>();
         }
-        hipLaunchKernelGGL(k_encode_ws, dim3(ws_grid(wa)), dim3(NT), 0, static_cast<hipStream_t>(s), p->d, cd, a, wa);
+        // the frame tail distributed over the group's workgroups (predictor_wsd.h); FPC_WS_TAIL=pair: on the utterance's own pair
+        const char* tl = getenv("FPC_WS_TAIL");
+        if (tl && tl[0] == 'p')
+            hipLaunchKernelGGL(k_encode_ws, dim3(ws_grid(wa)), dim3(NT), 0, static_cast<hipStream_t>(s), p->d, cd, a, wa);
+        else
+            hipLaunchKernelGGL(k_encode_wsd, dim3(ws_grid(wa)), dim3(NT), 0, static_cast<hipStream_t>(s), p->d, cd, a, wa);
         FPC_HIP(hipGetLastError());
         if (hist_dev && qtz) {
             const size_t frames = (size_t)B * L;

@@ -50,7 +50,10 @@ constexpr int WFGT = WFG * 64;
 // granule block of a group, in 16-byte units: hello | h1 | h2 | next input
 // | the pairs' search results [utterance][half][stage][5]: {tag, distance (2 dwords), index}
 constexpr int WOFF_HELLO = 0, WOFF_H1 = WNS, WOFF_H2 = WOFF_H1 + WNS * WQ1, WOFF_X = WOFF_H2 + WNS * WQ2,
-              WOFF_PAIR = WOFF_X + WG * WQX, WGRANULES = WOFF_PAIR + WG * 2 * 2 * SURV;  // 3 200 granules = 51 200 bytes
+              WOFF_PAIR = WOFF_X + WG * WQX,
+              // | the distributed searches' results [utterance][workgroup][5], first and second stage (predictor_wsd.h)
+              WOFF_G1 = WOFF_PAIR + WG * 2 * 2 * SURV, WOFF_G2 = WOFF_G1 + WG * WNS * SURV,
+              WGRANULES = WOFF_G2 + WG * WNS * SURV;  // 8 320 granules = 133 120 bytes
 static_assert(NT == 512, "predictor_ws.h is written for 8 waves per workgroup");
 static_assert(WH1 / 4 == 96 && WH2 / 2 == 64 && WFC == NDIM + 1, "production shape");
 enum { WSIG_A = 0, WSIG_B, WSIG_H1, WSIG_H2, WSIG_P1, WSIG_P2, WSIG_C, WSIG_I, WSIG_X, WSIG_FG, WNSIG };
@@ -75,7 +78,6 @@ struct __attribute__((aligned(16))) WsLds : SearchLds {
     float pF[8][2][16];       // [segment][tile][row in tile]: the owned utterance only
     float fo[WG][WIN];        // predictions [utterance][row < 18]
     float xn[MAX_IN];         // the owner's next input row
-    float w1h[3 * WH1 * WU1];  // [gate][k / 16][k % 4][unit][(k % 16) / 4]: one 16-byte read = a lane's B operands of 4 k-steps
     float w1i[3 * WIN * WU1];  // [gate][k][unit]
     float w2i[WH1 * 3 * WU2];  // [k / 16][k % 4][gate * 4 + unit][(k % 16) / 4]
     float w2h[WH2 * 3 * WU2];
@@ -95,6 +97,15 @@ struct __attribute__((aligned(16))) WsLds : SearchLds {
     int oi2[SURV];
     double loc_d[2][SURV];       // first-stage lists of the two halves of a pair (this workgroup's, the partner's)
     int loc_i[2][SURV];
+    // the distributed tail (predictor_wsd.h): every workgroup of a group serves every utterance of the group
+    double cbs[3][WNS][NDIM + 1];  // this workgroup's entries 32 m + slice of the books hi stage 1, hi stage 2, lo
+    float pFa[8][WFC * WG];        // output-layer segment sums of all 16 utterances [segment][row * 16 + utterance]
+    float rsa[WG][WIN];            // residuals [utterance][row]
+    double xs[WG][NDIM + 1];       // first-stage targets
+    double xq2[WG][SURV][NDIM + 1];  // second-stage targets
+    double dl[WG][WNS];            // a half-wave's 32 distances (local ranking, heads of the gathered lists)
+    int list2[WG];                 // the utterances with a 2-stage search in this frame
+    int n2;
 #ifdef FPC_WS_PROF
     long long wprof[32], wlast, wlast_bg;  // diagnostic builds: cycles per stage, foreground [0..13) + [19..24), background [13..19)
 #endif
@@ -222,22 +233,21 @@ __device__ __forceinline__ bool ws_role(int ngroups, int& group, int& slice) {
 
 // per-wave constants of the matrix products (registers for the whole launch)
 struct WsRegs {
+    float wA[4][24];   // background wave bw = 1..3: W1h as MFMA B operands -- the three gate tiles of input segment bw - 1 and gate
+                       // tile bw - 1 of segment 3, 24 k-steps each (55 kB per workgroup that LDS has no room for next to the
+                       // encoder's distributed searches; the chain's other weights stay in LDS)
     float bA[3];       // background wave 1 (input segment 0): b_hh of GRU1
     float bB;          // b_hh of GRU2 (background wave 0)
     float bI;          // foreground wave w < 3: b_ih of GRU1, gate w
     float bI3[3];      // background wave 0: all three gates (teacher-forced forward: I(t+1) off the chain)
     float bC;          // foreground wave 0: b_ih of GRU2
     float bF[2];       // foreground wave 0: output bias, tiles 0 and 1
+    float bF16[2];     // output bias of rows 16, 17 (the distributed tail's output layer: every foreground thread)
 };
 
 // copies this workgroup's weight slices to LDS / registers (all threads; no barrier inside)
 __device__ __forceinline__ void ws_load_weights(const PredDev& P, WsLds& L, WsRegs& R, int slice, int tid) {
     const int wave = tid >> 6, lane = tid & 63, c = lane & 15;
-    for (int i = tid; i < 3 * WH1 * WU1; i += NT) {
-        const int g = i / (WH1 * WU1), r = i - g * WH1 * WU1, k = r / WU1, u = r - k * WU1;
-        L.w1h[((g * (WH1 / 16) + k / 16) * 4 + (k & 3)) * (4 * WU1) + u * 4 + ((k & 15) >> 2)] =
-            P.w1h[(size_t)k * 3 * WH1 + g * WH1 + WU1 * slice + u];
-    }
     for (int i = tid; i < 3 * WIN * WU1; i += NT) {
         const int g = i / (WIN * WU1), r = i - g * WIN * WU1, k = r / WU1, u = r - k * WU1;
         L.w1i[i] = P.w1i[(size_t)k * 3 * WH1 + g * WH1 + WU1 * slice + u];
@@ -253,13 +263,29 @@ __device__ __forceinline__ void ws_load_weights(const PredDev& P, WsLds& L, WsRe
     for (int i = tid; i < WH2 * WFC; i += NT) L.fcw[i] = P.fcw[i];
     const int fw = wave, bw = wave - WFG;
     R.bA[0] = R.bA[1] = R.bA[2] = 0.0f;
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int j = 0; j < 24; ++j) R.wA[g][j] = 0.0f;
     R.bB = R.bI = R.bC = 0.0f;
     R.bI3[0] = R.bI3[1] = R.bI3[2] = 0.0f;
     R.bF[0] = R.bF[1] = 0.0f;
+    R.bF16[0] = P.fcb[16];
+    R.bF16[1] = P.fcb[17];
     if (wave >= WFG) {
         if (bw == 1 && c < WU1) {  // (input segment 0)
 #pragma unroll
             for (int g = 0; g < 3; ++g) R.bA[g] = P.b1h[g * WH1 + WU1 * slice + c];
+        }
+        if (bw >= 1) {
+            const int sg = bw - 1, q = lane >> 4;
+#pragma unroll
+            for (int j = 0; j < 24; ++j) {
+#pragma unroll
+                for (int g = 0; g < 3; ++g)
+                    R.wA[g][j] = c < WU1 ? P.w1h[(size_t)(96 * sg + 4 * j + q) * 3 * WH1 + g * WH1 + WU1 * slice + c] : 0.0f;
+                R.wA[3][j] = c < WU1 ? P.w1h[(size_t)(96 * 3 + 4 * j + q) * 3 * WH1 + sg * WH1 + WU1 * slice + c] : 0.0f;
+            }
         }
         if (bw == 0 && c < 12) R.bB = P.b2h[(c / WU2) * WH2 + WU2 * slice + (c % WU2)];
         if (bw == 0 && c < WU1) {
@@ -312,7 +338,6 @@ __device__ __forceinline__ void ws_put(float* p, int lane, const f32x4ws& acc) {
 // this product go to three SIMDs, 4 units = 96 MFMAs each: wave bw takes the three gate tiles of input segment bw - 1 and gate
 // tile bw - 1 of segment 3, four independent accumulators per k-step, state operands read up front, weights one step ahead.
 __device__ __forceinline__ void ws_A(WsLds& L, const WsRegs& R, int bw, int lane) {
-    const int c = lane & 15, q = lane >> 4, cc = c < WU1 ? c : WU1 - 1;
     const int sg = bw - 1;  // 0..2
     f32x4ws acc[4];
 #pragma unroll
@@ -320,34 +345,17 @@ __device__ __forceinline__ void ws_A(WsLds& L, const WsRegs& R, int bw, int lane
     acc[3] = f32x4ws{0.f, 0.f, 0.f, 0.f};
     const float* hs = L.h1 + 96 * sg * WG + lane;
     const float* h3 = L.h1 + 96 * 3 * WG + lane;
-    // B operands: one 16-byte read serves this lane for 4 k-steps of a tile (6 blocks of 16 inputs per segment)
-    const f32x4ws* ws = reinterpret_cast<const f32x4ws*>(L.w1h) + (6 * sg * 4 + q) * WU1 + cc;        // + g * 24 * 48, + 48 per block
-    const f32x4ws* w3 = reinterpret_cast<const f32x4ws*>(L.w1h) + ((sg * 24 + 18) * 4 + q) * WU1 + cc;  // gate tile sg of segment 3
     float a[24], b[24];
 #pragma unroll
     for (int j = 0; j < 24; ++j) {
         a[j] = hs[64 * j];
         b[j] = h3[64 * j];
     }
-    f32x4ws w[4], wn[4];
 #pragma unroll
-    for (int g = 0; g < 3; ++g) w[g] = ws[g * 24 * 4 * WU1];
-    w[3] = w3[0];
+    for (int j = 0; j < 24; ++j) {
 #pragma unroll
-    for (int kb = 0; kb < 6; ++kb) {
-        if (kb + 1 < 6) {
-#pragma unroll
-            for (int g = 0; g < 3; ++g) wn[g] = ws[g * 24 * 4 * WU1 + 4 * WU1 * (kb + 1)];
-            wn[3] = w3[4 * WU1 * (kb + 1)];
-        }
-#pragma unroll
-        for (int jj = 0; jj < 4; ++jj) {
-#pragma unroll
-            for (int g = 0; g < 3; ++g) acc[g] = ws_mfma(a[4 * kb + jj], w[g][jj], acc[g]);
-            acc[3] = ws_mfma(b[4 * kb + jj], w[3][jj], acc[3]);
-        }
-#pragma unroll
-        for (int g = 0; g < 4; ++g) w[g] = wn[g];
+        for (int g = 0; g < 3; ++g) acc[g] = ws_mfma(a[j], R.wA[g][j], acc[g]);
+        acc[3] = ws_mfma(b[j], R.wA[3][j], acc[3]);
     }
 #pragma unroll
     for (int g = 0; g < 3; ++g) ws_put(L.pA[sg][g], lane, acc[g]);
@@ -498,7 +506,9 @@ __device__ __forceinline__ bool ws_gather2(const WsCtx& X, WsLds& L, int p, unsi
 // FOREGROUND, frame t: L.x = x(t) -> L.fo[slice] on the owners (written by threads ft < 18: a reader in another wave needs a
 // barrier first), states in L.h1 / L.h2; false: the launch is dead
 // EARLY_I (the teacher-forced forward): I(t) has been computed one frame ahead by background wave 0 (k_forward_ws)
-template <bool EARLY_I = false>
+__device__ __forceinline__ void wsd_F(WsLds& L, const WsRegs& R, int fw, int lane, int ft);  // predictor_wsd.h
+// FC_ALL (the distributed encoder tail): the output layer's segment sums of all 16 utterances, no prediction formed here
+template <bool EARLY_I = false, bool FC_ALL = false>
 __device__ __forceinline__ bool ws_foreground(const WsCtx& X, WsLds& L, const WsRegs& R, int t, int ft0, int& fg_epoch) {
     const int ft = ft0 + ws_opaque_zero();
     const int fw = ft0 >> 6, lane = ft & 63;
@@ -575,8 +585,9 @@ __device__ __forceinline__ bool ws_foreground(const WsCtx& X, WsLds& L, const Ws
     WSTAMP(8)
     if (!df_wait(&L.sig[WSIG_H2], 2 * (t + 1), &L.dead)) return false;  // h2(t) whole in LDS
     WSTAMP(9)
-    // the output layer: only the workgroup that owns an utterance needs its prediction (the other rows of the tile come for free)
-    if (X.own >= 0) {
+    if (FC_ALL) {
+        wsd_F(L, R, fw, lane, ft);
+    } else if (X.own >= 0) {  // the output layer: only the workgroup that owns an utterance needs its prediction
         ws_F(L, R, fw, lane, X.own);
         ws_fg_sync(L, fg_epoch);
         WSTAMP(10)

@@ -1,0 +1,392 @@
+// predictor_wsd.h -- the encoder's frame tail DISTRIBUTED over the 32 workgroups of a group (included after predictor_ws.h).
+//
+// With the tail on the utterance's own workgroups (ws_encode_tail: owner + helper) a frame of the group lasts as long as its
+// slowest utterance, and one of 16 is almost always above the threshold: 2 x (1 024 + 5 x 1 024 entries x 51 float64
+// operations) on two CUs while 30 others wait, plus 16 x 139 kB of codebook per stage through the XCD's L2 -- 24.7k cycles
+// per frame (profiles/r04_ablations.txt).  Here every workgroup keeps 1/32 of every codebook in LDS for the launch (entries
+// 32 m + slice: 32 per book, 13.8 kB) and serves EVERY utterance of the group: the TARGETS move, not the codebooks.
+//   thread (u = tid >> 5, m = tid & 31): utterance u of the group, entry m of this workgroup's slice -- or, when results
+//   come back, the list of workgroup m for utterance u: a half-wave per utterance throughout.
+//   1. output layer, residuals and thresholds of all 16 utterances on every workgroup (an MFMA tile has them anyway);
+//   2. first stage: one distance per thread, the half-wave's five best (one for a 1-stage search) -> 16-byte granules
+//      {epoch, distance, index} [utterance][workgroup][5];
+//   3. every workgroup gathers every list (thread (u, m) polls workgroup m's list for utterance u) and takes the five
+//      smallest of the 32 sorted lists -- five half-wave arg-min rounds with the winner's list popped -- so all 32 know
+//      the survivors without another hop;
+//   4. second stage: (utterance, survivor, entry) triples dealt over the threads, 512 per round, the half-wave's best
+//      per (utterance, survivor) -> granules; gathered and reduced the same way;
+//   5. every workgroup forms every utterance's quantized residual and next input row itself (no third hop); workgroup u
+//      stores utterance u's outputs.
+// Every choice is a minimum over (float64 distance in numpy's pairwise order, index) exactly as vq_func.py:10-24,110-125
+// makes it: results are bit-identical to encode_frame and ws_encode_tail (tests).
+
+// (distance, index) minimum over each HALF of the wave (lanes 0-31, 32-63), ties to the lower index; every lane gets its
+// half's.  The distance: one float64 pass (four steps inside the 16-lane rows, one row broadcast).  The index: where exactly
+// one lane of a half holds the smallest distance -- the rule: equal float64 distances of different entries are rare -- it is
+// read from that lane (a ballot and two scalar lane reads); otherwise the smallest index among the holders by a second pass.
+// (Three 32-bit passes over the distance's words instead of the float64 pass were measured slower: the passes are chains of
+// dependent DPP steps, and there would be three of them.)
+__device__ __forceinline__ void hw_argmin(double& d, int& i, int lane) {
+    double m = d;
+    m = min_f64(m, dpp_mov_f64<0xB1, 0xf, false>(m));   // quad_perm [1,0,3,2]
+    m = min_f64(m, dpp_mov_f64<0x4E, 0xf, false>(m));   // quad_perm [2,3,0,1]
+    m = min_f64(m, dpp_mov_f64<0x141, 0xf, false>(m));  // row_half_mirror
+    m = min_f64(m, dpp_mov_f64<0x140, 0xf, false>(m));  // row_mirror: every lane holds its row's minimum
+    m = min_f64(m, dpp_mov_f64<0x142, 0xa, false>(m));  // row_bcast:15 -> rows 1, 3: the half's minimum
+    const unsigned long long b = (unsigned long long)__double_as_longlong(m);
+    const unsigned lo0 = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)b, 31), hi0 = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(b >> 32), 31);
+    const unsigned lo1 = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)b, 63), hi1 = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(b >> 32), 63);
+    const bool up = lane >= 32;
+    const double dmin = __longlong_as_double((long long)(((unsigned long long)(up ? hi1 : hi0) << 32) | (up ? lo1 : lo0)));
+    int c = d == dmin ? i : 0x7fffffff;
+    c = min(c, dpp_mov_i32<0xB1, 0xf>(c));
+    c = min(c, dpp_mov_i32<0x4E, 0xf>(c));
+    c = min(c, dpp_mov_i32<0x141, 0xf>(c));
+    c = min(c, dpp_mov_i32<0x140, 0xf>(c));
+    c = min(c, dpp_mov_i32<0x142, 0xa>(c));
+    const int i0 = __builtin_amdgcn_readlane(c, 31), i1 = __builtin_amdgcn_readlane(c, 63);
+    const int r = up ? i1 : i0;
+    d = dmin;
+    i = r;
+}
+// float64 squared distance, numpy's pairwise order (vq_func.py:18), both operands in LDS
+__device__ __forceinline__ double wsd_dist(const double* x, const double* c) {
+    double r[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const double d = x[j] - c[j];
+        r[j] = d * d;
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const double d = x[8 + j] - c[8 + j];
+        const double dd = d * d;
+        r[j] = r[j] + dd;
+    }
+    double res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+    const double d = x[16] - c[16];
+    const double dd = d * d;
+    res = res + dd;
+    return res;
+}
+__device__ __forceinline__ void wsd_put(const WsCtx& X, int g, unsigned epoch, double d, int ix) {
+    if (X.withhold) return;
+    const unsigned long long b = (unsigned long long)__double_as_longlong(d);
+    const u32x4 w = {epoch, (unsigned)b, (unsigned)(b >> 32), (unsigned)ix};
+    if (X.fast)
+        __builtin_amdgcn_raw_buffer_store_b128(w, X.rs, g * 16, 0, 0);
+    else
+        __builtin_amdgcn_raw_buffer_store_b128(w, X.rs, g * 16, 0, 16);
+}
+// this thread's list of n <= 5 results (granules base .. base + n - 1); a list that never arrives reads as "no entry"
+__device__ __forceinline__ void wsd_get(const WsCtx& X, WsLds& L, int base, int n, unsigned epoch, double (&d)[SURV], int (&ix)[SURV]) {
+    int gi[SURV];
+#pragma unroll
+    for (int k = 0; k < SURV; ++k) gi[k] = k < n ? base + k : -1;
+    u32x4 v[SURV];
+    const bool ok = ws_poll<SURV>(X, L, gi, epoch, v);
+#pragma unroll
+    for (int k = 0; k < SURV; ++k) {
+        const bool have = ok && k < n && v[k].x == epoch;
+        d[k] = have ? __longlong_as_double((long long)(((unsigned long long)v[k].z << 32) | v[k].y)) : INFINITY;
+        ix[k] = have ? (int)v[k].w : 0x7fffffff;
+    }
+}
+__device__ __forceinline__ int wsd_clamp(int i, int n) { return i < 0 ? 0 : (i < n ? i : n - 1); }
+
+// output layer of ALL 16 utterances: rows 0-15 as one MFMA tile per input segment (foreground wave fw: segments 2 fw, 2 fw + 1),
+// rows 16, 17 as fmaf chains (32 (row, utterance) pairs x 8 segments on the 256 foreground threads)
+__device__ __forceinline__ void wsd_F(WsLds& L, const WsRegs& R, int fw, int lane, int ft) {
+    const int c = lane & 15, q = lane >> 4;
+    float hv[2][4], wv[2][4];
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+        const int sg = 2 * fw + s2;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float h = L.h2[(16 * sg + 4 * j) * WG + lane];
+            hv[s2][j] = h > 0.0f ? h : 0.0f;
+            wv[s2][j] = L.fcw[(16 * sg + 4 * j + q) * WFC + c];
+        }
+    }
+    const int rsg = ft >> 5, row = 16 + ((ft >> 4) & 1), ru = ft & 15;  // item ft: (segment, row 16 | 17, utterance)
+    float rh[16], rw[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        rh[k] = L.h2[(16 * rsg + k) * WG + ru];
+        rw[k] = L.fcw[(16 * rsg + k) * WFC + row];
+    }
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+        const int sg = 2 * fw + s2;
+        const float b0 = sg == 0 ? R.bF[0] : 0.0f;
+        f32x4ws a0 = {b0, b0, b0, b0};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) a0 = ws_mfma(hv[s2][j], wv[s2][j], a0);
+        ws_put(L.pFa[sg], lane, a0);  // [row c][utterances 4 q .. 4 q + 3]
+    }
+    float a = rsg == 0 ? R.bF16[row - 16] : 0.0f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) a = fmaf(rh[k] > 0.0f ? rh[k] : 0.0f, rw[k], a);
+    L.pFa[rsg][row * WG + ru] = a;
+}
+
+// the frame's tail for all utterances of the group (all 512 threads); `fa`: feat[u][frame][row] of item tid < 288 = (row, u);
+// pv: the pitch columns (threads < 32, as in k_encode_ws)
+__device__ __forceinline__ void wsd_tail(const WsCtx& X, WsLds& L, const CbDev& C, const EncArgs& A, unsigned* err, int frame,
+                                         float fa, float pv, int tid0, unsigned epoch) {
+    const int tid = tid0 + ws_opaque_zero(), lane = tid & 63, u = tid >> 5, m = tid & 31;
+    const bool uv = u < X.nu;
+    // ---- predictions, residuals, first-stage targets of all utterances (wavernn.py:195-196) ----
+    if (tid < WFC * WG) {
+        const int row = tid >> 4, uu = tid & 15;
+        const float acc = ((L.pFa[0][tid] + L.pFa[1][tid]) + (L.pFa[2][tid] + L.pFa[3][tid])) +
+                          ((L.pFa[4][tid] + L.pFa[5][tid]) + (L.pFa[6][tid] + L.pFa[7][tid]));
+        const float tt = fpc_tanhf(acc);
+        const float f = tt + tt;  // the "dual" FC is the same Linear summed twice (wavernn.py:89-92)
+        const float r = fa - f;
+        L.fo[uu][row] = f;
+        L.rsa[uu][row] = r;
+        if (row >= 1) L.xs[uu][row - 1] = (double)r;
+    }
+    WSTAMP(25)
+    if (tid == 0) L.n2 = 0;
+    if (tid < (WIN - WFC) * WG) {  // the pitch columns pass through (wavernn.py:178)
+        const int uu = tid / (WIN - WFC), k = WFC + tid % (WIN - WFC);
+        L.x[k * WG + uu] = pv;
+        if (uu == X.slice && uu < X.nu) A.c_in[((size_t)(X.b0 + uu) * A.Lf + frame) * WIN + k] = pv;
+    }
+    lds_barrier();
+    // ---- thresholds (:202,:206): every lane of the utterance's half-wave evaluates the same values ----
+    float sabs = 0.0f;
+    for (int d = 1; d < WFC; ++d) sabs += fabsf(L.rsa[u][d]);
+    const float r0 = L.rsa[u][0];
+    const int i1 = fabsf(r0) > A.l1, i2 = sabs > A.l2;
+    const bool nonfinite = !(fabsf(r0) <= 3.0e38f) || !(sabs <= 3.0e38f);
+    const bool live = uv && A.qtz && !nonfinite;
+    const bool do_scl = live && (i1 || C.scl_lo), do_vq = live && (i2 || C.vq_lo);
+    const bool two = do_vq && i2 && C.S_hi == 2;
+    const int cb0 = i2 ? 0 : 2, N0 = i2 ? C.N_hi0 : C.N_lo;
+    const double* cb0R = i2 ? C.vq_hi0_r : C.vq_lo_r;
+    if (uv && nonfinite && A.qtz && m == 0 && X.slice == u) status_or(err, FPC_ST_NONFINITE);
+    if (two && m == 0) L.list2[__hip_atomic_fetch_add(&L.n2, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)] = u;
+    // ---- first stage: this workgroup's 32 entries against utterance u ----
+    const int e = WNS * m + X.slice;
+    if (do_vq) {
+        const double d0 = e < N0 ? wsd_dist(L.xs[u], L.cbs[cb0][m]) : INFINITY;
+        const int e0 = e < N0 ? e : 0x7fffffff;
+        const int g1 = WOFF_G1 + (u * WNS + X.slice) * SURV;
+        if (!two) {  // the nearest entry is all a 1-stage search returns (vq_func.py:93-95)
+            double d = d0;
+            int ix = e0;
+            hw_argmin(d, ix, lane);
+            if (m == 0) wsd_put(X, g1, epoch, d, ix);
+        } else {  // the half-wave's five best, ranked by counting (ties: the lower entry first)
+            L.dl[u][m] = d0;  // (read back by the same wave: one in-order LDS queue per wave)
+            int rank = 0;
+#pragma unroll 8
+            for (int j = 0; j < WNS; ++j) {
+                const double dj = L.dl[u][j];
+                rank += (dj < d0) | ((dj == d0) & (j < m));
+            }
+            if (rank < SURV) wsd_put(X, g1 + rank, epoch, d0, e0);
+        }
+    }
+    WSTAMP(26)
+    // scalar quantizer of every utterance (scl_quantize, vq_func.py:167-185): codes in LDS, a half-wave per utterance
+    float rq0 = 0.0f;
+    int ix0 = -1;
+    if (do_scl) {
+        const int off = i1 ? 0 : C.n_hi, n = i1 ? C.n_hi : C.n_lo;
+        double bd = INFINITY;
+        int bi = 0x7fffffff;
+        const double v = (double)r0;
+        for (int c = m; c < n; c += WNS) {
+            const double df = v - L.sclc[off + c];
+            const double d = df * df;
+            if (d < bd) {
+                bd = d;
+                bi = c;
+            }
+        }
+        hw_argmin(bd, bi, lane);
+        bi = wsd_clamp(bi, n);
+        rq0 = (float)L.sclc[off + bi];
+        ix0 = bi + (i1 ? 0 : C.n_hi);
+    }
+    WSTAMP(27)
+    // ---- every workgroup's list for utterance u comes in (thread = list of workgroup m) ----
+    double ld[SURV];
+    int li[SURV];
+    wsd_get(X, L, WOFF_G1 + (u * WNS + m) * SURV, do_vq ? (two ? SURV : 1) : 0, epoch, ld, li);
+    WSTAMP(28)
+    int s[SURV] = {0, 0, 0, 0, 0};  // the survivors (1-stage: s[0] = the nearest entry)
+    if (do_vq) {
+        if (!two) {
+            double d = ld[0];
+            int ix = li[0];
+            hw_argmin(d, ix, lane);
+            s[0] = wsd_clamp(ix, N0);
+        } else {  // the five smallest of 32 sorted lists: five rounds of arg-min over the lists' heads, the winner's list popped
+#pragma unroll
+            for (int r = 0; r < SURV; ++r) {
+                double d = ld[0];
+                int ix = li[0];
+                hw_argmin(d, ix, lane);
+                if (ix == li[0] && ix != 0x7fffffff) {
+#pragma unroll
+                    for (int k = 0; k + 1 < SURV; ++k) {
+                        ld[k] = ld[k + 1];
+                        li[k] = li[k + 1];
+                    }
+                    ld[SURV - 1] = INFINITY;
+                    li[SURV - 1] = 0x7fffffff;
+                }
+                s[r] = wsd_clamp(ix, N0);
+            }
+            // second-stage targets: residual of every survivor (vq_func.py:103-108)
+#pragma unroll
+            for (int j = 0; j < (SURV * NDIM + WNS - 1) / WNS; ++j) {
+                const int p = m + WNS * j, k = p / NDIM, d = p - k * NDIM;
+                const int sk = k == 0 ? s[0] : (k == 1 ? s[1] : (k == 2 ? s[2] : (k == 3 ? s[3] : s[4])));  // (no indexed array)
+                if (p < SURV * NDIM) L.xq2[u][k][d] = L.xs[u][d] - cb0R[(size_t)sk * NDIM + d];
+            }
+        }
+    }
+    lds_barrier();
+    WSTAMP(29)
+    // ---- second stage: (utterance, survivor, entry) triples over the threads; the half-wave's best -> granule ----
+    const int n2 = L.n2;
+    for (int p = tid; p < n2 * SURV * WNS; p += NT) {
+        const int slot = p / (SURV * WNS), k = (p - slot * SURV * WNS) >> 5;
+        const int u2 = L.list2[slot];
+        double d = e < C.N_hi1 ? wsd_dist(L.xq2[u2][k], L.cbs[1][m]) : INFINITY;
+        int ix = e < C.N_hi1 ? e : 0x7fffffff;
+        hw_argmin(d, ix, lane);
+        if (m == 0) wsd_put(X, WOFF_G2 + (u2 * WNS + X.slice) * SURV + k, epoch, d, ix);
+    }
+    WSTAMP(30)
+    int w1 = 0, bk = 0;
+    double qd[SURV];
+    int qi[SURV];
+    wsd_get(X, L, WOFF_G2 + (u * WNS + m) * SURV, two ? SURV : 0, epoch, qd, qi);
+    if (two) {
+        double g = 0.0;
+#pragma unroll
+        for (int k = 0; k < SURV; ++k) {  // best entry per survivor over the 32 workgroups, then the head of the merge-insert
+            double d = qd[k];             // (vq_func.py:110-125): a later survivor wins only with a strictly smaller total error
+            int ix = qi[k];
+            hw_argmin(d, ix, lane);
+            if (k == 0 || d < g) {
+                g = d;
+                bk = k;
+                w1 = ix;
+            }
+        }
+        w1 = wsd_clamp(w1, C.N_hi1);
+    }
+    WSTAMP(31)
+    // ---- quantized residual, next input row (:242 / :244-252), outputs ----
+    const int sb = s[0] * (bk == 0) + s[1] * (bk == 1) + s[2] * (bk == 2) + s[3] * (bk == 3) + s[4] * (bk == 4);
+    float rq = 0.0f;  // lane m = row: r_qtz[row]
+    if (m == 0) rq = rq0;
+    if (do_vq && m >= 1 && m < WFC) {
+        const int d = m - 1;
+        const double q = two ? cb0R[(size_t)sb * NDIM + d] + C.vq_hi1_r[(size_t)w1 * NDIM + d] : cb0R[(size_t)s[0] * NDIM + d];
+        rq = (float)q;
+    }
+    const bool owner = X.slice == u && uv;
+    const size_t fi = (size_t)(X.b0 + u) * A.Lf + frame;
+    if (m < WFC) {
+        const float rs = L.rsa[u][m], f = L.fo[u][m];
+        const int ind = m == 0 ? i1 : i2;
+        float rv, ru, cn;
+        if (A.qtz) {
+            rv = rs;  // un-thresholded residual (:197)
+            ru = 0.0f;
+            cn = f + rq;
+        } else {
+            ru = rs * (float)(1 - ind);
+            rv = rs * (float)ind;
+            cn = f + rv;
+        }
+        L.x[m * WG + u] = uv ? cn : 0.0f;
+        if (owner) {
+            A.r[fi * WFC + m] = rv;
+            A.r_qtz[fi * WFC + m] = rq;
+            A.r_under[fi * WFC + m] = ru;
+            A.c_in[fi * WIN + m] = cn;
+        }
+    }
+    if (owner && m == 0) {
+        A.ind1[fi] = (float)i1;
+        A.ind2[fi] = (float)i2;
+        int o0 = ix0, o1 = -1, o2 = -1, o3 = -1;
+        if (do_vq) {
+            if (i2) {
+                o1 = two ? sb : s[0];
+                o2 = two ? w1 : -1;
+            } else {
+                o3 = s[0];
+            }
+        }
+        if (nonfinite) o0 = o1 = o2 = o3 = -2;
+        *reinterpret_cast<int4*>(&A.idx[fi * 4]) = make_int4(o0, o1, o2, o3);
+    }
+}
+
+__global__ __launch_bounds__(NT) void k_encode_wsd(const PredDev P, const CbDev C, const EncArgs A, const WsArgs S) {
+    __shared__ WsLds L;
+    const int tid = threadIdx.x;
+    int group, slice;
+    if (!ws_role(S.ngroups, group, slice)) return;
+    WsCtx X = ws_ctx(S, group, slice);
+    X.own = -1;  // (the output layer runs for all utterances on every workgroup: ws_foreground<false, true>)
+    WsRegs R;
+    for (int i = tid; i < WH1 * WG; i += NT) L.h1[i] = 0.0f;  // h = None -> zeros (wavernn.py:182)
+    for (int i = tid; i < WH2 * WG; i += NT) L.h2[i] = 0.0f;
+    for (int i = tid; i < WIN * WG; i += NT) L.x[i] = 0.0f;   // c_in[:, 0, :] is all zero (wavernn.py:177-178)
+    for (int k = tid; k < C.n_hi; k += NT) L.sclc[k] = C.scl_hi[k];
+    for (int k = tid; k < C.n_lo; k += NT) L.sclc[C.n_hi + k] = C.scl_lo[k];
+    for (int i = tid; i < 3 * WNS * (NDIM + 1); i += NT) {  // this workgroup's entries 32 m + slice of the three books
+        const int cb = i / (WNS * (NDIM + 1)), r = i - cb * WNS * (NDIM + 1), mm = r / (NDIM + 1), d = r - mm * (NDIM + 1);
+        const double* src = cb == 0 ? C.vq_hi0_r : (cb == 1 ? C.vq_hi1_r : C.vq_lo_r);
+        const int N = cb == 0 ? C.N_hi0 : (cb == 1 ? C.N_hi1 : C.N_lo), e = WNS * mm + slice;
+        L.cbs[cb][mm][d] = (src != nullptr && e < N && d < NDIM) ? src[(size_t)e * NDIM + d] : 0.0;
+    }
+    __syncthreads();
+    ws_prologue(P, X, L, R, S, tid);
+    int fg_epoch = 0;
+    int i = 0;
+    WPROF_INIT()
+    for (; i < A.Lf; ++i) {
+        const unsigned epoch = (unsigned)i + 1u;
+        // this frame's feature rows of every utterance of the group: thread = (row, utterance) for the residuals, and the
+        // pitch columns, which pass through to the next input (wavernn.py:178): fetched before the step
+        float fa = 0.0f, pv = 0.0f;
+        if (tid < WFC * WG) {
+            const int row = tid >> 4, uu = tid & 15;
+            if (uu < X.nu) fa = A.feat[((size_t)(X.b0 + uu) * A.Lf + i) * WIN + row];
+        }
+        if (tid < (WIN - WFC) * WG) {
+            const int uu = tid / (WIN - WFC), k = WFC + tid % (WIN - WFC);
+            if (uu < X.nu) pv = A.feat[((size_t)(X.b0 + uu) * A.Lf + i) * WIN + k];
+        }
+        if (tid < WFGT) {
+            __builtin_amdgcn_s_setprio(FPC_FG_PRIO);
+            (void)ws_foreground<false, true>(X, L, R, i, tid, fg_epoch);
+            __builtin_amdgcn_s_setprio(0);
+        } else {
+            (void)ws_background(X, L, R, i, i + 1 == A.Lf, tid - WFGT);
+        }
+        WBSTAMP(19)
+        lds_barrier();  // both roles meet: the tail takes the whole workgroup
+        WSTAMP(20)
+        wsd_tail(X, L, C, A, S.err, i, fa, pv, tid, epoch);
+        WSTAMP(21)
+        if (ws_frame_dead(L, tid)) break;
+        WSTAMP(22)
+    }
+    WPROF_DUMP(A.Lf)
+    if (i < A.Lf && slice < X.nu) encode_poison(P, A, X.b0 + slice, i, tid);
+}
