@@ -104,8 +104,7 @@ struct __attribute__((aligned(16))) WsLds : SearchLds {
     double xs[WG][NDIM + 1];       // first-stage targets
     double xq2[WG][SURV][NDIM + 1];  // second-stage targets
     double dl[WG][WNS];            // a half-wave's 32 distances (local ranking, heads of the gathered lists)
-    int list2[WG];                 // the utterances with a 2-stage search in this frame
-    int n2;
+
 #ifdef FPC_WS_PROF
     long long wprof[32], wlast, wlast_bg;  // diagnostic builds: cycles per stage, foreground [0..13) + [19..24), background [13..19)
 #endif

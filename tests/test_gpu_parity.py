@@ -1126,13 +1126,17 @@ def test_weights_stationary_kernels_equal_row_split_forms(torch_cuda, model, syn
             monkeypatch.delenv("FPC_PRED_WS")
             monkeypatch.delenv("FPC_PRED_SPLIT")
             monkeypatch.delenv("FPC_PRED_DF")
-            for fast in ("1", "0"):
+            # the encoder's tail in both forms: distributed over the group's 32 workgroups (the shipped one), and on the
+            # utterance's own pair of workgroups (FPC_WS_TAIL=pair)
+            for fast, tail in (("1", ""), ("0", ""), ("1", "pair"), ("0", "pair")):
                 monkeypatch.setenv("FPC_FAST_HOP", fast)
+                monkeypatch.setenv("FPC_WS_TAIL", tail)
                 got = run(feat, cfg)
                 assert len(got) == len(ref)
                 for k, (a, b) in enumerate(zip(ref, got)):
-                    assert np.array_equal(a, b), (B, L, name, fast, k)
+                    assert np.array_equal(a, b), (B, L, name, fast, tail, k)
             monkeypatch.delenv("FPC_FAST_HOP")
+            monkeypatch.delenv("FPC_WS_TAIL")
     # ... and the oracle itself (one partly filled group, the reference's four codebooks)
     feat = synth.predictor_features(5, 50, utt0=7100)
     c = synth.codebooks()
