@@ -264,9 +264,12 @@ __device__ __forceinline__ void wsd_tail(const WsCtx& X, WsLds& L, const CbDev& 
         double bd = INFINITY;
         int bkey = 0x7fffffff;
         if (e < C.N_hi1) {
+            double c2[NDIM + 1];  // (this thread's entry stays in registers across the five targets)
+#pragma unroll
+            for (int j = 0; j < NDIM + 1; ++j) c2[j] = L.cbs[1][m][j];
 #pragma unroll 1
             for (int k = 0; k < SURV; ++k) {
-                const double d = wsd_dist(L.xq2[u][k], L.cbs[1][m]);
+                const double d = ws_dist(L.xq2[u][k], c2);
                 if (d < bd) {  // (ascending k: strict < keeps the earlier survivor)
                     bd = d;
                     bkey = k * 2048 + e;
