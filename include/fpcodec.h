@@ -119,7 +119,8 @@ FPC_API void fpc_predictor_destroy(fpc_predictor* p);
  *    for the handle's previous launch.  Creating and destroying handles is thread-safe; calls on one handle are not.
  * Environment: FPC_PRED_WS=0 never the weights-stationary kernels; FPC_PRED_SPLIT=0 one workgroup per utterance, 2|4|8
  * exactly that many (either selects the row-split kernels); FPC_PRED_DF=0 the phase kernels; FPC_FAST_HOP=0 the
- * write-through exchange everywhere; FPC_SPIN_LIMIT_US / FPC_TEST_WITHHOLD_PUBLISH are test hooks (a shorter bound; the
+ * write-through exchange everywhere; FPC_WS_TAIL=pair the encoder's search on an owner + helper workgroup per utterance
+ * instead of distributed over the group (the tests' second form, same bits); FPC_SPIN_LIMIT_US / FPC_TEST_WITHHOLD_PUBLISH are test hooks (a shorter bound; the
  * last workgroup of utterance 0 / group 0 never publishes). */
 
 /* Synchronises the device and returns what the launches on the handle have reported: FPC_OK, FPC_ERR_TIMEOUT (a
