@@ -56,7 +56,7 @@ constexpr int WOFF_HELLO = 0, WOFF_H1 = WNS, WOFF_H2 = WOFF_H1 + WNS * WQ1, WOFF
               WGRANULES = WOFF_G2 + WG * WNS * SURV;  // 8 320 granules = 133 120 bytes
 static_assert(NT == 512, "predictor_ws.h is written for 8 waves per workgroup");
 static_assert(WH1 / 4 == 96 && WH2 / 2 == 64 && WFC == NDIM + 1, "production shape");
-enum { WSIG_A = 0, WSIG_B, WSIG_H1, WSIG_H2, WSIG_P1, WSIG_P2, WSIG_C, WSIG_I, WSIG_X, WSIG_FG, WNSIG };
+enum { WSIG_A = 0, WSIG_B, WSIG_H1, WSIG_H2, WSIG_P1, WSIG_P2, WSIG_C, WSIG_I, WSIG_X, WSIG_FG, WSIG_FB, WNSIG };
 
 struct WsArgs {
     int B, ngroups;
@@ -76,6 +76,7 @@ struct __attribute__((aligned(16))) WsLds : SearchLds {
     float pC[4][256];         // [segment][(gate * 4 + unit) * 16 + utterance]
     float pB[2][256];
     float pF[8][2][16];       // [segment][tile][row in tile]: the owned utterance only
+    float pFl[2][8][2][16];   // the same for the forward's off-chain output layer, by frame parity
     float fo[WG][WIN];        // predictions [utterance][row < 18]
     float xn[MAX_IN];         // the owner's next input row
     float w1i[3 * WIN * WU1];  // [gate][k][unit]
@@ -223,6 +224,20 @@ __device__ __forceinline__ bool ws_poll(const WsCtx& X, WsLds& L, const int (&gi
     }
 }
 
+// ws_poll with work of the caller's between the first round's loads and their check (the work rides on the L2 round trip)
+template <int N, class F>
+__device__ __forceinline__ bool ws_poll_over(const WsCtx& X, WsLds& L, const int (&gi)[N], unsigned epoch, u32x4 (&v)[N], F&& mid) {
+#pragma unroll
+    for (int j = 0; j < N; ++j) v[j] = __builtin_amdgcn_raw_buffer_load_b128(X.rs, (gi[j] < 0 ? 0 : gi[j]) * 16, 0, 16);
+    mid();
+    bool ok = true;
+#pragma unroll
+    for (int j = 0; j < N; ++j) ok &= gi[j] < 0 || v[j].x == epoch;
+    if (__all(ok)) return true;
+    asm volatile("" ::: "memory");
+    return ws_poll<N>(X, L, gi, epoch, v);
+}
+
 __device__ __forceinline__ bool ws_role(int ngroups, int& group, int& slice) {
     const int i = blockIdx.x, x = i % 8, m = i / 8;
     slice = m % WNS;
@@ -268,7 +283,8 @@ __device__ __forceinline__ void ws_load_weights(const PredDev& P, WsLds& L, WsRe
         for (int j = 0; j < 24; ++j) R.wA[g][j] = 0.0f;
     R.bB = R.bI = R.bC = 0.0f;
     R.bI3[0] = R.bI3[1] = R.bI3[2] = 0.0f;
-    R.bF[0] = R.bF[1] = 0.0f;
+    R.bF[0] = P.fcb[c];
+    R.bF[1] = P.fcb[16 + (lane & 1)];  // (rows 16, 17 are evaluated by lanes 0-15: row = 16 + (lane & 1))
     R.bF16[0] = P.fcb[16];
     R.bF16[1] = P.fcb[17];
     if (wave >= WFG) {
@@ -293,11 +309,7 @@ __device__ __forceinline__ void ws_load_weights(const PredDev& P, WsLds& L, WsRe
         }
     } else {
         if (fw < 3 && c < WU1) R.bI = P.b1i[fw * WH1 + WU1 * slice + c];
-        if (fw == 0) {
-            if (c < 12) R.bC = P.b2i[(c / WU2) * WH2 + WU2 * slice + (c % WU2)];
-            R.bF[0] = P.fcb[c];
-            R.bF[1] = P.fcb[16 + (lane & 1)];  // (rows 16, 17 are evaluated by lanes 0-15: row = 16 + (lane & 1))
-        }
+        if (fw == 0 && c < 12) R.bC = P.b2i[(c / WU2) * WH2 + WU2 * slice + (c % WU2)];
     }
 }
 
@@ -392,15 +404,17 @@ __device__ __forceinline__ void ws_I(WsLds& L, float bias, int g, int lane, int 
     ws_put(L.pI[buf][g], lane, acc);
 }
 // C = W2i h1: foreground wave fw = input segment of 96 (one chain of 24 dependent MFMAs: operands read ahead)
-__device__ __forceinline__ void ws_C(WsLds& L, const WsRegs& R, int fw, int lane) {
+// (ws_C_weights: this lane's B operands, read while hop 1 is still in the air)
+__device__ __forceinline__ void ws_C_weights(WsLds& L, int fw, int lane, f32x4ws (&w)[6]) {
     const int c = lane & 15, q = lane >> 4, cc = c < 12 ? c : 11;
-    f32x4ws acc = {R.bC, R.bC, R.bC, R.bC};
-    const float* hs = L.h1 + 96 * fw * WG + lane;
     const f32x4ws* ws = reinterpret_cast<const f32x4ws*>(L.w2i) + (6 * fw * 4 + q) * 12 + cc;  // + 48 per block of 16 inputs
-    float a[24];
-    f32x4ws w[6];
 #pragma unroll
     for (int kb = 0; kb < 6; ++kb) w[kb] = ws[48 * kb];
+}
+__device__ __forceinline__ void ws_C(WsLds& L, const WsRegs& R, int fw, int lane, const f32x4ws (&w)[6]) {
+    f32x4ws acc = {R.bC, R.bC, R.bC, R.bC};
+    const float* hs = L.h1 + 96 * fw * WG + lane;
+    float a[24];
 #pragma unroll
     for (int j = 0; j < 24; ++j) a[j] = hs[64 * j];
 #pragma unroll
@@ -452,9 +466,68 @@ __device__ __forceinline__ void ws_F(WsLds& L, const WsRegs& R, int fw, int lane
     }
 }
 
+// The teacher-forced forward's output layer, off the chain: nothing of frame t + 1 depends on the prediction of frame t, so
+// background waves 1-3 evaluate it behind A(t + 1), when hop 2 of frame t is over -- h2(t) stays whole in LDS until the GRU2
+// gates of frame t + 1, which come behind hop 1 of that frame, i.e. behind these waves' own gather -- while the foreground
+// waits for hop 2 and starts the next frame (its SIMDs run no matrix product then).
+// Wave w3 = 0, 1, 2: input segments {0, 1, 2}, {3, 4, 5}, {6, 7} (independent chains of four MFMAs), rows 16, 17 on wave 2.
+__device__ __forceinline__ void ws_F_late(WsLds& L, const WsRegs& R, float (&pF)[8][2][16], int w3, int lane, int own) {
+    const int c = lane & 15, q = lane >> 4;
+    const int s0 = 3 * w3, ns = w3 == 2 ? 2 : 3;
+    float hv[3][4], wv[3][4];
+#pragma unroll
+    for (int s2 = 0; s2 < 3; ++s2) {
+        const int sg = s0 + (s2 < ns ? s2 : 0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float h = L.h2[(16 * sg + 4 * j) * WG + lane];
+            hv[s2][j] = h > 0.0f ? h : 0.0f;
+            wv[s2][j] = L.fcw[(16 * sg + 4 * j + q) * WFC + c];
+        }
+    }
+    float rh[16], rw[16];
+    const int row = 16 + (lane & 1), rsg = (lane >> 1) & 7;
+    if (w3 == 2) {
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            rh[k] = L.h2[(16 * rsg + k) * WG + own];
+            rw[k] = L.fcw[(16 * rsg + k) * WFC + row];
+        }
+    }
+#pragma unroll
+    for (int s2 = 0; s2 < 3; ++s2) {
+        if (s2 < ns) {
+            const int sg = s0 + s2;
+            const float b0 = sg == 0 ? R.bF[0] : 0.0f;
+            f32x4ws a0 = {b0, b0, b0, b0};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) a0 = ws_mfma(hv[s2][j], wv[s2][j], a0);
+            if (q == (own >> 2)) {
+                const int r = own & 3;
+                pF[sg][0][c] = r == 0 ? a0[0] : (r == 1 ? a0[1] : (r == 2 ? a0[2] : a0[3]));
+            }
+        }
+    }
+    if (w3 == 2 && lane < 2 * 8) {
+        float a = rsg == 0 ? R.bF[1] : 0.0f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) a = fmaf(rh[k] > 0.0f ? rh[k] : 0.0f, rw[k], a);
+        pF[rsg][1][row - 16] = a;
+    }
+}
+// ... and its last step for row `row` < 18 (the segment sums are complete: every wave of ws_F_late has passed a barrier since)
+__device__ __forceinline__ float ws_F_out(const float (&pF)[8][2][16], int row) {
+    const int tile = row >> 4, o = row & 15;
+    const float acc = ((pF[0][tile][o] + pF[1][tile][o]) + (pF[2][tile][o] + pF[3][tile][o])) +
+                      ((pF[4][tile][o] + pF[5][tile][o]) + (pF[6][tile][o] + pF[7][tile][o]));
+    const float tt = fpc_tanhf(acc);
+    return tt + tt;  // the "dual" FC is the same Linear summed twice (wavernn.py:89-92)
+}
+
 // hop 1 gather by six waves (foreground 1-3, background 1-3): p < 384, six granules each; the waves of SIMD 0 have other
 // work meanwhile (background wave 0 computes B(t), the foreground's wave 0 must not take issue slots from it)
-__device__ __forceinline__ bool ws_gather1(const WsCtx& X, WsLds& L, int p, unsigned epoch, bool guard_A, int t) {
+template <class F>
+__device__ __forceinline__ bool ws_gather1(const WsCtx& X, WsLds& L, int p, unsigned epoch, bool guard_A, int t, F&& mid) {
     constexpr int NG = (WNS * WQ1 + 383) / 384;
     int gi[NG];
 #pragma unroll
@@ -463,7 +536,7 @@ __device__ __forceinline__ bool ws_gather1(const WsCtx& X, WsLds& L, int p, unsi
         gi[j] = (i < WNS * WQ1 && i / WQ1 != X.slice) ? WOFF_H1 + i : -1;
     }
     u32x4 v[NG];
-    if (!ws_poll<NG>(X, L, gi, epoch, v)) return false;
+    if (!ws_poll_over<NG>(X, L, gi, epoch, v, mid)) return false;
     // (a background wave may be here before its neighbours have finished A(t) on the old image)
     if (guard_A && !df_wait(&L.sig[WSIG_A], 3 * (t + 1), &L.dead)) return false;
 #pragma unroll
@@ -476,6 +549,9 @@ __device__ __forceinline__ bool ws_gather1(const WsCtx& X, WsLds& L, int p, unsi
         }
     }
     return true;
+}
+__device__ __forceinline__ bool ws_gather1(const WsCtx& X, WsLds& L, int p, unsigned epoch, bool guard_A, int t) {
+    return ws_gather1(X, L, p, epoch, guard_A, t, [] {});
 }
 // hop 2 gather by the two waves of SIMD 0 (foreground wave 0 and background wave 0): p < 128, six granules each
 __device__ __forceinline__ bool ws_gather2(const WsCtx& X, WsLds& L, int p, unsigned epoch) {
@@ -507,7 +583,8 @@ __device__ __forceinline__ bool ws_gather2(const WsCtx& X, WsLds& L, int p, unsi
 // EARLY_I (the teacher-forced forward): I(t) has been computed one frame ahead by background wave 0 (k_forward_ws)
 __device__ __forceinline__ void wsd_F(WsLds& L, const WsRegs& R, int fw, int lane, int ft);  // predictor_wsd.h
 // FC_ALL (the distributed encoder tail): the output layer's segment sums of all 16 utterances, no prediction formed here
-template <bool EARLY_I = false, bool FC_ALL = false>
+// FC_LATE (the teacher-forced forward): no output layer here -- the background evaluates it off the chain (ws_background)
+template <bool EARLY_I = false, bool FC_ALL = false, bool FC_LATE = false>
 __device__ __forceinline__ bool ws_foreground(const WsCtx& X, WsLds& L, const WsRegs& R, int t, int ft0, int& fg_epoch) {
     const int ft = ft0 + ws_opaque_zero();
     const int fw = ft0 >> 6, lane = ft & 63;
@@ -548,9 +625,11 @@ __device__ __forceinline__ bool ws_foreground(const WsCtx& X, WsLds& L, const Ws
         df_signal(&L.sig[WSIG_H1]);
     }
     WSTAMP(3)
+    f32x4ws wC[6];
+    ws_C_weights(L, fw, lane, wC);
     if (!df_wait(&L.sig[WSIG_H1], 6 * (t + 1), &L.dead)) return false;  // h1(t) whole in LDS
     WSTAMP(4)
-    ws_C(L, R, fw, lane);
+    ws_C(L, R, fw, lane, wC);
     df_signal(&L.sig[WSIG_C]);  // (A(t+1) starts behind C(t): side by side on one matrix pipe the chain's product took 3.4k cycles)
     ws_fg_sync(L, fg_epoch);
     WSTAMP(5)
@@ -586,6 +665,7 @@ __device__ __forceinline__ bool ws_foreground(const WsCtx& X, WsLds& L, const Ws
     WSTAMP(9)
     if (FC_ALL) {
         wsd_F(L, R, fw, lane, ft);
+    } else if (FC_LATE) {
     } else if (X.own >= 0) {  // the output layer: only the workgroup that owns an utterance needs its prediction
         ws_F(L, R, fw, lane, X.own);
         ws_fg_sync(L, fg_epoch);
@@ -603,8 +683,10 @@ __device__ __forceinline__ bool ws_foreground(const WsCtx& X, WsLds& L, const Ws
 }
 
 // BACKGROUND, frame t: wave 0: B(t) and half of hop 2's gather; waves 1-3: half of hop 1's gather, then A(t+1)
-template <bool EARLY_I = false>
-__device__ __forceinline__ bool ws_background(const WsCtx& X, WsLds& L, const WsRegs& R, int t, bool last, int bt) {
+// FC_LATE: y_late = the owned utterance's output row of frame t
+template <bool EARLY_I = false, bool FC_LATE = false>
+__device__ __forceinline__ bool ws_background(const WsCtx& X, WsLds& L, const WsRegs& R, int t, bool last, int bt,
+                                              float* y_late = nullptr) {
     const int bw = bt >> 6, lane = (bt + ws_opaque_zero()) & 63;
     if (!df_wait(&L.sig[WSIG_P1], WFG * (t + 1), &L.dead)) return false;
     WBSTAMP(13)
@@ -634,6 +716,15 @@ __device__ __forceinline__ bool ws_background(const WsCtx& X, WsLds& L, const Ws
     if (!last) ws_A(L, R, bw, lane);
     df_signal(&L.sig[WSIG_A]);
     WBSTAMP(16)
+    if (FC_LATE && X.own >= 0) {
+        if (!df_wait(&L.sig[WSIG_H2], 2 * (t + 1), &L.dead)) return false;  // h2(t) whole in LDS
+        ws_F_late(L, R, L.pFl[t & 1], bw - 1, lane, X.own);
+        df_signal(&L.sig[WSIG_FB]);
+        if (bw == 3) {
+            if (!df_wait(&L.sig[WSIG_FB], 3 * (t + 1), &L.dead)) return false;
+            if (lane < WFC) y_late[lane] = ws_F_out(L.pFl[t & 1], lane);
+        }
+    }
     return true;
 }
 
@@ -700,12 +791,19 @@ __global__ __launch_bounds__(NT) void k_forward_ws(const PredDev P, const float*
     if (tid == 0) L.sig[WSIG_I] = 1;
     __syncthreads();
     WPROF_INIT()
-    auto x_row = [&](int t, float (&xr)[2]) {  // this thread's two values of the input rows of frame t (0 beyond the end)
+    // this thread's two values of an input row of the group: where they come from (frame 0) and where they go in the image
+    const float* xsrc[2];
+    int xdst[2];
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int i = tid + WFGT * j, u = i / WIN, k = i - u * WIN;
-            xr[j] = (t < Lf && i < WIN * WG && u < X.nu) ? x[((size_t)(X.b0 + u) * Lf + t) * WIN + k] : 0.0f;
-        }
+    for (int j = 0; j < 2; ++j) {
+        const int i = tid + WFGT * j, u = i / WIN, k = i - u * WIN;
+        const bool have = tid < WFGT && i < WIN * WG;
+        xsrc[j] = (have && u < X.nu) ? x + (size_t)(X.b0 + u) * Lf * WIN + k : nullptr;
+        xdst[j] = have ? k * WG + u : -1;
+    }
+    auto x_row = [&](int t, float (&xr)[2]) {  // (0 beyond the end and for the utterances a part-filled group lacks)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) xr[j] = (t < Lf && xsrc[j] != nullptr) ? xsrc[j][t * WIN] : 0.0f;
     };
     if (tid < WFGT) {
         __builtin_amdgcn_s_setprio(FPC_FG_PRIO);
@@ -716,20 +814,17 @@ __global__ __launch_bounds__(NT) void k_forward_ws(const PredDev P, const float*
             // x(t+1) into LDS (x(t) is not read any more: I(t) is done), then the row after it on its way
             if (!df_wait(&L.sig[WSIG_I], t + 1, &L.dead)) break;
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int i = tid + WFGT * j, u = i / WIN, k = i - u * WIN;
-                if (i < WIN * WG) L.x[k * WG + u] = xa[j];
-            }
+            for (int j = 0; j < 2; ++j)
+                if (xdst[j] >= 0) L.x[xdst[j]] = xa[j];
             df_signal(&L.sig[WSIG_X]);
             x_row(t + 2, xa);
-            if (!ws_foreground<true>(X, L, R, t, tid, fg_epoch)) break;
-            if (owner && tid < WFC) y[((size_t)(X.b0 + slice) * Lf + t) * WFC + tid] = L.fo[slice][tid];
+            if (!ws_foreground<true, false, true>(X, L, R, t, tid, fg_epoch)) break;
             WSTAMP(12)
         }
         __builtin_amdgcn_s_setprio(0);
     } else {
         for (int tb = 0; tb < Lf; ++tb)
-            if (!ws_background<true>(X, L, R, tb, tb + 1 == Lf, tid - WFGT)) break;
+            if (!ws_background<true, true>(X, L, R, tb, tb + 1 == Lf, tid - WFGT, y + ((size_t)(X.b0 + slice) * Lf + tb) * WFC)) break;
     }
     WPROF_DUMP(Lf)
     __syncthreads();

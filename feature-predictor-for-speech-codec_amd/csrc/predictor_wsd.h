@@ -125,7 +125,7 @@ __device__ __forceinline__ void wsd_F(WsLds& L, const WsRegs& R, int fw, int lan
         for (int j = 0; j < 4; ++j) a0 = ws_mfma(hv[s2][j], wv[s2][j], a0);
         ws_put(L.pFa[sg], lane, a0);  // [row c][utterances 4 q .. 4 q + 3]
     }
-    float a = rsg == 0 ? R.bF16[row - 16] : 0.0f;
+    float a = rsg == 0 ? (row == 16 ? R.bF16[0] : R.bF16[1]) : 0.0f;  // (no indexed access: the struct stays in registers)
 #pragma unroll
     for (int k = 0; k < 16; ++k) a = fmaf(rh[k] > 0.0f ? rh[k] : 0.0f, rw[k], a);
     L.pFa[rsg][row * WG + ru] = a;
