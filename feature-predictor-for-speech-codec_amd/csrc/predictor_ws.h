@@ -105,6 +105,7 @@ struct __attribute__((aligned(16))) WsLds : SearchLds {
     double xs[WG][NDIM + 1];       // first-stage targets
     double xq2[WG][SURV][NDIM + 1];  // second-stage targets
     double dl[WG][WNS];            // a half-wave's 32 distances (local ranking, heads of the gathered lists)
+    unsigned dh[WG][WNS];          // ... and their high words
 
 #ifdef FPC_WS_PROF
     long long wprof[32], wlast, wlast_bg;  // diagnostic builds: cycles per stage, foreground [0..13) + [19..24), background [13..19)
@@ -195,6 +196,12 @@ __device__ __forceinline__ void ws_store(const WsCtx& X, int granule, unsigned e
 // wait was given up (timeout, or the workgroup is dead already)
 template <int N>
 __device__ __forceinline__ bool ws_poll(const WsCtx& X, WsLds& L, const int (&gi)[N], unsigned epoch, u32x4 (&v)[N]) {
+    {  // (nothing wanted by any lane: no round trip)
+        bool none = true;
+#pragma unroll
+        for (int j = 0; j < N; ++j) none &= gi[j] < 0;
+        if (__all(none)) return true;
+    }
     unsigned spins = 0;
     unsigned long long t0 = 0, last = 0;
 #if FPC_WS_POLL_DELAY
@@ -252,7 +259,8 @@ struct WsRegs {
                        // encoder's distributed searches; the chain's other weights stay in LDS)
     float bA[3];       // background wave 1 (input segment 0): b_hh of GRU1
     float bB;          // b_hh of GRU2 (background wave 0)
-    float bI;          // foreground wave w < 3: b_ih of GRU1, gate w
+    float bI;          // foreground wave w < 3: b_ih of GRU1, gate w (the forward's first frame)
+    float bIo;         // foreground wave w, column c < 9 of its own input tile: gate c / 3, unit 3 w + c % 3 (ws_I_own)
     float bI3[3];      // background wave 0: all three gates (teacher-forced forward: I(t+1) off the chain)
     float bC;          // foreground wave 0: b_ih of GRU2
     float bF[2];       // foreground wave 0: output bias, tiles 0 and 1
@@ -281,7 +289,7 @@ __device__ __forceinline__ void ws_load_weights(const PredDev& P, WsLds& L, WsRe
     for (int g = 0; g < 4; ++g)
 #pragma unroll
         for (int j = 0; j < 24; ++j) R.wA[g][j] = 0.0f;
-    R.bB = R.bI = R.bC = 0.0f;
+    R.bB = R.bI = R.bIo = R.bC = 0.0f;
     R.bI3[0] = R.bI3[1] = R.bI3[2] = 0.0f;
     R.bF[0] = P.fcb[c];
     R.bF[1] = P.fcb[16 + (lane & 1)];  // (rows 16, 17 are evaluated by lanes 0-15: row = 16 + (lane & 1))
@@ -309,6 +317,7 @@ __device__ __forceinline__ void ws_load_weights(const PredDev& P, WsLds& L, WsRe
         }
     } else {
         if (fw < 3 && c < WU1) R.bI = P.b1i[fw * WH1 + WU1 * slice + c];
+        if (c < 9) R.bIo = P.b1i[(c / 3) * WH1 + WU1 * slice + 3 * fw + c % 3];
         if (fw == 0 && c < 12) R.bC = P.b2i[(c / WU2) * WH2 + WU2 * slice + (c % WU2)];
     }
 }
@@ -402,6 +411,18 @@ __device__ __forceinline__ void ws_I(WsLds& L, float bias, int g, int lane, int 
 #pragma unroll
     for (int j = 0; j < WIN / 4; ++j) acc = ws_mfma(xs[64 * j], ws[4 * WU1 * j], acc);
     ws_put(L.pI[buf][g], lane, acc);
+}
+// The closed loop's form of I (x(t) is the previous frame's result: I is on the chain): foreground wave fw evaluates the
+// columns ITS gate threads need -- 3 gates x units 3 fw .. 3 fw + 2 = 9 columns of one tile -- so the gates follow in the same
+// wave without a barrier of the role.  Sums at p[(gate * 3 + unit - 3 fw) * 16 + utterance], p = the wave's 144 floats.
+__device__ __forceinline__ void ws_I_own(WsLds& L, float bias, int fw, int lane, float* p) {
+    const int c = lane & 15, q = lane >> 4, cc = c < 9 ? c : 8;
+    f32x4ws acc = {bias, bias, bias, bias};
+    const float* xs = L.x + lane;
+    const float* ws = L.w1i + ((cc / 3) * WIN + q) * WU1 + 3 * fw + cc % 3;
+#pragma unroll
+    for (int j = 0; j < WIN / 4; ++j) acc = ws_mfma(xs[64 * j], ws[4 * WU1 * j], acc);
+    if (c < 9) *reinterpret_cast<f32x4ws*>(&p[c * 16 + 4 * q]) = acc;
 }
 // C = W2i h1: foreground wave fw = input segment of 96 (one chain of 24 dependent MFMAs: operands read ahead)
 // (ws_C_weights: this lane's B operands, read while hop 1 is still in the air)
@@ -592,8 +613,7 @@ __device__ __forceinline__ bool ws_foreground(const WsCtx& X, WsLds& L, const Ws
     if (EARLY_I) {
         if (!df_wait(&L.sig[WSIG_I], t + 1, &L.dead)) return false;
     } else {
-        if (fw < 3) ws_I(L, R.bI, fw, lane, t & 1);
-        ws_fg_sync(L, fg_epoch);
+        ws_I_own(L, R.bIo, fw, lane, &L.pI[0][0][0] + 144 * fw);
     }
     WSTAMP(0)
     if (!df_wait(&L.sig[WSIG_A], 3 * (t + 1), &L.dead)) return false;  // A(t): prologue, then one round per frame
@@ -606,9 +626,12 @@ __device__ __forceinline__ bool ws_foreground(const WsCtx& X, WsLds& L, const Ws
             const float ghr = (L.pA[0][0][v] + L.pA[1][0][v]) + (L.pA[2][0][v] + L.pA[3][0][v]);
             const float ghz = (L.pA[0][1][v] + L.pA[1][1][v]) + (L.pA[2][1][v] + L.pA[3][1][v]);
             const float ghn = (L.pA[0][2][v] + L.pA[1][2][v]) + (L.pA[2][2][v] + L.pA[3][2][v]);
-            const float r = fpc_sigmoidf(L.pI[t & 1][0][v] + ghr);
-            const float z = fpc_sigmoidf(L.pI[t & 1][1][v] + ghz);
-            const float n = fpc_tanhf(fmaf(r, ghn, L.pI[t & 1][2][v]));
+            // (I: by gate tile a frame ahead, or this wave's own tile -- read back by the wave that wrote it)
+            const float* pi = EARLY_I ? &L.pI[t & 1][0][v] : &L.pI[0][0][0] + 144 * fw + lane;
+            constexpr int PG = EARLY_I ? 256 : 48;
+            const float r = fpc_sigmoidf(pi[0] + ghr);
+            const float z = fpc_sigmoidf(pi[PG] + ghz);
+            const float n = fpc_tanhf(fmaf(r, ghn, pi[2 * PG]));
             const float hp = L.h1[base + lane];
             L.h1[base + lane] = fmaf(z, hp - n, n);
         }

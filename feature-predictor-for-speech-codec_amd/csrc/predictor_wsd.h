@@ -26,7 +26,34 @@
 // read from that lane (a ballot and two scalar lane reads); otherwise the smallest index among the holders by a second pass.
 // (Three 32-bit passes over the distance's words instead of the float64 pass were measured slower: the passes are chains of
 // dependent DPP steps, and there would be three of them.)
+// Fast path first: distances are >= +0, so their bit patterns order like the values and the HIGH WORDS order them weakly:
+// one pass of 32-bit minima (one DPP-fused instruction a step), and where exactly one lane of each half holds the smallest
+// high word that lane holds the strictly smallest distance -- its (distance, index) is read out by lane number.  Two
+// distances that agree in sign, exponent and 20 mantissa bits (or a half that is all +inf) take the float64 passes below.
 __device__ __forceinline__ void hw_argmin(double& d, int& i, int lane) {
+    {
+        const unsigned long long bits = (unsigned long long)__double_as_longlong(d);
+        const unsigned hi = (unsigned)(bits >> 32), lo = (unsigned)bits;
+        unsigned h = hi;
+        h = min(h, (unsigned)dpp_mov_i32<0xB1, 0xf>((int)h));
+        h = min(h, (unsigned)dpp_mov_i32<0x4E, 0xf>((int)h));
+        h = min(h, (unsigned)dpp_mov_i32<0x141, 0xf>((int)h));
+        h = min(h, (unsigned)dpp_mov_i32<0x140, 0xf>((int)h));
+        h = min(h, (unsigned)dpp_mov_i32<0x142, 0xa>((int)h));
+        const unsigned h0 = (unsigned)__builtin_amdgcn_readlane((int)h, 31), h1 = (unsigned)__builtin_amdgcn_readlane((int)h, 63);
+        const bool up = lane >= 32;
+        const unsigned long long bal = __ballot(hi == (up ? h1 : h0));
+        const unsigned b0 = (unsigned)bal, b1 = (unsigned)(bal >> 32);
+        if (__popc(b0) <= 1 && __popc(b1) <= 1) {  // (wave-uniform)
+            const int l0 = b0 != 0u ? __ffs((int)b0) - 1 : 0, l1 = 32 + (b1 != 0u ? __ffs((int)b1) - 1 : 0);
+            const unsigned lo0 = (unsigned)__builtin_amdgcn_readlane((int)lo, l0), hi0 = (unsigned)__builtin_amdgcn_readlane((int)hi, l0);
+            const unsigned lo1 = (unsigned)__builtin_amdgcn_readlane((int)lo, l1), hi1 = (unsigned)__builtin_amdgcn_readlane((int)hi, l1);
+            const int i0 = __builtin_amdgcn_readlane(i, l0), i1 = __builtin_amdgcn_readlane(i, l1);
+            d = __longlong_as_double((long long)(((unsigned long long)(up ? hi1 : hi0) << 32) | (up ? lo1 : lo0)));
+            i = up ? i1 : i0;
+            return;
+        }
+    }
     double m = d;
     m = min_f64(m, dpp_mov_f64<0xB1, 0xf, false>(m));   // quad_perm [1,0,3,2]
     m = min_f64(m, dpp_mov_f64<0x4E, 0xf, false>(m));   // quad_perm [2,3,0,1]
@@ -131,31 +158,27 @@ __device__ __forceinline__ void wsd_F(WsLds& L, const WsRegs& R, int fw, int lan
     L.pFa[rsg][row * WG + ru] = a;
 }
 
-// the frame's tail for all utterances of the group (all 512 threads); `fa`: feat[u][frame][row] of item tid < 288 = (row, u);
-// pv: the pitch columns (threads < 32, as in k_encode_ws)
+// the frame's tail for all utterances of the group (all 512 threads); `fv`: feat[u][frame][m] of thread (u, m < 20)
 __device__ __forceinline__ void wsd_tail(const WsCtx& X, WsLds& L, const CbDev& C, const EncArgs& A, unsigned* err, int frame,
-                                         float fa, float pv, int tid0, unsigned epoch) {
+                                         float fv, int tid0, unsigned epoch) {
     const int tid = tid0 + ws_opaque_zero(), lane = tid & 63, u = tid >> 5, m = tid & 31;
     const bool uv = u < X.nu;
-    // ---- predictions, residuals, first-stage targets of all utterances (wavernn.py:195-196) ----
-    if (tid < WFC * WG) {
-        const int row = tid >> 4, uu = tid & 15;
-        const float acc = ((L.pFa[0][tid] + L.pFa[1][tid]) + (L.pFa[2][tid] + L.pFa[3][tid])) +
-                          ((L.pFa[4][tid] + L.pFa[5][tid]) + (L.pFa[6][tid] + L.pFa[7][tid]));
+    // ---- prediction, residual, first-stage target of utterance u: lane m < 18 = row m (wavernn.py:195-196).  Everything an
+    // utterance's half-wave reads from here on it has written itself (one in-order LDS queue per wave): no barrier.
+    if (m < WFC) {
+        const int o = m * WG + u;
+        const float acc = ((L.pFa[0][o] + L.pFa[1][o]) + (L.pFa[2][o] + L.pFa[3][o])) +
+                          ((L.pFa[4][o] + L.pFa[5][o]) + (L.pFa[6][o] + L.pFa[7][o]));
         const float tt = fpc_tanhf(acc);
         const float f = tt + tt;  // the "dual" FC is the same Linear summed twice (wavernn.py:89-92)
-        const float r = fa - f;
-        L.fo[uu][row] = f;
-        L.rsa[uu][row] = r;
-        if (row >= 1) L.xs[uu][row - 1] = (double)r;
+        const float r = fv - f;
+        L.fo[u][m] = f;
+        L.rsa[u][m] = r;
+        if (m >= 1) L.xs[u][m - 1] = (double)r;
+    } else if (m < WIN) {  // the pitch columns pass through (wavernn.py:178; stored with the other outputs: a store here
+        L.x[m * WG + u] = fv;  // would stand in front of the next wait for a load)
     }
     WSTAMP(25)
-    if (tid < (WIN - WFC) * WG) {  // the pitch columns pass through (wavernn.py:178)
-        const int uu = tid / (WIN - WFC), k = WFC + tid % (WIN - WFC);
-        L.x[k * WG + uu] = pv;
-        if (uu == X.slice && uu < X.nu) A.c_in[((size_t)(X.b0 + uu) * A.Lf + frame) * WIN + k] = pv;
-    }
-    lds_barrier();
     // ---- thresholds (:202,:206): every lane of the utterance's half-wave evaluates the same values ----
     float sabs = 0.0f;
     for (int d = 1; d < WFC; ++d) sabs += fabsf(L.rsa[u][d]);
@@ -167,6 +190,7 @@ __device__ __forceinline__ void wsd_tail(const WsCtx& X, WsLds& L, const CbDev& 
     const bool two = do_vq && i2 && C.S_hi == 2;
     const int cb0 = i2 ? 0 : 2, N0 = i2 ? C.N_hi0 : C.N_lo;
     const double* cb0R = i2 ? C.vq_hi0_r : C.vq_lo_r;
+
     if (uv && nonfinite && A.qtz && m == 0 && X.slice == u) status_or(err, FPC_ST_NONFINITE);
     // ---- first stage: this workgroup's 32 entries against utterance u ----
     const int e = WNS * m + X.slice;
@@ -181,12 +205,31 @@ __device__ __forceinline__ void wsd_tail(const WsCtx& X, WsLds& L, const CbDev& 
             if (m == 0) wsd_put(X, g1, epoch, d, ix);
         } else {  // the half-wave's five best, ranked by counting (ties: the lower entry first; five arg-min rounds with the
             // winner struck out were measured slower: 4.65 against 4.50 ms at 128 x 300)
+            // First on the distances' high words (they order the distances weakly: hw_argmin): rank = lanes with a smaller
+            // high word, exact for every lane whose high word no other lane shares -- and two lanes that share one get the
+            // same count, so five distinct ranks 0..4 in the half prove the five best exact.  Otherwise the float64 count.
+            const unsigned hw = (unsigned)((unsigned long long)__double_as_longlong(d0) >> 32);
             L.dl[u][m] = d0;  // (read back by the same wave: one in-order LDS queue per wave)
+            L.dh[u][m] = hw;
             int rank = 0;
+#pragma unroll
+            for (int j4 = 0; j4 < WNS / 4; ++j4) {
+                const uint4 hj = reinterpret_cast<const uint4*>(L.dh[u])[j4];
+                rank += (int)(hj.x < hw) + (int)(hj.y < hw) + (int)(hj.z < hw) + (int)(hj.w < hw);
+            }
+            bool sure = true;
+#pragma unroll
+            for (int r = 0; r < SURV; ++r) {
+                const unsigned long long bal = __ballot(rank == r);
+                sure &= __popc((unsigned)bal) <= 1 && __popc((unsigned)(bal >> 32)) <= 1;
+            }
+            if (!sure) {  // (wave-uniform)
+                rank = 0;
 #pragma unroll 8
-            for (int j = 0; j < WNS; ++j) {
-                const double dj = L.dl[u][j];
-                rank += (dj < d0) | ((dj == d0) & (j < m));
+                for (int j = 0; j < WNS; ++j) {
+                    const double dj = L.dl[u][j];
+                    rank += (dj < d0) | ((dj == d0) & (j < m));
+                }
             }
             if (rank < SURV) wsd_put(X, g1 + rank, epoch, d0, e0);
         }
@@ -227,6 +270,9 @@ __device__ __forceinline__ void wsd_tail(const WsCtx& X, WsLds& L, const CbDev& 
             hw_argmin(d, ix, lane);
             s[0] = wsd_clamp(ix, N0);
         } else {  // the five smallest of 32 sorted lists: five rounds of arg-min over the lists' heads, the winner's list popped
+            // (a survivor's first-stage row -- lane m < 17: element m -- is asked for as soon as the survivor is known: the
+            //  L2 round trips ride under the remaining rounds)
+            double row[SURV];
 #pragma unroll
             for (int r = 0; r < SURV; ++r) {
                 double d = ld[0];
@@ -242,13 +288,13 @@ __device__ __forceinline__ void wsd_tail(const WsCtx& X, WsLds& L, const CbDev& 
                     li[SURV - 1] = 0x7fffffff;
                 }
                 s[r] = wsd_clamp(ix, N0);
+                row[r] = m < NDIM ? cb0R[(size_t)s[r] * NDIM + m] : 0.0;
             }
             // second-stage targets: residual of every survivor (vq_func.py:103-108)
+            if (m < NDIM) {
+                const double xv = L.xs[u][m];
 #pragma unroll
-            for (int j = 0; j < (SURV * NDIM + WNS - 1) / WNS; ++j) {
-                const int p = m + WNS * j, k = p / NDIM, d = p - k * NDIM;
-                const int sk = k == 0 ? s[0] : (k == 1 ? s[1] : (k == 2 ? s[2] : (k == 3 ? s[3] : s[4])));  // (no indexed array)
-                if (p < SURV * NDIM) L.xq2[u][k][d] = L.xs[u][d] - cb0R[(size_t)sk * NDIM + d];
+                for (int k = 0; k < SURV; ++k) L.xq2[u][k][m] = xv - row[k];
             }
         }
     }
@@ -324,6 +370,7 @@ __device__ __forceinline__ void wsd_tail(const WsCtx& X, WsLds& L, const CbDev& 
             A.c_in[fi * WIN + m] = cn;
         }
     }
+    if (owner && m >= WFC && m < WIN) A.c_in[fi * WIN + m] = fv;
     if (owner && m == 0) {
         A.ind1[fi] = (float)i1;
         A.ind2[fi] = (float)i2;
@@ -364,20 +411,14 @@ __global__ __launch_bounds__(NT) void k_encode_wsd(const PredDev P, const CbDev 
     ws_prologue(P, X, L, R, S, tid);
     int fg_epoch = 0;
     int i = 0;
+    // this thread's feature value of a frame: thread (u, m) = column m < 20 of utterance u -- rows 0-17 for the residuals, the
+    // pitch columns pass through to the next input (wavernn.py:178) -- where it is in frame 0 (nullptr: none)
+    const float* fvp = nullptr;
+    if ((tid & 31) < WIN && (tid >> 5) < X.nu) fvp = A.feat + (size_t)(X.b0 + (tid >> 5)) * A.Lf * WIN + (tid & 31);
     WPROF_INIT()
     for (; i < A.Lf; ++i) {
         const unsigned epoch = (unsigned)i + 1u;
-        // this frame's feature rows of every utterance of the group: thread = (row, utterance) for the residuals, and the
-        // pitch columns, which pass through to the next input (wavernn.py:178): fetched before the step
-        float fa = 0.0f, pv = 0.0f;
-        if (tid < WFC * WG) {
-            const int row = tid >> 4, uu = tid & 15;
-            if (uu < X.nu) fa = A.feat[((size_t)(X.b0 + uu) * A.Lf + i) * WIN + row];
-        }
-        if (tid < (WIN - WFC) * WG) {
-            const int uu = tid / (WIN - WFC), k = WFC + tid % (WIN - WFC);
-            if (uu < X.nu) pv = A.feat[((size_t)(X.b0 + uu) * A.Lf + i) * WIN + k];
-        }
+        const float fv = fvp != nullptr ? fvp[i * WIN] : 0.0f;  // fetched before the step
         if (tid < WFGT) {
             __builtin_amdgcn_s_setprio(FPC_FG_PRIO);
             (void)ws_foreground<false, true>(X, L, R, i, tid, fg_epoch);
@@ -388,11 +429,17 @@ __global__ __launch_bounds__(NT) void k_encode_wsd(const PredDev P, const CbDev 
         WBSTAMP(19)
         lds_barrier();  // both roles meet: the tail takes the whole workgroup
         WSTAMP(20)
-        wsd_tail(X, L, C, A, S.err, i, fa, pv, tid, epoch);
+        wsd_tail(X, L, C, A, S.err, i, fv, tid, epoch);
         WSTAMP(21)
-        if (ws_frame_dead(L, tid)) break;
+        // The frame's last barrier (the next input rows are in LDS) carries the give-up flag as well: one thread copies it
+        // before the barrier, everybody acts on the copy behind it.  A wait given up behind the copy shows a frame later, or in
+        // the check behind the loop: every wait fails at once from then on, the launch poisons its outputs either way.
+        if (tid == 0) L.dead_latch = __hip_atomic_load(&L.dead, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        lds_barrier();
+        if (L.dead_latch != 0) break;
         WSTAMP(22)
     }
+    if (i == A.Lf && A.Lf > 0 && ws_frame_dead(L, tid)) i = A.Lf - 1;  // (given up in the last frame's tail)
     WPROF_DUMP(A.Lf)
     if (i < A.Lf && slice < X.nu) encode_poison(P, A, X.b0 + slice, i, tid);
 }
