@@ -16,7 +16,7 @@ SYMBOLS = [
     "fpc_encode", "fpc_decode_features", "fpc_vq_quantize", "fpc_scl_quantize", "fpc_ceps2lpc",
     "fpc_lpcnet_create", "fpc_lpcnet_destroy", "fpc_lpcnet_workspace_bytes",
     "fpc_lpcnet_synthesize", "fpc_lpcnet_condition", "fpc_lpcnet_last_decode_ms",
-    "fpc_lpcnet_kernel_variant",
+    "fpc_lpcnet_kernel_variant", "fpc_lpcnet_set_chunk_frames",
     "fpc_trainer_create", "fpc_trainer_destroy", "fpc_trainer_step", "fpc_trainer_export",
     "fpc_cb_workspace_bytes", "fpc_cb_find_nearest", "fpc_cb_update", "fpc_cb_mean0",
 ]
@@ -72,6 +72,7 @@ def lib():
         L.fpc_lpcnet_last_decode_ms.restype = C.c_float
         L.fpc_lpcnet_last_decode_ms.argtypes = [C.c_void_p]
         L.fpc_lpcnet_kernel_variant.argtypes = [C.c_void_p]
+        L.fpc_lpcnet_set_chunk_frames.argtypes = [C.c_void_p, C.c_int]
         L.fpc_trainer_create.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
         L.fpc_trainer_destroy.argtypes = [C.c_void_p]
         L.fpc_trainer_step.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_double, C.POINTER(C.c_float),

@@ -56,20 +56,31 @@ __global__ void k_embed_tables(const float* __restrict__ embed, const float* __r
 //   MODE 1: 'same' k=3 conv, K = 3*C, x_f[tap*C+c] = x[f+tap-1][c], zero rows outside the utterance
 //   MODE 2: like 1 with the input row built on the fly from the 36-float feature frame:
 //           20 features | 64-dim pitch embedding (C = 84)
-// block = 256 threads = 4 waves = 16 frames x 128 outputs; grid = (B * ceil(T/16), ceil(N/128)).
+// block = 256 threads = 4 waves = 16 frames x 128 outputs; grid = (B * ceil(frames/16), ceil(N/128)).
+// Frames are ABSOLUTE frame numbers of the utterance (FrameView): a launch evaluates frames [o0, o1), reads the input
+// rows it needs from a buffer that holds frames x_t0 .. x_t0 + x_T - 1 of every utterance (zero rows outside [0, T):
+// the 'same' padding of the utterance, not of the chunk) and writes into a buffer that holds y_t0 .. y_t0 + y_T - 1
+// -- the whole utterance in one launch (x_t0 = y_t0 = o0 = 0, x_T = y_T = o1 = T) or a chunk of it with its halo rows.
 // ---------------------------------------------------------------------------------
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+struct FrameView {
+    int T;           // frames of an utterance
+    int o0, o1;      // frames evaluated by this launch
+    int x_t0, x_T;   // input buffer: first frame held, frames per utterance
+    int y_t0, y_T;   // output buffer
+};
 
 template <int MODE>
 __global__ __launch_bounds__(256) void k_frame_mfma(const float* __restrict__ x, int ldx, int C, int K,
                                                     const float* __restrict__ W,
                                                     const float* __restrict__ bias, int N,
-                                                    float* __restrict__ y, int T, int do_tanh,
+                                                    float* __restrict__ y, const FrameView V, int do_tanh,
                                                     const float* __restrict__ embed_pitch) {
     extern __shared__ __attribute__((aligned(16))) float xs[];  // [18][Cs]
     const int Cs = ((C + 29) / 32) * 32 + 2;                    // row stride = 2 mod 32: conflict-free A reads
-    const int tiles = (T + 15) / 16;
-    const int b = blockIdx.x / tiles, t0 = (blockIdx.x % tiles) * 16;
+    const int T = V.T;
+    const int tiles = (V.o1 - V.o0 + 15) / 16;
+    const int b = blockIdx.x / tiles, t0 = V.o0 + (blockIdx.x % tiles) * 16;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     // ---- stage rows t0-1 .. t0+16 of this utterance (zeros outside [0,T)) ----
     const int nrows = MODE == 0 ? 16 : 18, roff = MODE == 0 ? 0 : -1;
@@ -78,7 +89,7 @@ __global__ __launch_bounds__(256) void k_frame_mfma(const float* __restrict__ x,
         const int tt = t0 + rr + roff;
         float v = 0.0f;
         if (tt >= 0 && tt < T) {
-            const size_t f = (size_t)b * T + tt;
+            const size_t f = (size_t)b * V.x_T + (tt - V.x_t0);
             if (MODE == 2) {
                 const float* fr = x + f * FPC_NB_FEATURES;
                 v = c < FPC_NB_USED_FEATURES
@@ -113,8 +124,8 @@ __global__ __launch_bounds__(256) void k_frame_mfma(const float* __restrict__ x,
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int tt = t0 + kq * 4 + r;
-        if (tt < T) {
-            const size_t f = (size_t)b * T + tt;
+        if (tt < V.o1) {
+            const size_t f = (size_t)b * V.y_T + (tt - V.y_t0);
             y[f * N + col0] = do_tanh ? fpc_tanhf(acc0[r]) : acc0[r];
             if (has1) y[f * N + col1] = do_tanh ? fpc_tanhf(acc1[r]) : acc1[r];
         }
@@ -154,14 +165,25 @@ struct fpc_lpcnet {
     int lds_read_cycles_greedy = 0, lds_read_cycles = 0;  // LDS cycles of the mat-vec state reads per sample (diagnostic)
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool timed = false;
+    int chunk = 0;  // frames per chunk of fpc_lpcnet_synthesize (0: the whole utterance in one pass)
 };
 
 static size_t ws_floats_per_frame() { return 128 + 128 + 128 + GA + GB; }
+// frames per pass of fpc_lpcnet_synthesize: T, or the handle's chunk when the utterance is longer than that
+static int pass_frames(const fpc_lpcnet* m, int T) { return (m && m->chunk > 0 && m->chunk < T) ? m->chunk : T; }
 
 extern "C" long long fpc_lpcnet_workspace_bytes(const fpc_lpcnet* m, int B, int T) {
-    (void)m;
     if (B <= 0 || T <= 0) return 0;
-    return (long long)B * T * (long long)ws_floats_per_frame() * 4 + 256;
+    const int C = pass_frames(m, T);
+    if (C == T) return (long long)B * T * (long long)ws_floats_per_frame() * 4 + 256;
+    // chunked: the first conv's rows with a halo frame either side, the carried state; independent of T
+    return (long long)B * ((long long)C * (long long)ws_floats_per_frame() + 2 * 128 + STATE_FLOATS) * 4 + 256;
+}
+
+extern "C" int fpc_lpcnet_set_chunk_frames(fpc_lpcnet* m, int frames) {
+    FPC_REQUIRE(m && frames >= 0, "fpc_lpcnet_set_chunk_frames: bad argument");
+    m->chunk = frames;
+    return FPC_OK;
 }
 
 extern "C" void fpc_lpcnet_destroy(fpc_lpcnet* m);
@@ -182,6 +204,7 @@ extern "C" int fpc_lpcnet_create(const fpc_lpcnet_weights* w, fpc_lpcnet** out) 
     std::unique_ptr<fpc_lpcnet, Del> own(new fpc_lpcnet());
     fpc_lpcnet* m = own.get();
     FPC_HIP(hipGetDevice(&m->device));
+    if (const char* e = getenv("FPC_LPCNET_CHUNK")) m->chunk = atoi(e) > 0 ? atoi(e) : 0;
 
     auto up = [&](fpc::DevBuf& d, const float* src, size_t n) -> hipError_t {
         hipError_t e = d.alloc(n * 4);
@@ -481,37 +504,51 @@ namespace {
 struct CondBufs {
     float *x1, *x2, *x3, *cfa, *cfb;
 };
-CondBufs carve(void* ws, int B, int T) {
+// C = frames per pass (T, or a chunk: x1 then holds a halo frame either side and `state` the carried records)
+CondBufs carve(void* ws, int B, int C, bool chunked, float** state = nullptr) {
     float* p = static_cast<float*>(ws);
-    const size_t F = (size_t)B * T;
+    const size_t F = (size_t)B * C;
     CondBufs c;
     c.x1 = p;
-    c.x2 = c.x1 + F * 128;
+    c.x2 = c.x1 + (chunked ? (size_t)B * (C + 2) : F) * 128;
     c.x3 = c.x2 + F * 128;
     c.cfa = c.x3 + F * 128;
     c.cfb = c.cfa + F * GA;
+    if (state) *state = c.cfb + F * GB;
     return c;
 }
+FrameView whole(int T) { return FrameView{T, 0, T, 0, T, 0, T}; }
 
 template <int MODE>
 void launch_frame(const float* x, int ldx, int C, int K, const float* W, const float* bias, int N, float* y,
-                  int B, int T, int do_tanh, const float* embed_pitch, hipStream_t st) {
+                  int B, const FrameView& V, int do_tanh, const float* embed_pitch, hipStream_t st) {
     const int Cs = ((C + 29) / 32) * 32 + 2;
-    const dim3 grid(B * ((T + 15) / 16), (N + 127) / 128);
+    const dim3 grid(B * ((V.o1 - V.o0 + 15) / 16), (N + 127) / 128);
     hipLaunchKernelGGL(k_frame_mfma<MODE>, grid, dim3(256), (size_t)18 * Cs * sizeof(float), st, x, ldx, C, K, W,
-                       bias, N, y, T, do_tanh, embed_pitch);
+                       bias, N, y, V, do_tanh, embed_pitch);
 }
 
-int run_condition(fpc_lpcnet* m, const float* feat, int B, int T, const CondBufs& c, float* cfeat,
-                  hipStream_t st) {
+// frames [f0, f1) of every utterance; the buffers hold C frames per utterance from frame f0 on (x1: C + 2 from f0 - 1 on
+// when the pass is a chunk -- the second conv reads a frame either side, which the first conv evaluates again), cfeat
+// likewise C from f0 on
+// (cf_t0, cf_T: the view of the cfeat buffer -- the chunk's own rows, or the caller's whole [B][T][128])
+int run_condition(fpc_lpcnet* m, const float* feat, int B, int T, int f0, int f1, int C, const CondBufs& c, float* cfeat,
+                  int cf_t0, int cf_T, hipStream_t st) {
     const float* none = nullptr;
+    const bool chunked = C != T;
+    const int h0 = chunked ? std::max(0, f0 - 1) : 0, h1 = chunked ? std::min(T, f1 + 1) : T;
+    const int x1_t0 = chunked ? f0 - 1 : 0, x1_T = chunked ? C + 2 : T;
+    const FrameView v1{T, h0, h1, 0, T, x1_t0, x1_T};    // features (whole) -> x1 with halo
+    const FrameView v2{T, f0, f1, x1_t0, x1_T, f0, C};   // x1 -> x2
+    const FrameView v3{T, f0, f1, f0, C, f0, C};         // x2 -> x3 -> cfeat
     // conv1 (84 ch, built on the fly from the feature frame) -> x1, conv2 -> x2, dense1 -> x3, dense2 -> cfeat
-    launch_frame<2>(feat, 0, 84, 3 * 84, m->conv1_k.as<float>(), m->conv1_b.as<float>(), 128, c.x1, B, T, 1,
+    launch_frame<2>(feat, 0, 84, 3 * 84, m->conv1_k.as<float>(), m->conv1_b.as<float>(), 128, c.x1, B, v1, 1,
                     m->embed_pitch.as<float>(), st);
-    launch_frame<1>(c.x1, 128, 128, 3 * 128, m->conv2_k.as<float>(), m->conv2_b.as<float>(), 128, c.x2, B, T, 1,
+    launch_frame<1>(c.x1, 128, 128, 3 * 128, m->conv2_k.as<float>(), m->conv2_b.as<float>(), 128, c.x2, B, v2, 1,
                     none, st);
-    launch_frame<0>(c.x2, 128, 128, 128, m->d1_k.as<float>(), m->d1_b.as<float>(), 128, c.x3, B, T, 1, none, st);
-    launch_frame<0>(c.x3, 128, 128, 128, m->d2_k.as<float>(), m->d2_b.as<float>(), 128, cfeat, B, T, 1, none, st);
+    launch_frame<0>(c.x2, 128, 128, 128, m->d1_k.as<float>(), m->d1_b.as<float>(), 128, c.x3, B, v3, 1, none, st);
+    const FrameView v4{T, f0, f1, f0, C, cf_t0, cf_T};
+    launch_frame<0>(c.x3, 128, 128, 128, m->d2_k.as<float>(), m->d2_b.as<float>(), 128, cfeat, B, v4, 1, none, st);
     FPC_HIP(hipGetLastError());
     return FPC_OK;
 }
@@ -521,8 +558,14 @@ extern "C" int fpc_lpcnet_condition(fpc_lpcnet* m, const float* features_dev, in
                                     float* cfeat_dev, void* workspace_dev, fpc_stream s) {
     FPC_REQUIRE(m && features_dev && cfeat_dev && workspace_dev, "fpc_lpcnet_condition: null argument");
     FPC_REQUIRE(B > 0 && T > 0, "fpc_lpcnet_condition: bad shape B=%d T=%d", B, T);
-    return run_condition(m, features_dev, B, T, carve(workspace_dev, B, T), cfeat_dev,
-                         static_cast<hipStream_t>(s));
+    const int C = pass_frames(m, T);
+    const CondBufs c = carve(workspace_dev, B, C, C != T);
+    for (int f0 = 0; f0 < T; f0 += C) {
+        const int rc = run_condition(m, features_dev, B, T, f0, std::min(T, f0 + C), C, c, cfeat_dev, 0, T,
+                                     static_cast<hipStream_t>(s));
+        if (rc != FPC_OK) return rc;
+    }
+    return FPC_OK;
 }
 
 extern "C" int fpc_lpcnet_synthesize(fpc_lpcnet* m, const float* features_dev, int B, int T,
@@ -533,20 +576,20 @@ extern "C" int fpc_lpcnet_synthesize(fpc_lpcnet* m, const float* features_dev, i
     FPC_REQUIRE(B > 0 && T > 0 && (long long)T * FPC_FRAME_SIZE < (1ll << 31),
                 "fpc_lpcnet_synthesize: bad shape B=%d T=%d", B, T);
     hipStream_t st = static_cast<hipStream_t>(s);
-    const CondBufs c = carve(workspace_dev, B, T);
+    // One pass over the whole utterance, or (fpc_lpcnet_set_chunk_frames) passes of C frames: the frame-rate layers and
+    // the conditioning products of a chunk, then the sample loop over it with the per-stream state carried in a record --
+    // the workspace holds one chunk, whatever T is.
+    const int C = pass_frames(m, T);
+    const bool chunked = C != T;
+    float* state = nullptr;
+    const CondBufs c = carve(workspace_dev, B, C, chunked, &state);
     float* cfeat = c.x1;  // x1 is free again once conv2 has run
-    // cfeat cannot alias a live buffer: run conv1->x1, conv2->x2, d1->x3, d2->x1
-    int rc = run_condition(m, features_dev, B, T, c, cfeat, st);
-    if (rc != FPC_OK) return rc;
-    // conditioning products with the cfeat rows of both GRU input kernels
-    launch_frame<0>(cfeat, 128, 128, 128, m->ga_k.as<float>() + (size_t)3 * EMB * GA, m->bias_a.as<float>(), GA,
-                    c.cfa, B, T, 0, nullptr, st);
-    launch_frame<0>(cfeat, 128, 128, 128, m->gb_k.as<float>() + (size_t)RNN_A * GB, m->bias_b.as<float>(), GB,
-                    c.cfb, B, T, 0, nullptr, st);
     DecodeParams P;
     P.tab = m->tab.as<float>();
     P.cfa = c.cfa;
     P.cfb = c.cfb;
+    P.cf_T = C;
+    P.state = chunked ? state : nullptr;
     P.features = features_dev;
     P.seeds = reinterpret_cast<const unsigned long long*>(seeds_dev);
     P.pcm = pcm_dev;
@@ -572,7 +615,6 @@ extern "C" int fpc_lpcnet_synthesize(fpc_lpcnet* m, const float* features_dev, i
         FPC_HIP(hipMemsetAsync(stamps.p, 0, kStampWords * sizeof(unsigned), st));
         P.stamps = stamps.as<unsigned>();
     }
-    FPC_HIP(hipEventRecord(m->ev0, st));
     const int variant = decode_variant(m);
 #define FPC_LAUNCH(QZR, QN)                                                                       \
     do {                                                                                          \
@@ -581,12 +623,27 @@ extern "C" int fpc_lpcnet_synthesize(fpc_lpcnet* m, const float* features_dev, i
         else                                                                                      \
             hipLaunchKernelGGL((k_decode<false, QZR, QN>), dim3(B), dim3(NTHREADS), 0, st, P);    \
     } while (0)
-    if (variant == 208)
-        FPC_LAUNCH(2, 8);
-    else if (variant == 408)
-        FPC_LAUNCH(4, 8);
-    else
-        FPC_LAUNCH(16, 16);
+    for (int f0 = 0; f0 < T; f0 += C) {
+        const int f1 = std::min(T, f0 + C);
+        // cfeat cannot alias a live buffer: run conv1->x1, conv2->x2, d1->x3, d2->x1
+        const int rc = run_condition(m, features_dev, B, T, f0, f1, C, c, cfeat, f0, C, st);
+        if (rc != FPC_OK) return rc;
+        // conditioning products with the cfeat rows of both GRU input kernels
+        const FrameView v{T, f0, f1, f0, C, f0, C};
+        launch_frame<0>(cfeat, 128, 128, 128, m->ga_k.as<float>() + (size_t)3 * EMB * GA, m->bias_a.as<float>(), GA,
+                        c.cfa, B, v, 0, nullptr, st);
+        launch_frame<0>(cfeat, 128, 128, 128, m->gb_k.as<float>() + (size_t)RNN_A * GB, m->bias_b.as<float>(), GB,
+                        c.cfb, B, v, 0, nullptr, st);
+        P.f0 = f0;
+        P.f1 = f1;
+        if (f0 == 0) FPC_HIP(hipEventRecord(m->ev0, st));  // (chunked: the span from the first sample loop to the last)
+        if (variant == 208)
+            FPC_LAUNCH(2, 8);
+        else if (variant == 408)
+            FPC_LAUNCH(4, 8);
+        else
+            FPC_LAUNCH(16, 16);
+    }
 #undef FPC_LAUNCH
     FPC_HIP(hipEventRecord(m->ev1, st));
     FPC_HIP(hipGetLastError());

@@ -26,6 +26,7 @@
 // oracle/fpc_oracle.c::orc_lpcnet_synthesize; results are bit-identical.
 #pragma once
 
+constexpr int STATE_FLOATS = 512;  // per-stream record of a chunked pass (DecodeParams::state)
 constexpr int NTHREADS = 768;
 constexpr int NSAMP = 256;  // sampler lanes (waves 0-3)
 constexpr int NMAT = 512;   // mat-vec lanes (waves 4-11)
@@ -48,12 +49,15 @@ constexpr int PSTRIDE = GA + 4;
 
 struct DecodeParams {
     const float* tab;       // [3][256][384][3]  embedding x input-kernel tables, gate-interleaved
-    const float* cfa;       // [B][T][1152]  GRU_A conditioning product (+biases)
-    const float* cfb;       // [B][T][48]    GRU_B conditioning product (+biases)
+    const float* cfa;       // [B][cf_T][1152]  GRU_A conditioning product (+biases) of frames f0 .. f0 + cf_T - 1
+    const float* cfb;       // [B][cf_T][48]    GRU_B conditioning product (+biases)
     const float* features;  // [B][T][36]
     const unsigned long long* seeds;
     int16_t* pcm;  // [B][T*160]
     int T;
+    int f0, f1, cf_T;  // this launch decodes frames [f0, f1) (the whole utterance: 0, T, T)
+    float* state;      // [B][STATE_FLOATS] per-stream record carried between the launches of a chunked pass (nullptr: none):
+                       // s1[384] | s2[16] | history ring[16] | control block[4] | de-emphasis state
     const float* lane_w;     // [128][512] sparse GRU_A weights: 2 leaves x 2 blocks x 8x4
     const int* lane_meta;    // [2][512]   packed column blocks; (group+1)<<16 | lanes<<8 | lane
     const float* lane_wb;    // [72][256]  GRU_B input weights [gate][24 inputs] of (unit, slice)
@@ -194,8 +198,11 @@ __global__ __launch_bounds__(NTHREADS) void k_decode(const DecodeParams P) {
     const int b = blockIdx.x, T = P.T;
 
     // ---- LDS init ----
+    // a chunk after the first resumes from the record its predecessor left (same values, so the same samples)
+    const bool resume = P.state != nullptr && P.f0 > 0;
+    float* const rec = P.state != nullptr ? P.state + (size_t)b * STATE_FLOATS : nullptr;
     for (int i = tid; i < RNN_A; i += NTHREADS) {
-        L.s1[i] = 0.0f;
+        L.s1[i] = resume ? rec[i] : 0.0f;
         L.brn_a[i] = P.brn_a[i];
     }
     for (int i = tid; i < GA; i += NTHREADS) {
@@ -208,17 +215,21 @@ __global__ __launch_bounds__(NTHREADS) void k_decode(const DecodeParams P) {
         L.tt[k] = make_float2(t0, t1 - t0);
     }
     if (tid < RNN_B) {
-        L.s2[tid] = 0.0f;
-        L.hist[tid] = 0.0f;
+        L.s2[tid] = resume ? rec[RNN_A + tid] : 0.0f;
+        L.hist[tid] = resume ? rec[RNN_A + 16 + tid] : 0.0f;
     }
     if (tid == 0) {
-        L.o_sig = 128u * GA;
-        L.o_pred = (256u + 128u) * GA;
-        L.o_exc = (512u + 128u) * GA;
-        L.pred = -0.0f;
+        if (resume) {
+            *reinterpret_cast<float4*>(&L.o_sig) = *reinterpret_cast<const float4*>(&rec[RNN_A + 32]);
+        } else {
+            L.o_sig = 128u * GA;
+            L.o_pred = (256u + 128u) * GA;
+            L.o_exc = (512u + 128u) * GA;
+            L.pred = -0.0f;
+        }
     }
     int16_t* out = P.pcm + (size_t)b * T * FPC_FRAME_SIZE;
-    if (tid < FPC_LPC_ORDER + 1) out[tid] = 0;  // test_lpcnet.py skips order+1 samples
+    if (tid < FPC_LPC_ORDER + 1 && P.f0 == 0) out[tid] = 0;  // test_lpcnet.py skips order+1 samples
     __syncthreads();
 
     if (wave >= 4) {
@@ -248,11 +259,61 @@ __global__ __launch_bounds__(NTHREADS) void k_decode(const DecodeParams P) {
         }
         paddr_ = opaque(paddr_);
 
-        for (int fr = 0; fr < T; ++fr) {
+#define FPC_COLS(FROM, TO)                                                                                        \
+    _Pragma("unroll") for (int bc = (FROM); bc < (TO); ++bc) {                                                    \
+        if (bc == 0 || (bc == (FROM) && bc < 8 && false)) {                                                       \
+            const unsigned colp = opaque(colp_);                                                                  \
+            const float4 ha = *reinterpret_cast<const float4*>(&L.s1[(colp & 0xff) * 4]);                         \
+            const float4 hb = *reinterpret_cast<const float4*>(&L.s1[((colp >> 8) & 0xff) * 4]);                  \
+            hv0[0] = ha.x, hv0[1] = ha.y, hv0[2] = ha.z, hv0[3] = ha.w;                                           \
+            hv0[4] = hb.x, hv0[5] = hb.y, hv0[6] = hb.z, hv0[7] = hb.w;                                           \
+        }                                                                                                         \
+        if (bc == 8) {                                                                                            \
+            const unsigned colp = opaque(colp_);                                                                  \
+            const float4 hc = *reinterpret_cast<const float4*>(&L.s1[((colp >> 16) & 0xff) * 4]);                 \
+            const float4 hd = *reinterpret_cast<const float4*>(&L.s1[(colp >> 24) * 4]);                          \
+            hv1[0] = hc.x, hv1[1] = hc.y, hv1[2] = hc.z, hv1[3] = hc.w;                                           \
+            hv1[4] = hd.x, hv1[5] = hd.y, hv1[6] = hd.z, hv1[7] = hd.w;                                           \
+        }                                                                                                         \
+        _Pragma("unroll") for (int rp = 0; rp < 4; ++rp) {                                                 \
+            if (bc < 8)                                                                                           \
+                acc[rp] = fma2(w2[bc * 4 + rp], splat2(hv0[bc]), acc[rp]);                                        \
+            else                                                                                                  \
+                a[rp] = fma2(w2[bc * 4 + rp], splat2(hv1[bc - 8]), a[rp]);                                        \
+        }                                                                                                         \
+    }                                                                                                             \
+    _Pragma("unroll") for (int rp = 0; rp < 4; ++rp) {                                                            \
+        pin(acc[rp]);                                                                                             \
+        pin(a[rp]);                                                                                               \
+    }
+#define FPC_PUBLISH()                                                                                             \
+    _Pragma("unroll") for (int rp = 0; rp < 4; ++rp) acc[rp] = acc[rp] + a[rp]; /* the in-lane tree level */         \
+    if (paddr_ != 0u) { /* publish this lane's 8 partial row sums */                                                  \
+        typedef float v4f __attribute__((ext_vector_type(4)));                                                        \
+        typedef __attribute__((address_space(3))) v4f lds_v4f;                                                        \
+        lds_v4f* pp = (lds_v4f*)(size_t)paddr_; /* 32-byte aligned: two ds_write_b128 */                              \
+        v4f lo, hi;                                                                                                   \
+        lo.x = acc[0].x, lo.y = acc[0].y, lo.z = acc[1].x, lo.w = acc[1].y;                                           \
+        hi.x = acc[2].x, hi.y = acc[2].y, hi.z = acc[3].x, hi.w = acc[3].y;                                           \
+        pp[0] = lo;                                                                                                   \
+        pp[1] = hi;                                                                                                   \
+    }
+        if (P.state != nullptr) {  // (uniform) a resumed chunk: the sparse product of the state it starts from, as the
+            if (resume) {          // last sample of the chunk before left it in LDS
+                f2 acc[4], a[4];
+                float hv0[8], hv1[8];
+#pragma unroll
+                for (int rp = 0; rp < 4; ++rp) acc[rp] = a[rp] = splat2(0.0f);
+                FPC_COLS(0, 16)
+                FPC_PUBLISH()
+            }
+            __syncthreads();
+        }
+        for (int fr = P.f0; fr < P.f1; ++fr) {
             // voiced frames (pdf sharpening on) keep a separate parallel leaf phase: one more barrier
             const bool voiced = fpc_shape_exponent(P.features[((size_t)b * T + fr) * FPC_NB_FEATURES + 19]) > 0.0f;
             if (gate_lane) {  // this frame's conditioning values of unit ml: written and read by the same lane
-                const float* cfa = P.cfa + ((size_t)b * T + fr) * GA;
+                const float* cfa = P.cfa + ((size_t)b * P.cf_T + (fr - P.f0)) * GA;
                 L.cfa[ml_] = cfa[ml_];
                 L.cfa[RNN_A + ml_] = cfa[RNN_A + ml_];
                 L.cfa[2 * RNN_A + ml_] = cfa[2 * RNN_A + ml_];
@@ -304,33 +365,6 @@ __global__ __launch_bounds__(NTHREADS) void k_decode(const DecodeParams P) {
                 float hv0[8], hv1[8];
 #pragma unroll
                 for (int rp = 0; rp < 4; ++rp) acc[rp] = a[rp] = splat2(0.0f);
-#define FPC_COLS(FROM, TO)                                                                                        \
-    _Pragma("unroll") for (int bc = (FROM); bc < (TO); ++bc) {                                                    \
-        if (bc == 0 || (bc == (FROM) && bc < 8 && false)) {                                                       \
-            const unsigned colp = opaque(colp_);                                                                  \
-            const float4 ha = *reinterpret_cast<const float4*>(&L.s1[(colp & 0xff) * 4]);                         \
-            const float4 hb = *reinterpret_cast<const float4*>(&L.s1[((colp >> 8) & 0xff) * 4]);                  \
-            hv0[0] = ha.x, hv0[1] = ha.y, hv0[2] = ha.z, hv0[3] = ha.w;                                           \
-            hv0[4] = hb.x, hv0[5] = hb.y, hv0[6] = hb.z, hv0[7] = hb.w;                                           \
-        }                                                                                                         \
-        if (bc == 8) {                                                                                            \
-            const unsigned colp = opaque(colp_);                                                                  \
-            const float4 hc = *reinterpret_cast<const float4*>(&L.s1[((colp >> 16) & 0xff) * 4]);                 \
-            const float4 hd = *reinterpret_cast<const float4*>(&L.s1[(colp >> 24) * 4]);                          \
-            hv1[0] = hc.x, hv1[1] = hc.y, hv1[2] = hc.z, hv1[3] = hc.w;                                           \
-            hv1[4] = hd.x, hv1[5] = hd.y, hv1[6] = hd.z, hv1[7] = hd.w;                                           \
-        }                                                                                                         \
-        _Pragma("unroll") for (int rp = 0; rp < 4; ++rp) {                                                 \
-            if (bc < 8)                                                                                           \
-                acc[rp] = fma2(w2[bc * 4 + rp], splat2(hv0[bc]), acc[rp]);                                        \
-            else                                                                                                  \
-                a[rp] = fma2(w2[bc * 4 + rp], splat2(hv1[bc - 8]), a[rp]);                                        \
-        }                                                                                                         \
-    }                                                                                                             \
-    _Pragma("unroll") for (int rp = 0; rp < 4; ++rp) {                                                            \
-        pin(acc[rp]);                                                                                             \
-        pin(a[rp]);                                                                                               \
-    }
                 FPC_COLS(0, FPC_NA)
                 FPC_BARRIER(1)  // Z1
                 FPC_COLS(FPC_NA, FPC_NA + FPC_NB)
@@ -339,22 +373,13 @@ __global__ __launch_bounds__(NTHREADS) void k_decode(const DecodeParams P) {
                     FPC_BARRIER(3)  // Z3 (voiced frames only: the sampler waves' leaf phase ends here)
                 }
                 FPC_COLS(FPC_NA + FPC_NB, 16)
-#undef FPC_COLS
-#pragma unroll
-                for (int rp = 0; rp < 4; ++rp) acc[rp] = acc[rp] + a[rp];  // the in-lane tree level
-                if (paddr_ != 0u) {  // publish this lane's 8 partial row sums
-                    typedef float v4f __attribute__((ext_vector_type(4)));
-                    typedef __attribute__((address_space(3))) v4f lds_v4f;
-                    lds_v4f* pp = (lds_v4f*)(size_t)paddr_;  // 32-byte aligned: two ds_write_b128
-                    v4f lo, hi;
-                    lo.x = acc[0].x, lo.y = acc[0].y, lo.z = acc[1].x, lo.w = acc[1].y;
-                    hi.x = acc[2].x, hi.y = acc[2].y, hi.z = acc[3].x, hi.w = acc[3].y;
-                    pp[0] = lo;
-                    pp[1] = hi;
-                }
+                FPC_PUBLISH()
                 FPC_BARRIER(4)  // X
             }
         }
+#undef FPC_COLS
+#undef FPC_PUBLISH
+        if (rec != nullptr && gate_lane) rec[ml_] = L.s1[ml_];  // (written by this lane)
     } else {
         // =========================== sampler role ===========================
         __builtin_amdgcn_s_setprio(3);  // the sample-to-sample critical path lives in these waves
@@ -382,14 +407,15 @@ __global__ __launch_bounds__(NTHREADS) void k_decode(const DecodeParams P) {
         for (int k = 0; k < 16; ++k) fcw[k] = mk2(P.lane_fc[k * NSAMP + sl], P.lane_fc[(16 + k) * NSAMP + sl]);
         fcw[16] = mk2(P.lane_fc[32 * NSAMP + sl], P.lane_fc[33 * NSAMP + sl]);
         fcw[17] = mk2(P.lane_fc[34 * NSAMP + sl], P.lane_fc[35 * NSAMP + sl]);
-        float mem = 0.0f;     // de-emphasis state (tracked by every lane of the drawing wave)
+        float mem = resume ? rec[RNN_A + 36] : 0.0f;     // de-emphasis state (tracked by every lane of the drawing wave)
         float pcm_new = 0.0f; // the sample just drawn (drawing wave)
-        float s2_own = 0.0f;  // state of unit u, replicated over the 16 lanes of its row
+        float s2_own = resume ? rec[RNN_A + u] : 0.0f;  // state of unit u, replicated over the 16 lanes of its row
+        if (P.state != nullptr) __syncthreads();  // (the mat-vec waves' product of the resumed state)
 
-        for (int fr = 0; fr < T; ++fr) {
+        for (int fr = P.f0; fr < P.f1; ++fr) {
             const float* feat = P.features + ((size_t)b * T + fr) * FPC_NB_FEATURES;
             const float shape_e = fpc_shape_exponent(feat[19]);
-            const float* cfb = P.cfb + ((size_t)b * T + fr) * GB;
+            const float* cfb = P.cfb + ((size_t)b * P.cf_T + (fr - P.f0)) * GB;
             const float cfb_z = cfb[u], cfb_r = cfb[RNN_B + u], cfb_n = cfb[2 * RNN_B + u];
             const float* fa = feat + (FPC_NB_FEATURES - FPC_LPC_ORDER);  // this frame's LPC, and the next frame's
             const float* fan = fa + (fr + 1 < T ? FPC_NB_FEATURES : 0);
@@ -575,6 +601,16 @@ __global__ __launch_bounds__(NTHREADS) void k_decode(const DecodeParams P) {
                     if (lane == 0) out[t] = fpc_pcm16(mem);
                 }
 #endif
+            }
+        }
+        if (rec != nullptr) {  // (behind the last sample's barrier X nothing writes these any more)
+            if (sl < RNN_B) {
+                rec[RNN_A + sl] = L.s2[sl];
+                rec[RNN_A + 16 + sl] = L.hist[sl];
+            }
+            if (sl == 0) {
+                *reinterpret_cast<float4*>(&rec[RNN_A + 32]) = *reinterpret_cast<const float4*>(&L.o_sig);
+                rec[RNN_A + 36] = mem;
             }
         }
     }

@@ -76,6 +76,14 @@ class LPCNet:
                                                    ws.data_ptr(), _lib.stream_ptr()), "fpc_lpcnet_condition")
         return cf
 
+    def set_chunk_frames(self, frames):
+        """frames per pass of synthesize (0: the whole utterance at once); a chunked pass needs a workspace that does
+        not grow with T and gives the same samples (fpc_lpcnet_set_chunk_frames)"""
+        _lib.check(_lib.lib().fpc_lpcnet_set_chunk_frames(self.handle, int(frames)), "fpc_lpcnet_set_chunk_frames")
+
+    def workspace_bytes(self, B, T):
+        return int(_lib.lib().fpc_lpcnet_workspace_bytes(self.handle, B, T))
+
     def last_decode_ms(self):
         return float(_lib.lib().fpc_lpcnet_last_decode_ms(self.handle))
 

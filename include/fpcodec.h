@@ -228,8 +228,18 @@ typedef struct fpc_lpcnet fpc_lpcnet;
 FPC_API int fpc_lpcnet_create(const fpc_lpcnet_weights* w, fpc_lpcnet** out);
 FPC_API void fpc_lpcnet_destroy(fpc_lpcnet* m);
 
-/* bytes of device workspace fpc_lpcnet_synthesize needs for (B,T) */
+/* bytes of device workspace fpc_lpcnet_synthesize / fpc_lpcnet_condition need for (B,T) with the handle's current
+ * chunk setting: B*T*1584 floats for a whole-utterance pass, B*(chunk*1584 + 768) floats -- independent of T -- for a
+ * chunked one */
 FPC_API long long fpc_lpcnet_workspace_bytes(const fpc_lpcnet* m, int B, int T);
+
+/* Frames per pass of fpc_lpcnet_synthesize (0, the default: the whole utterance in one pass; the environment variable
+ * FPC_LPCNET_CHUNK sets the default of new handles).  With frames > 0 an utterance longer than that is synthesised chunk by
+ * chunk -- frame-rate layers and conditioning products of a chunk (the convolutions' halo frames evaluated again), then the
+ * sample loop over it, the per-stream state (both GRU states, history ring, control block, de-emphasis) carried in a
+ * 2 kB record per utterance -- so the workspace does not grow with T.  Same samples bit for bit (tests); each chunk ends
+ * when its slowest utterance does, which costs time: the default stays one pass. */
+FPC_API int fpc_lpcnet_set_chunk_frames(fpc_lpcnet* m, int frames);
 
 /* test_lpcnet.py loop.  Device pointers.
  *   features [B,T,36] float32 (un-normalised: cepstrum, pitch, corr, 16 LPC)
@@ -245,8 +255,9 @@ FPC_API int fpc_lpcnet_synthesize(fpc_lpcnet* m, const float* features_dev, int 
 FPC_API int fpc_lpcnet_condition(fpc_lpcnet* m, const float* features_dev, int B, int T,
                          float* cfeat_dev, void* workspace_dev, fpc_stream s);
 
-/* average duration (ms) of the last decode-kernel launch measured with HIP
- * events on the launch stream; synchronises on those events. <0 if none. */
+/* duration (ms) of the last call's decode-kernel launch measured with HIP events on the launch stream (a chunked
+ * pass: from its first sample loop to its last, the chunks' frame-rate launches in between included); synchronises
+ * on those events. <0 if none. */
 FPC_API float fpc_lpcnet_last_decode_ms(fpc_lpcnet* m);
 
 /* diagnostic: which decode-kernel instance the model's sparsity pattern selects, as

@@ -1076,6 +1076,43 @@ def test_vocoder_long_utterance_parity(torch_cuda, vocoder, synth, oracle):
     assert int(np.abs(pcm[0].astype(np.int32)).max()) > 100  # a live signal, not silence
 
 
+def test_vocoder_chunked_pass_same_samples_bounded_workspace(torch_cuda, synth, oracle):
+    """fpc_lpcnet_set_chunk_frames: the frame-rate layers, the conditioning products and the sample loop chunk by chunk
+    with the per-stream state carried in a record -- the same samples bit for bit as the one-pass form and as the oracle
+    (chunks of 1, 5 and 7 frames over 23: ragged last chunk, halo frames at both ends of the utterance, a voiced and an
+    unvoiced stream), the conditioning vectors too, and a workspace that does not grow with T"""
+    from fpcodec_amd.lpcnet import LPCNet
+    w = synth.lpcnet_weights()
+    voc = LPCNet(w)
+    B, T = 3, 23
+    f = _voc_features(synth, oracle, B, T, utt0=3)
+    f[1, :, 19] = 0.9   # a voiced stream: the sharpened-pdf path through every chunk
+    sd = synth.seeds(B, utt0=3)
+    whole = voc.synthesize(f, sd).cpu().numpy()
+    cf_whole = voc.condition(f).cpu().numpy()
+    ref = oracle.LPCNet(w).synthesize(f[0], int(sd[0]))
+    assert np.array_equal(whole[0], ref)
+    for chunk in (1, 5, 7, 23, 50):
+        voc.set_chunk_frames(chunk)
+        got = voc.synthesize(f, sd).cpu().numpy()
+        nz = np.argwhere(got != whole)
+        assert nz.size == 0, f"chunk {chunk}: first mismatch at {nz[:3].tolist()}"
+        assert np.array_equal(voc.condition(f).cpu().numpy(), cf_whole), chunk
+    voc.set_chunk_frames(50)
+    per_frame = (128 * 3 + 1152 + 48) * 4
+    assert voc.workspace_bytes(256, 300) == voc.workspace_bytes(256, 30000) == 256 * (50 * per_frame + 768 * 4) + 256
+    assert voc.workspace_bytes(256, 40) == 256 * 40 * per_frame + 256      # shorter than a chunk: one pass
+    voc.set_chunk_frames(0)
+    assert voc.workspace_bytes(256, 300) == 256 * 300 * per_frame + 256
+    # five times the benchmark's length in chunks of 50 (30 launches of the sample loop) against the one-pass form
+    T = 1500
+    f = _voc_features(synth, oracle, 2, T, utt0=7)
+    sd = synth.seeds(2, utt0=7)
+    one = voc.synthesize(f, sd).cpu().numpy()
+    voc.set_chunk_frames(50)
+    assert np.array_equal(voc.synthesize(f, sd).cpu().numpy(), one)
+
+
 # ---- the weights-stationary predictor kernels (csrc/predictor_ws.h): the shipped form for the production shape ----
 def _ws_cfgs(cb_paths, tmp):
     """codebook configurations: the reference's four books, only the above-threshold ones, a 1-stage book, ragged stages, and a
