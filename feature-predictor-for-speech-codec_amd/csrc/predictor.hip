@@ -1881,8 +1881,8 @@ extern "C" int fpc_predictor_forward(fpc_predictor* p, const float* x_dev, int B
         WsArgs wa;
         const int rcw = ws_args(p, B, static_cast<hipStream_t>(s), &wa);
         if (rcw != FPC_OK) return rcw;
-        hipLaunchKernelGGL(k_forward_ws, dim3(ws_grid(wa)), dim3(NT), 0, static_cast<hipStream_t>(s), p->d, x_dev, L, h1_dev,
-                           h2_dev, y_dev, wa);
+        hipLaunchKernelGGL(k_forward_ws<false>, dim3(ws_grid(wa)), dim3(NT), 0, static_cast<hipStream_t>(s), p->d, x_dev, L, h1_dev,
+                           h2_dev, y_dev, wa, WsSave{});
         FPC_HIP(hipGetLastError());
 #ifdef FPC_WS_PROF
         ws_prof_print(p, "k_forward_ws", B, static_cast<hipStream_t>(s));
@@ -2210,15 +2210,23 @@ extern "C" int fpc_trainer_step(fpc_trainer* t, const float* feat_dev, int B, in
         refresh();
         t->step = 0;
     }
-    SplitArgs sp;  // forward and backward each run an utterance on 2-8 workgroups while the batch leaves CUs idle
-    {
+    SplitArgs sp;  // backward (and the row-split forward) run an utterance on 2-8 workgroups while the batch leaves CUs idle
+    if (ws_wanted(p)) {
+        // the forward on the weights-stationary kernel (predictor_ws.h): 16 utterances a group, the kept activations stored
+        // by the workgroup that evaluates them -- the same values as k_train_fwd's, bit for bit (tests)
+        WsArgs wa;
+        const int rc = ws_args(p, B, st, &wa);
+        if (rc != FPC_OK) return rc;
+        const WsSave sv{T.h1p, T.r1, T.z1, T.n1, T.hn1, T.h1, T.h2p, T.r2, T.z2, T.n2, T.hn2, T.h2, T.relu, T.th};
+        hipLaunchKernelGGL(k_forward_ws<true>, dim3(ws_grid(wa)), dim3(NT), 0, st, P, feat_dev, L, nullptr, nullptr, nullptr, wa, sv);
+    } else {
         const int rc = split_args(p, B, st, &sp);
         if (rc != FPC_OK) return rc;
+        if (two_roles())
+            hipLaunchKernelGGL(k_train_fwd_df, dim3(B * sp.n), dim3(NT), 0, st, P, feat_dev, L, T, sp);
+        else
+            hipLaunchKernelGGL(k_train_fwd, dim3(B * sp.n), dim3(NT), 0, st, P, feat_dev, L, T, sp);
     }
-    if (two_roles())
-        hipLaunchKernelGGL(k_train_fwd_df, dim3(B * sp.n), dim3(NT), 0, st, P, feat_dev, L, T, sp);
-    else
-        hipLaunchKernelGGL(k_train_fwd, dim3(B * sp.n), dim3(NT), 0, st, P, feat_dev, L, T, sp);
     const double cnt = (double)B * (L - 1) * F;
     hipLaunchKernelGGL(k_train_loss, dim3(B), dim3(256), sizeof(float) * (size_t)L * F, st, feat_dev, in, F, L,
                        (float)(2.0 / cnt), T);

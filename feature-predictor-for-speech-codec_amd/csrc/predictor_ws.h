@@ -145,8 +145,16 @@ struct __attribute__((aligned(16))) WsLds : SearchLds {
 #define WPROF_DUMP(frames)
 #endif
 
+// what the training forward keeps per sample n = utterance * L + frame for the backward pass (TrainBufs, k_train_fwd):
+// the activations of this workgroup's units for every utterance of the group; tanh outputs by the utterance's owner
+struct WsSave {
+    float *h1p, *r1, *z1, *n1, *hn1, *h1;         // [N][384]
+    float *h2p, *r2, *z2, *n2, *hn2, *h2, *relu;  // [N][128]
+    float* th;                                    // [N][18]
+};
 struct WsCtx {
     __amdgpu_buffer_rsrc_t rs;  // this group's granule block
+    int Lf;                     // frames of the launch (the training forward's sample index)
     int slice, nu, b0;          // this workgroup's slice, valid utterances of the group, first utterance
     int own;                    // utterance of the group whose prediction this workgroup needs (-1: none)
     unsigned* err;
@@ -537,12 +545,13 @@ __device__ __forceinline__ void ws_F_late(WsLds& L, const WsRegs& R, float (&pF)
     }
 }
 // ... and its last step for row `row` < 18 (the segment sums are complete: every wave of ws_F_late has passed a barrier since)
+template <bool TANH_ONLY = false>
 __device__ __forceinline__ float ws_F_out(const float (&pF)[8][2][16], int row) {
     const int tile = row >> 4, o = row & 15;
     const float acc = ((pF[0][tile][o] + pF[1][tile][o]) + (pF[2][tile][o] + pF[3][tile][o])) +
                       ((pF[4][tile][o] + pF[5][tile][o]) + (pF[6][tile][o] + pF[7][tile][o]));
     const float tt = fpc_tanhf(acc);
-    return tt + tt;  // the "dual" FC is the same Linear summed twice (wavernn.py:89-92)
+    return TANH_ONLY ? tt : tt + tt;  // the "dual" FC is the same Linear summed twice (wavernn.py:89-92)
 }
 
 // hop 1 gather by six waves (foreground 1-3, background 1-3): p < 384, six granules each; the waves of SIMD 0 have other
@@ -605,8 +614,10 @@ __device__ __forceinline__ bool ws_gather2(const WsCtx& X, WsLds& L, int p, unsi
 __device__ __forceinline__ void wsd_F(WsLds& L, const WsRegs& R, int fw, int lane, int ft);  // predictor_wsd.h
 // FC_ALL (the distributed encoder tail): the output layer's segment sums of all 16 utterances, no prediction formed here
 // FC_LATE (the teacher-forced forward): no output layer here -- the background evaluates it off the chain (ws_background)
-template <bool EARLY_I = false, bool FC_ALL = false, bool FC_LATE = false>
-__device__ __forceinline__ bool ws_foreground(const WsCtx& X, WsLds& L, const WsRegs& R, int t, int ft0, int& fg_epoch) {
+// SAVE (the training forward): the gates' activations of every sample go to *sv
+template <bool EARLY_I = false, bool FC_ALL = false, bool FC_LATE = false, bool SAVE = false>
+__device__ __forceinline__ bool ws_foreground(const WsCtx& X, WsLds& L, const WsRegs& R, int t, int ft0, int& fg_epoch,
+                                              const WsSave* sv = nullptr) {
     const int ft = ft0 + ws_opaque_zero();
     const int fw = ft0 >> 6, lane = ft & 63;
     const unsigned epoch = (unsigned)t + 1u;
@@ -633,7 +644,17 @@ __device__ __forceinline__ bool ws_foreground(const WsCtx& X, WsLds& L, const Ws
             const float z = fpc_sigmoidf(pi[PG] + ghz);
             const float n = fpc_tanhf(fmaf(r, ghn, pi[2 * PG]));
             const float hp = L.h1[base + lane];
-            L.h1[base + lane] = fmaf(z, hp - n, n);
+            const float hn = fmaf(z, hp - n, n);
+            L.h1[base + lane] = hn;
+            if (SAVE && (lane & 15) < X.nu) {
+                const size_t o = ((size_t)(X.b0 + (lane & 15)) * X.Lf + t) * WH1 + WU1 * X.slice + 3 * fw + (lane >> 4);
+                sv->h1p[o] = hp;
+                sv->r1[o] = r;
+                sv->z1[o] = z;
+                sv->n1[o] = n;
+                sv->hn1[o] = ghn;
+                sv->h1[o] = hn;
+            }
         }
         // (the same wave reads what it has just written: one in-order LDS queue per wave)
         if (lane < 16) {
@@ -671,7 +692,18 @@ __device__ __forceinline__ bool ws_foreground(const WsCtx& X, WsLds& L, const Ws
         const float z = fpc_sigmoidf(giz + ghz);
         const float n = fpc_tanhf(fmaf(r, ghn, gin));
         const float hp = L.h2[base + v];
-        L.h2[base + v] = fmaf(z, hp - n, n);
+        const float hn = fmaf(z, hp - n, n);
+        L.h2[base + v] = hn;
+        if (SAVE && (v & 15) < X.nu) {
+            const size_t o = ((size_t)(X.b0 + (v & 15)) * X.Lf + t) * WH2 + WU2 * X.slice + (v >> 4);
+            sv->h2p[o] = hp;
+            sv->r2[o] = r;
+            sv->z2[o] = z;
+            sv->n2[o] = n;
+            sv->hn2[o] = ghn;
+            sv->h2[o] = hn;
+            sv->relu[o] = hn > 0.0f ? hn : 0.0f;
+        }
         if (lane < WQ2) {
             const int i0 = 3 * lane, i1 = i0 + 1 < WV2 ? i0 + 1 : WV2 - 1, i2 = i0 + 2 < WV2 ? i0 + 2 : WV2 - 1;
             ws_store(X, WOFF_H2 + X.slice * WQ2 + lane, epoch, L.h2[base + i0], L.h2[base + i1], L.h2[base + i2]);
@@ -707,7 +739,7 @@ __device__ __forceinline__ bool ws_foreground(const WsCtx& X, WsLds& L, const Ws
 
 // BACKGROUND, frame t: wave 0: B(t) and half of hop 2's gather; waves 1-3: half of hop 1's gather, then A(t+1)
 // FC_LATE: y_late = the owned utterance's output row of frame t
-template <bool EARLY_I = false, bool FC_LATE = false>
+template <bool EARLY_I = false, bool FC_LATE = false, bool TANH_ONLY = false>
 __device__ __forceinline__ bool ws_background(const WsCtx& X, WsLds& L, const WsRegs& R, int t, bool last, int bt,
                                               float* y_late = nullptr) {
     const int bw = bt >> 6, lane = (bt + ws_opaque_zero()) & 63;
@@ -745,7 +777,7 @@ __device__ __forceinline__ bool ws_background(const WsCtx& X, WsLds& L, const Ws
         df_signal(&L.sig[WSIG_FB]);
         if (bw == 3) {
             if (!df_wait(&L.sig[WSIG_FB], 3 * (t + 1), &L.dead)) return false;
-            if (lane < WFC) y_late[lane] = ws_F_out(L.pFl[t & 1], lane);
+            if (lane < WFC) y_late[lane] = ws_F_out<TANH_ONLY>(L.pFl[t & 1], lane);
         }
     }
     return true;
@@ -773,6 +805,7 @@ __device__ __forceinline__ WsCtx ws_ctx(const WsArgs& S, int group, int slice) {
     WsCtx X;
     X.rs = __builtin_amdgcn_make_buffer_rsrc((void*)(S.g + (size_t)group * WGRANULES), 0, WGRANULES * 16, 0x00020000);
     X.slice = slice;
+    X.Lf = 0;
     X.b0 = group * WG;
     X.nu = S.B - X.b0 < WG ? S.B - X.b0 : WG;
     X.err = S.err;
@@ -783,21 +816,25 @@ __device__ __forceinline__ WsCtx ws_ctx(const WsArgs& S, int group, int slice) {
     return X;
 }
 
+// TRAIN: the training forward (k_train_fwd's contract): states from zero, the kept activations to `sv`, tanh outputs to
+// sv.th instead of predictions to y, no final states
+template <bool TRAIN>
 __global__ __launch_bounds__(NT) void k_forward_ws(const PredDev P, const float* __restrict__ x, int Lf, float* h1, float* h2,
-                                                   float* __restrict__ y, const WsArgs S) {
+                                                   float* __restrict__ y, const WsArgs S, const WsSave sv) {
     __shared__ WsLds L;
     const int tid = threadIdx.x;
     int group, slice;
     if (!ws_role(S.ngroups, group, slice)) return;
     WsCtx X = ws_ctx(S, group, slice);
+    X.Lf = Lf;
     WsRegs R;
     for (int i = tid; i < WH1 * WG; i += NT) {  // state images [k][u] from [utterance][k]
         const int u = i / WH1, k = i - u * WH1;
-        L.h1[k * WG + u] = u < X.nu ? h1[(size_t)(X.b0 + u) * WH1 + k] : 0.0f;
+        L.h1[k * WG + u] = (!TRAIN && u < X.nu) ? h1[(size_t)(X.b0 + u) * WH1 + k] : 0.0f;
     }
     for (int i = tid; i < WH2 * WG; i += NT) {
         const int u = i / WH2, k = i - u * WH2;
-        L.h2[k * WG + u] = u < X.nu ? h2[(size_t)(X.b0 + u) * WH2 + k] : 0.0f;
+        L.h2[k * WG + u] = (!TRAIN && u < X.nu) ? h2[(size_t)(X.b0 + u) * WH2 + k] : 0.0f;
     }
     for (int i = tid; i < WIN * WG; i += NT) {
         const int u = i / WIN, k = i - u * WIN;
@@ -841,16 +878,19 @@ __global__ __launch_bounds__(NT) void k_forward_ws(const PredDev P, const float*
                 if (xdst[j] >= 0) L.x[xdst[j]] = xa[j];
             df_signal(&L.sig[WSIG_X]);
             x_row(t + 2, xa);
-            if (!ws_foreground<true, false, true>(X, L, R, t, tid, fg_epoch)) break;
+            if (!ws_foreground<true, false, true, TRAIN>(X, L, R, t, tid, fg_epoch, &sv)) break;
             WSTAMP(12)
         }
         __builtin_amdgcn_s_setprio(0);
     } else {
         for (int tb = 0; tb < Lf; ++tb)
-            if (!ws_background<true, true>(X, L, R, tb, tb + 1 == Lf, tid - WFGT, y + ((size_t)(X.b0 + slice) * Lf + tb) * WFC)) break;
+            if (!ws_background<true, true, TRAIN>(X, L, R, tb, tb + 1 == Lf, tid - WFGT,
+                                                  (TRAIN ? sv.th : y) + ((size_t)(X.b0 + slice) * Lf + tb) * WFC))
+                break;
     }
     WPROF_DUMP(Lf)
     __syncthreads();
+    if (TRAIN) return;  // (a launch that gave up leaves its status bit: the step's Adam update is skipped, FPC_ERR_TIMEOUT)
     // new states of this workgroup's units; a launch that gave up fails loudly: NaN outputs and states, FPC_ERR_TIMEOUT
     const bool dead = ws_dead(L);
     const float qnan = __uint_as_float(0x7fc00000u);

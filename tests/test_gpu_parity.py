@@ -837,13 +837,16 @@ def test_train_step_row_split_equals_single_workgroup_form(torch_cuda, synth, mo
     """the training step with forward and backward on 2 / 4 / 8 workgroups per utterance (slices of the states and of the
     back-propagated vectors exchanged as granules) against one workgroup per utterance: losses, every gradient and the
     parameters after two steps, bit for bit -- with the forward as the shipped two-role kernel and (modes "p0", "p2":
-    FPC_PRED_DF=0) as the phase kernel"""
+    FPC_PRED_DF=0) as the phase kernel, and (mode "ws", the default) on the weights-stationary kernel"""
     from fpcodec_amd.train_frame import Trainer
     from fpcodec_amd.wavernn import Wavernn
     feat = synth.predictor_features(6, 40, utt0=4200)
     out = {}
-    for mode in ("0", "2", "4", "8", "p0", "p2"):
-        monkeypatch.setenv("FPC_PRED_SPLIT", mode[-1])
+    for mode in ("0", "2", "4", "8", "p0", "p2", "ws"):
+        if mode == "ws":  # the shipped default: the forward on the weights-stationary kernel (one part-filled group of 16)
+            monkeypatch.delenv("FPC_PRED_SPLIT", raising=False)
+        else:
+            monkeypatch.setenv("FPC_PRED_SPLIT", mode[-1])
         if mode[0] == "p":
             monkeypatch.setenv("FPC_PRED_DF", "0")
         else:
@@ -856,7 +859,7 @@ def test_train_step_row_split_equals_single_workgroup_form(torch_cuda, synth, mo
         l1 = tr.step(feat)
         sd = m.state_dict()
         out[mode] = ([np.float32(l0), np.float32(l1)] + [g[k] for k in sorted(g)] + [sd[k].numpy() for k in sorted(sd)])
-    for mode in ("2", "4", "8", "p0", "p2"):
+    for mode in ("2", "4", "8", "p0", "p2", "ws"):
         for a, b in zip(out["0"], out[mode]):
             assert not np.isnan(b).any() and np.array_equal(a, b), mode
 
