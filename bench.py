@@ -235,7 +235,7 @@ def e2e_config5(voc, torch, synth, parallel, rank, world, L=300):
            "entropy_bits_per_symbol": ent, "bits_per_frame": bits_frame, "bitrate_bps": bits_frame * 100.0,
            "decode_features_ms": (t4 - t3) * 1e3,
            "predictor_roofline": {
-               "bound": "mfma", "unit": "TFLOP/s", "peak": PEAK_F32_TFLOPS, "kernel": "k_encode_ws",
+               "bound": "mfma", "unit": "TFLOP/s", "peak": PEAK_F32_TFLOPS, "kernel": "k_encode_wsd",
                "kernel_ms": enc_ms, "achieved": enc_flop / (enc_ms * 1e-3) / 1e12,
                "frac": enc_flop / (enc_ms * 1e-3) / 1e12 / PEAK_F32_TFLOPS,
                "forward_kernel": "k_forward_ws", "forward_ms": fwd_ms,

@@ -1780,8 +1780,8 @@ static void ws_prof_print(fpc_predictor* p, const char* who, int B, hipStream_t 
     (void)hipStreamSynchronize(st);
     volatile unsigned* w = (volatile unsigned*)p->status_host;
     fprintf(stderr, "%s B=%d cycles/frame FG: I %u waitA %u gates1 %u gather1 %u waitH1 %u C %u waitB %u gates2 %u gather2 %u waitH2 %u "
-            "fc %u out %u tail %u | rendezvous %u frame-tail %u hop3 %u | BG wave 1: waitP1 %u gather1 %u waitH1 %u A %u waitC %u (unused %u) "
-            "toRendezvous %u rest %u | tail stamps 25..31: %u %u %u %u %u %u %u\n", who, B, w[1], w[2], w[3], w[4], w[5], w[6], w[7], w[8], w[9], w[10], w[11], w[12], w[13],
+            "fc %u out %u tail %u | rendezvous %u frame-tail(wsd: rows+outputs) %u hop3(wsd: last barrier) %u | BG wave 1: waitP1 %u gather1 %u waitH1 %u A %u waitC %u (unused %u) "
+            "toRendezvous %u rest %u | tail stamps 25..31 (wsd: residual, stage 1, scalar, gather 1, survivors, stage 2, gather 2): %u %u %u %u %u %u %u\n", who, B, w[1], w[2], w[3], w[4], w[5], w[6], w[7], w[8], w[9], w[10], w[11], w[12], w[13],
             w[21], w[22], w[23], w[14], w[15], w[16], w[17], w[18], w[19], w[20], w[24], w[26], w[27], w[28], w[29], w[30], w[31], w[32]);
     for (int k = 1; k < 40; ++k) w[k] = 0;
 }
@@ -2040,7 +2040,8 @@ extern "C" int fpc_encode(fpc_predictor* p, const fpc_codebooks* cb, const float
             FPC_HIP(hipGetLastError());
         }
 #ifdef FPC_WS_PROF
-        ws_prof_print(p, qtz ? "k_encode_ws qtz=1" : "k_encode_ws qtz=0", B, static_cast<hipStream_t>(s));
+        ws_prof_print(p, (tl && tl[0] == 'p') ? (qtz ? "k_encode_ws qtz=1" : "k_encode_ws qtz=0") : (qtz ? "k_encode_wsd qtz=1" : "k_encode_wsd qtz=0"), B,
+                      static_cast<hipStream_t>(s));
 #endif
         return after_launch(p, static_cast<hipStream_t>(s));
     }

@@ -36,5 +36,11 @@ if os.path.exists(os.path.join(e, "summary.txt")):
 txt = open(os.path.join(o, "ws_check.txt")).read() + "\n---- stage profile (-DFPC_WS_PROF -DFPC_WS_PROF_TAIL build, workgroup 5 of group 0; cycles per frame) ----\n" + \
     "\n".join(l for l in open(os.path.join(o, "ws_prof.txt")).read().splitlines() if "cycles/frame" in l or "frames" in l or "frame above" in l)
 open(os.path.join(P, "r04_predictor_ws.txt"), "w").write(f"tree {head}; library: " + open(os.path.join(o, "build_info.txt")).read() + txt + "\n")
-shutil.copy(os.path.join(o, "train.txt"), os.path.join(P, "r04_train_timing.txt"))
+open(os.path.join(P, "r04_train_timing.txt"), "w").write(
+    f"tree {head}; tools/time_train.py: the shipped step (forward on the weights-stationary kernel k_forward_ws<true>), then FPC_PRED_WS=0\n" +
+    "".join(l for l in open(os.path.join(o, "train.txt")) if "amdgpu.ids" not in l))
+if os.path.exists(os.path.join(o, "chunk.txt")):
+    open(os.path.join(P, "r04_chunked_decode_rerun.txt"), "w").write(
+        f"tree {head}; tools/chunk_bench.py 0 150 100 50 0 (the table of r04_chunked_decode.txt measured again in the round's last pass)\n" +
+        "".join(l for l in open(os.path.join(o, "chunk.txt")) if "amdgpu.ids" not in l))
 print("collected into profiles/r04_*")

@@ -20,4 +20,7 @@ echo "== predictor kernels: stage profile (diagnostic build)"
 FPC_LIB_PATH=build_variants/lib_ws_prof.so timeout -k 10 300 python tools/ws_prof.py > $o/ws_prof.txt 2>&1 || true
 grep -c cycles $o/ws_prof.txt || true
 echo "== training step"; timeout -k 10 200 python tools/time_train.py > $o/train.txt 2>&1; tail -2 $o/train.txt
+echo "FPC_PRED_WS=0 (the step's forward on the two-role row-split kernel):" >> $o/train.txt
+FPC_PRED_WS=0 timeout -k 10 200 python tools/time_train.py 2>&1 | grep "train step" >> $o/train.txt
+echo "== chunked decode"; timeout -k 10 300 python tools/chunk_bench.py 0 150 100 50 0 > $o/chunk.txt 2>&1; tail -5 $o/chunk.txt
 ls $o
