@@ -89,9 +89,11 @@ FPC_API void fpc_predictor_destroy(fpc_predictor* p);
  *     groups follow as workgroups retire; a partly filled last group costs what a full one does).  Each workgroup keeps
  *     1/32 of every weight matrix in LDS for the whole launch; the new state values go round as 16-byte granules
  *     {epoch, 3 values} in a block that belongs to the predictor handle and is cleared on the stream before each launch.
+ *     fpc_trainer_step's forward is the same kernel (the activations the backward pass keeps are stored by the workgroups
+ *     that evaluate them); the teacher-forced kernels take the output layer and the input product off the frame's chain.
  * (2) Row split (csrc/predictor.hip, predictor_df.h) -- every other shape, FPC_PRED_WS=0, a pinned split, and the training
- *     step: one utterance on 1, 2, 4 or 8 workgroups (one CU each) while the batch leaves CUs idle (B x n <= number of
- *     CUs), the slices of the recurrent state exchanged as tagged 8-byte words; weights streamed from L2 every frame.
+ *     step's backward pass (and its forward under those switches): one utterance on 1, 2, 4 or 8 workgroups (one CU
+ *     each) while the batch leaves CUs idle (B x n <= number of CUs), the slices of the recurrent state exchanged as tagged 8-byte words; weights streamed from L2 every frame.
  *     Two-role kernels (three waves walk a frame's latency chain, the others stream the recurrent products; LDS counters
  *     instead of workgroup barriers), or with FPC_PRED_DF=0 the phase-after-phase kernels (the tests' reference form); the
  *     training step's forward follows the same switch.
