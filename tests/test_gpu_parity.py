@@ -1060,6 +1060,9 @@ def test_vocoder_stress_parity_randomised(torch_cuda, synth, oracle):
         for b in range(B):
             nz = np.nonzero(pcm[b] != refs[b])[0]
             assert nz.size == 0, f"weights {wseed} {dens} utt {b}: first mismatch at sample {nz[:5]}"
+        # the chunked pass (state carried between launches, the resumed sparse product) on every kernel instance
+        voc.set_chunk_frames(7 + wseed % 5)
+        assert np.array_equal(voc.synthesize(f, sd).cpu().numpy(), pcm), f"weights {wseed}: chunked pass differs"
         total += B * (T * 160 - 17)
     assert total > 300000
 
