@@ -1249,6 +1249,51 @@ def test_weights_stationary_timeout_is_an_error_not_garbage(torch_cuda, synth, c
         assert np.array_equal(a, b)
 
 
+def test_trainer_step_that_gives_up_updates_nothing_and_the_count_follows(torch_cuda, synth, monkeypatch):
+    """the training step whose forward (weights-stationary kernel: one workgroup of group 0 withholds, its partners time out
+    after 20 ms) gave up: the call fails with the timeout code, NO parameter moves (the Adam launches read the latched status
+    word), and after the error has been reported the next steps continue with Adam's bias corrections of the updates actually
+    applied -- parameters bit-identical to a trainer that never saw the failure (the step counter)"""
+    from fpcodec_amd._lib import FpcError
+    from fpcodec_amd.train_frame import Trainer
+    from fpcodec_amd.wavernn import Wavernn
+    feat = synth.predictor_features(6, 30, utt0=4300)
+
+    def fresh():
+        m = Wavernn(20, 384, 128, 18)
+        m.load_state_dict(synth.predictor_state_dict())
+        return m, Trainer(m, lr=1e-3, max_batch=6, max_frames=30)
+
+    m0, t0 = fresh()
+    ref_losses = [t0.step(feat) for _ in range(3)]
+    t0.sync()
+    ref = {k: v.numpy().copy() for k, v in m0.state_dict().items()}
+
+    m1, t1 = fresh()
+    l0 = t1.step(feat)
+    t1.sync()
+    before = {k: v.numpy().copy() for k, v in m1.state_dict().items()}
+    monkeypatch.setenv("FPC_TEST_WITHHOLD_PUBLISH", "1")
+    monkeypatch.setenv("FPC_SPIN_LIMIT_US", "20000")
+    with pytest.raises(FpcError, match="timed out"):
+        t1.step(feat)
+    monkeypatch.delenv("FPC_TEST_WITHHOLD_PUBLISH")
+    monkeypatch.delenv("FPC_SPIN_LIMIT_US")
+    try:
+        m1.check()  # (reports and clears whatever the failed step left)
+    except FpcError:
+        pass
+    t1.sync()
+    after = {k: v.numpy() for k, v in m1.state_dict().items()}
+    for k in before:
+        assert np.array_equal(before[k], after[k]), f"{k} moved in a step that gave up"
+    l1, l2 = t1.step(feat), t1.step(feat)
+    assert [l0, l1, l2] == ref_losses
+    t1.sync()
+    for k, v in m1.state_dict().items():
+        assert np.array_equal(v.numpy(), ref[k]), k
+
+
 def test_encoder_mask_mode_and_multi_stage_lo_vs_reference_golden(torch_cuda, model, cb_paths, tmp_path):
     """the two reference behaviours the fused kernels do not cover, served by the host loop of Wavernn.encoder (predictor step
     and searches on the device, one frame at a time) against golden G12, generated by tests/golden/make_golden_modes.py from
