@@ -688,6 +688,9 @@ def test_bench_rccl_branch_single_rank(torch_cuda, tmp_path):
     j = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
     assert j["n_gpus"] == 1 and j["distinct_gpus"] == 1 and len(j["ranks"]) == 1 and j["ranks"][0]["pci_bus_id"] != "unknown"
     assert j["e2e"]["ranks"] == 1 and j["e2e"]["utterances"] == 128
+    pr = j["e2e"]["predictor_roofline"]  # the predictor kernels against the f32 MFMA peak
+    assert pr["bound"] == "mfma" and pr["kernel"] == "k_encode_wsd" and 0.0 < pr["frac"] < 1.0 and 0.0 < pr["forward_frac"] < 1.0
+    assert abs(pr["achieved"] - pr["algorithmic_flop"] / (pr["kernel_ms"] * 1e-3) / 1e12) < 1e-6
 
 
 def test_train_cb_stage_loop_vs_reference_golden(torch_cuda, synth, golden, tmp_path):
