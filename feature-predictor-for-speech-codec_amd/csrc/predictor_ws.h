@@ -884,8 +884,8 @@ __global__ __launch_bounds__(NT) void k_forward_ws(const PredDev P, const float*
         __builtin_amdgcn_s_setprio(0);
     } else {
         for (int tb = 0; tb < Lf; ++tb)
-            if (!ws_background<true, true, TRAIN>(X, L, R, tb, tb + 1 == Lf, tid - WFGT,
-                                                  (TRAIN ? sv.th : y) + ((size_t)(X.b0 + slice) * Lf + tb) * WFC))
+            if (!ws_background<true, true, TRAIN>(X, L, R, tb, tb + 1 == Lf, tid - WFGT,  // (the row of the owned utterance, if any)
+                                                  owner ? (TRAIN ? sv.th : y) + ((size_t)(X.b0 + slice) * Lf + tb) * WFC : nullptr))
                 break;
     }
     WPROF_DUMP(Lf)
