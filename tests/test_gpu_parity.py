@@ -1137,7 +1137,18 @@ def _ws_cfgs(cb_paths, tmp):
     p = os.path.join(tmp, "degenerate.npy")
     np.save(p, c)
     deg = dict(full, cb_path=p)
-    return {"full": full, "hi_only": hi, "one_stage": one, "ragged": rag, "degenerate": deg}
+    # near ties: both stages are clouds of width 1e-7 around a few centres, so the best distances agree in their high 32 bits
+    # (sign, exponent, 20 mantissa bits) but not in the low ones -- the selections' high-word fast paths must hand over to the
+    # float64 passes exactly then (predictor_wsd.h: hw_argmin, the first stage's rank)
+    rng = np.random.default_rng(99)
+    n = np.load(cb_paths["vq_hi"]).copy()
+    for st in range(n.shape[0]):
+        centres = n[st, :8].copy()
+        n[st] = centres[rng.integers(0, 8, n.shape[1])] + 1e-7 * rng.standard_normal(n[st].shape)
+    pn = os.path.join(tmp, "near_ties.npy")
+    np.save(pn, n)
+    near = dict(full, cb_path=pn)
+    return {"full": full, "hi_only": hi, "one_stage": one, "ragged": rag, "degenerate": deg, "near_ties": near}
 
 
 def test_weights_stationary_kernels_equal_row_split_forms(torch_cuda, model, synth, oracle, cb_paths, monkeypatch, tmp_path):
@@ -1146,7 +1157,8 @@ def test_weights_stationary_kernels_equal_row_split_forms(torch_cuda, model, syn
     phase-after-phase kernels (FPC_PRED_WS=0, FPC_PRED_DF=0, one workgroup per utterance) and the oracle: forward incl.
     carried states, encoder with and without quantisation incl. symbols and histograms, receiver -- bit for bit, for 1 / 7 /
     16 / 33 / 128 / 200 utterances (partly filled groups, two rounds of groups), on BOTH hop paths (FPC_FAST_HOP=0: write-through
-    stores, the path a placement on several XCDs takes) and for five codebook configurations"""
+    stores, the path a placement on several XCDs takes) and for six codebook configurations (the last two live on the
+    selections' float64 fallbacks: exact ties, and distances that agree in their high words only)"""
     torch = torch_cuda
     cfgs = _ws_cfgs(cb_paths, str(tmp_path))
 
@@ -1160,7 +1172,7 @@ def test_weights_stationary_kernels_equal_row_split_forms(torch_cuda, model, syn
         return ([t.cpu().numpy() for t in (y, h1, h2, y2, h1b, h2b)] + [t.cpu().numpy() for t in enc[:6]] + list(enc[6]) +
                 [enc[7].cpu().numpy()] + [t.cpu().numpy() for t in enc2[:6]] + [dec.cpu().numpy()])
 
-    for B, L, names in ((1, 30, ("full",)), (7, 40, ("full", "hi_only", "one_stage", "ragged", "degenerate")), (16, 33, ("full",)),
+    for B, L, names in ((1, 30, ("full",)), (7, 40, ("full", "hi_only", "one_stage", "ragged", "degenerate", "near_ties")), (16, 33, ("full",)),
                         (33, 25, ("full", "ragged")), (128, 60, ("full",)), (200, 20, ("full", "degenerate"))):
         feat = torch.from_numpy(synth.predictor_features(B, L, utt0=7000)).cuda()
         for name in names:
