@@ -174,6 +174,11 @@ def e2e_config5(voc, torch, synth, parallel, rank, world, L=300):
                bl_cb_path=paths["vq_lo"], l1=0.09, l2=0.28, qtz=True)
     model = Wavernn(in_features=20, gru_units1=384, gru_units2=128, fc_units=18)
     model.load_state_dict(synth.predictor_state_dict())
+    if world > max(1, torch.cuda.device_count()):
+        # ranks folded onto fewer devices (the gloo rehearsal): the predictor's multi-workgroup forms need all workgroups
+        # of a group resident at once, which two processes on one GPU cannot promise each other -- one workgroup per
+        # utterance (include/fpcodec.h "Kernel forms"; unpinned, every group would decide for the fallback after 10 ms)
+        model.set_split(1)
     total = E2E_PER_GPU * world
     lo, hi = parallel.shard_range(total, rank, world)
     B = hi - lo

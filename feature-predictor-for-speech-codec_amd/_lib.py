@@ -7,11 +7,12 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("FPC_LIB_PATH") or os.path.join(_HERE, "libfpcodec.so")  # override: kernel-variant experiments
 _lib = None
+ABI_VERSION = 2  # the FPC_ABI_VERSION of include/fpcodec.h this binding is written against
 
 SYMBOLS = [
     "fpc_last_error", "fpc_abi_version", "fpc_build_info", "fpc_device_count",
     "fpc_predictor_create", "fpc_predictor_destroy", "fpc_predictor_forward", "fpc_predictor_status",
-    "fpc_predictor_set_split",
+    "fpc_predictor_set_split", "fpc_predictor_fallback_groups",
     "fpc_codebooks_create", "fpc_codebooks_destroy", "fpc_codebooks_hist_size",
     "fpc_encode", "fpc_decode_features", "fpc_vq_quantize", "fpc_scl_quantize", "fpc_ceps2lpc",
     "fpc_lpcnet_create", "fpc_lpcnet_destroy", "fpc_lpcnet_workspace_bytes",
@@ -65,6 +66,15 @@ def lib():
                 f"{LIB_PATH} is missing: build the HIP extension first "
                 "(python -c 'import __graft_entry__ as g; g.build()'); there is no CPU fallback")
         L = C.CDLL(LIB_PATH)
+        # the version first: symbol sets and signatures differ between versions (an older library reached through
+        # FPC_LIB_PATH must be named as such, not fail at some symbol lookup)
+        try:
+            got = int(L.fpc_abi_version())
+        except AttributeError:
+            got = -1
+        if got != ABI_VERSION:
+            raise FpcError(f"{LIB_PATH} has ABI version {got}, this binding needs {ABI_VERSION} "
+                           "(include/fpcodec.h FPC_ABI_VERSION): rebuild the library from this tree")
         L.fpc_last_error.restype = C.c_char_p
         L.fpc_build_info.restype = C.c_char_p
         L.fpc_lpcnet_workspace_bytes.restype = C.c_longlong
@@ -89,6 +99,7 @@ def lib():
         L.fpc_predictor_destroy.argtypes = [C.c_void_p]
         L.fpc_predictor_status.argtypes = [C.c_void_p]
         L.fpc_predictor_set_split.argtypes = [C.c_void_p, C.c_int]
+        L.fpc_predictor_fallback_groups.argtypes = [C.c_void_p]
         L.fpc_predictor_forward.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p,
                                             C.c_void_p, C.c_void_p, C.c_void_p]
         L.fpc_codebooks_create.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
@@ -97,7 +108,7 @@ def lib():
         L.fpc_codebooks_destroy.argtypes = [C.c_void_p]
         L.fpc_codebooks_hist_size.argtypes = [C.c_void_p]
         L.fpc_encode.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float,
-                                 C.c_float, C.c_int] + [C.c_void_p] * 9
+                                 C.c_float, C.c_int] + [C.c_void_p] * 10
         L.fpc_decode_features.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
                                           C.c_void_p, C.c_void_p]
         L.fpc_vq_quantize.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p,

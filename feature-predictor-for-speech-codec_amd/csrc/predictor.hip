@@ -29,11 +29,6 @@ namespace {
 #ifndef FPC_NT
 #define FPC_NT 512
 #endif
-#ifdef FPC_WAVES_EU
-#define FPC_OCC __attribute__((amdgpu_waves_per_eu(FPC_WAVES_EU, FPC_WAVES_EU)))
-#else
-#define FPC_OCC
-#endif
 #ifndef FPC_CD
 #define FPC_CD 16
 #endif
@@ -73,6 +68,14 @@ struct SplitCtx {
     bool no_fast = false;           // ... unless FPC_FAST_HOP=0 forbids them
 };
 constexpr unsigned FPC_ST_TIMEOUT = 1u, FPC_ST_NONFINITE = 2u;
+// A spin reads the clock every 64 polls (~10-100 us apart while the wave runs).  A gap between two reads beyond this bound
+// means the wave itself was descheduled (queue preemption, a debugger) and says nothing about the partner: the spin's
+// clock starts again.  A quarter of the give-up bound, but never below 1 ms -- with a short bound (FPC_SPIN_LIMIT_US below
+// ~0.4 ms) every ordinary gap would exceed limit / 4, the clock would restart at every check and the spin never give up.
+__device__ __forceinline__ unsigned long long spin_rearm_gap(unsigned long long limit) {
+    const unsigned long long q = limit / 4;
+    return q > 100000ull ? q : 100000ull;  // s_memrealtime ticks (100 MHz)
+}
 typedef __attribute__((address_space(1))) unsigned gu32;
 __device__ __forceinline__ unsigned status_load(const unsigned* w) {
     return __hip_atomic_load((gu32*)w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -111,7 +114,7 @@ __device__ __forceinline__ float await_granule(unsigned long long* g, unsigned e
             const unsigned long long now = __builtin_amdgcn_s_memrealtime();
             // (two time reads are ~10-100 us apart while the wave runs; a much larger gap means the wave itself was
             //  descheduled -- queue preemption, a debugger -- and says nothing about the partner: the clock starts again)
-            if (t0 == 0 || now - last > X.limit / 4) t0 = now;
+            if (t0 == 0 || now - last > spin_rearm_gap(X.limit)) t0 = now;
             last = now;
             if (now - t0 > X.limit || (status_load(X.err) & FPC_ST_TIMEOUT) != 0u) {
                 status_or(X.err, FPC_ST_TIMEOUT);
@@ -153,7 +156,6 @@ struct CbDev {
     const double *vq_hi0, *vq_hi1, *vq_lo;     // transposed [17][N]
     const double *vq_hi0_r, *vq_hi1_r, *vq_lo_r;  // row-major [N][17] (entry fetch)
     const double *scl_hi, *scl_lo;
-    const double *vq_hi0_p, *vq_hi1_p, *vq_lo_p;  // coordinate pairs [9][N][2] (16-byte loads, one entry per lane; coordinate 17 = 0)
 };
 
 // workgroup barrier for data that changes hands through LDS only: __syncthreads also waits for the wave's outstanding
@@ -182,50 +184,12 @@ struct __attribute__((aligned(16))) SearchLds {
     long long prof[16];  // diagnostic builds only: cycle stamps of the search phases
 #endif
 };
-struct __attribute__((aligned(16))) PredLds : SearchLds {
-    float x[MAX_IN];
-    float h1[MAX_H1];
-    float h2[MAX_H2];
-    float pi[4][3 * MAX_H1];  // segment sums of the input mat-vec rows [segment][row]
-    float ph[4][3 * MAX_H1];  // ... of the recurrent mat-vec rows
-    float pf[8][MAX_FC];      // ... of the output layer
-    float relu[MAX_H2];
-    float fo[MAX_FC];
-#ifdef FPC_PRED_PROF
-    long long pprof[12], plast;  // diagnostic builds only: cycles per phase of the predictor step, summed over frames
-#endif
-};
 #ifdef FPC_VQ_PROF
 #define VQ_STAMP(k) \
     if (tid == 0) L.prof[k] = clock64();
 #else
 #define VQ_STAMP(k)
 #endif
-#ifdef FPC_PRED_PROF
-#define PSTAMP(k)                                           \
-    if (tid == 0) {                                         \
-        const long long now_ = __builtin_readcyclecounter(); \
-        L.pprof[k] += now_ - L.plast;                       \
-        L.plast = now_;                                     \
-    }
-#else
-#define PSTAMP(k)
-#endif
-
-// k-ordered fmaf chains of one row over v[0..K) with weights wT[k][R]: 16 loads in flight per block
-__device__ __forceinline__ float chain1(const float* __restrict__ wT, const float* v, int K, int R, int r, float a) {
-    int k = 0;
-    for (; k + 16 <= K; k += 16) {
-        float w[16];
-#pragma unroll
-        for (int j = 0; j < 16; ++j) w[j] = wT[(size_t)(k + j) * R + r];
-#pragma unroll
-        for (int j = 0; j < 16; ++j) a = fmaf(v[k + j], w[j], a);
-    }
-    for (; k < K; ++k) a = fmaf(v[k], wT[(size_t)k * R + r], a);
-    return a;
-}
-
 // four adjacent rows (r..r+3, R % 4 == 0) advance together: one 16-byte load per k serves 4 chains (dword loads
 // would be bound by the texture-address unit, not by L2).  The loads run as a ROLLING WINDOW of CD k-steps: a
 // register is refilled with k + CD as soon as k has been used, so CD - 1 loads stay in flight for the whole chain
@@ -285,102 +249,6 @@ __device__ __forceinline__ int segments(int K) {
     const int S = K >= 256 ? 4 : (K >= 64 ? 2 : 1);
     return K % S == 0 ? S : 1;
 }
-__device__ __forceinline__ float seg_tree(const float (*p)[3 * MAX_H1], int S, int row) {
-    if (S == 4) return (p[0][row] + p[1][row]) + (p[2][row] + p[3][row]);
-    if (S == 2) return p[0][row] + p[1][row];
-    return p[0][row];
-}
-
-// ---- GRU layer: both mat-vecs in one pass over (matrix, row quad, segment) work items ----
-__device__ __forceinline__ void gru_rows(const float* __restrict__ wiT, const float* __restrict__ whT,
-                         const float* __restrict__ bi, const float* __restrict__ bh,
-                         const float* x, int K, const float* h, int H, PredLds& L, int tid, int nsplit = 1, int half = 0,
-                         int part = 0 /* 0: both mat-vecs, 1: recurrent only, 2: input only */) {
-    const int R = 3 * H;
-    const int Qg = H / 4 / nsplit;  // row quads per gate in this workgroup's slice of the units (H % (4 nsplit) == 0)
-    const int Q = 3 * Qg;
-    const int Si = segments(K), Sh = segments(H);
-    const int n_h = Q * Sh, n_all = n_h + Q * Si;
-    const int it0 = part == 2 ? n_h : 0, it1 = part == 1 ? n_h : n_all;
-    for (int it = it0 + tid; it < it1; it += NT) {
-        const bool is_h = it < n_h;
-        const int j = is_h ? it : it - n_h;
-        const int q = j % Q, sg = j / Q;  // consecutive threads -> adjacent row quads: coalesced 16-byte loads
-        const int gate = q / Qg, qq = q - gate * Qg;
-        const int len = (is_h ? H : K) / (is_h ? Sh : Si), k0 = sg * len, r = gate * H + 4 * (half * Qg + qq);
-        float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (sg == 0) a = *reinterpret_cast<const float4*>(&(is_h ? bh : bi)[r]);
-        chain4((is_h ? whT : wiT) + (size_t)k0 * R, (is_h ? h : x) + k0, len, R, r, a);
-        *reinterpret_cast<float4*>(&(is_h ? L.ph : L.pi)[sg][r]) = a;
-    }
-    __syncthreads();
-}
-
-__device__ __forceinline__ void gru_gates(int K, float* h, int H, PredLds& L, int tid, int nsplit, int half);
-__device__ __forceinline__ void gru_layer(const float* __restrict__ wiT, const float* __restrict__ whT,
-                          const float* __restrict__ bi, const float* __restrict__ bh,
-                          const float* x, int K, float* h, int H, PredLds& L, int tid, int nsplit = 1, int half = 0) {
-    gru_rows(wiT, whT, bi, bh, x, K, h, H, L, tid, nsplit, half);
-    gru_gates(K, h, H, L, tid, nsplit, half);
-}
-__device__ __forceinline__ void gru_gates(int K, float* h, int H, PredLds& L, int tid, int nsplit, int half) {
-    const int Si = segments(K), Sh = segments(H);
-    const int Hh = H / nsplit;
-    for (int ii = tid; ii < Hh; ii += NT) {  // torch.nn.GRU gate rows [r; z; n]
-        const int i = half * Hh + ii;
-        const float gir = seg_tree(L.pi, Si, i), giz = seg_tree(L.pi, Si, H + i), gin = seg_tree(L.pi, Si, 2 * H + i);
-        const float ghr = seg_tree(L.ph, Sh, i), ghz = seg_tree(L.ph, Sh, H + i), ghn = seg_tree(L.ph, Sh, 2 * H + i);
-        const float r = fpc_sigmoidf(gir + ghr);
-        const float z = fpc_sigmoidf(giz + ghz);
-        const float n = fpc_tanhf(fmaf(r, ghn, gin));
-        h[i] = fmaf(z, h[i] - n, n);
-    }
-    __syncthreads();
-}
-
-// one frame of Wavernn.forward: L.x -> L.fo, states in L.h1/L.h2
-__device__ __forceinline__ void pred_step(const PredDev& P, PredLds& L, int tid, SplitCtx* X = nullptr) {
-    if (X && X->n > 1) {  // this workgroup's slice of the units of each GRU, then the slices change hands
-        // (GRU2's recurrent product under the first exchange -- two passes of 96 + 288 work items instead of one of 384 on
-        //  576 threads -- was measured 5 % slower: the passes stay whole)
-        PSTAMP(0)
-        gru_rows(P.w1i, P.w1h, P.b1i, P.b1h, L.x, P.in, L.h1, P.h1, L, tid, X->n, X->half);
-        PSTAMP(1)
-        gru_gates(P.in, L.h1, P.h1, L, tid, X->n, X->half);
-        PSTAMP(2)
-        exchange_halves(L.h1, P.h1, *X, X->g1, tid);
-        PSTAMP(3)
-        gru_rows(P.w2i, P.w2h, P.b2i, P.b2h, L.h1, P.h1, L.h2, P.h2, L, tid, X->n, X->half);
-        PSTAMP(4)
-        gru_gates(P.h1, L.h2, P.h2, L, tid, X->n, X->half);
-        PSTAMP(5)
-        exchange_halves(L.h2, P.h2, *X, X->g2, tid);
-        PSTAMP(6)
-    } else {
-        gru_layer(P.w1i, P.w1h, P.b1i, P.b1h, L.x, P.in, L.h1, P.h1, L, tid);
-        gru_layer(P.w2i, P.w2h, P.b2i, P.b2h, L.h1, P.h1, L.h2, P.h2, L, tid);
-    }
-    for (int i = tid; i < P.h2; i += NT) L.relu[i] = L.h2[i] > 0.0f ? L.h2[i] : 0.0f;
-    __syncthreads();
-    const int Sf = (P.h2 % 8 == 0 && P.h2 >= 64) ? 8 : 1;  // the few output rows: 8 segments each
-    const int lenf = P.h2 / Sf;
-    if (tid < P.fc * Sf) {
-        const int o = tid % P.fc, sg = tid / P.fc;
-        L.pf[sg][o] = chain1(P.fcw + (size_t)sg * lenf * P.fc, L.relu + sg * lenf, lenf, P.fc, o, sg == 0 ? P.fcb[o] : 0.0f);
-    }
-    __syncthreads();
-    if (tid < P.fc) {
-        float acc = L.pf[0][tid];
-        if (Sf == 8)
-            acc = ((L.pf[0][tid] + L.pf[1][tid]) + (L.pf[2][tid] + L.pf[3][tid])) +
-                  ((L.pf[4][tid] + L.pf[5][tid]) + (L.pf[6][tid] + L.pf[7][tid]));
-        const float t = fpc_tanhf(acc);
-        L.fo[tid] = t + t;  // the "dual" FC is the same Linear summed twice (wavernn.py:89-92)
-    }
-    __syncthreads();
-    PSTAMP(7)
-}
-
 // ---- float64 squared distance with numpy's pairwise association (vq_func.py:18) ----
 __device__ __forceinline__ double dist17(const double* x, const double* __restrict__ cbT, int N, int e) {
     double r[8];
@@ -846,7 +714,14 @@ struct SplitArgs {
     unsigned long long limit; // give-up bound of one spin, s_memrealtime ticks
     int withhold;             // test hook: the last slice of utterance 0 never publishes
     int no_fast;              // FPC_FAST_HOP=0: the write-through exchange even when every slice sits on one XCD (tests run both)
+    const unsigned* only;     // the weights-stationary launch's fallback (predictor_ws.h, ws_hello): run only the utterances
+                              // whose group of 16 decided WS_FALLBACK there ([groups] decision words), nullptr: all
 };
+constexpr unsigned WS_GO = 1u, WS_FALLBACK = 2u;
+// (workgroup-uniform) is utterance b left to this launch?
+__device__ __forceinline__ bool split_wanted(const SplitArgs& S, int b) {
+    return S.only == nullptr || __hip_atomic_load((gu32*)(S.only + b / 16), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == WS_FALLBACK;
+}
 __device__ __forceinline__ SplitCtx split_ctx(const SplitArgs& S, const PredDev& P, int b, int half) {
     SplitCtx X;
     X.n = S.n;
@@ -867,50 +742,6 @@ __device__ __forceinline__ SplitCtx split_ctx(const SplitArgs& S, const PredDev&
     return X;
 }
 
-__global__ __launch_bounds__(NT) FPC_OCC void k_forward(const PredDev P, const float* __restrict__ x, int Lf,
-                                                float* h1, float* h2, float* __restrict__ y, const SplitArgs S) {
-    __shared__ PredLds L;
-    const int b = blockIdx.x / S.n, half = blockIdx.x % S.n, tid = threadIdx.x;
-    SplitCtx X = split_ctx(S, P, b, half);
-    const bool writer = half == 0;  // both halves compute the same outputs; one stores them
-    for (int i = tid; i < P.h1; i += NT) L.h1[i] = h1[(size_t)b * P.h1 + i];
-    for (int i = tid; i < P.h2; i += NT) L.h2[i] = h2[(size_t)b * P.h2 + i];
-    __syncthreads();
-    int t = 0;
-#ifdef FPC_PRED_PROF
-    if (tid == 0) {
-        for (int i = 0; i < 12; ++i) L.pprof[i] = 0;
-        L.plast = __builtin_readcyclecounter();
-    }
-#endif
-    for (; t < Lf; ++t) {
-        if (tid < P.in) L.x[tid] = x[((size_t)b * Lf + t) * P.in + tid];
-        __syncthreads();
-        pred_step(P, L, tid, &X);
-        if (X.dead) break;  // (workgroup-uniform) a spin of the row split gave up
-        if (writer && tid < P.fc) y[((size_t)b * Lf + t) * P.fc + tid] = L.fo[tid];
-    }
-    __syncthreads();
-#ifdef FPC_PRED_PROF
-    if (tid == 0 && blockIdx.x == gridDim.x / 2)
-        for (int i = 0; i < 8; ++i) S.err[1 + i] = (unsigned)(L.pprof[i] / (Lf > 0 ? Lf : 1));
-#endif
-    if (X.dead) {  // fail loudly: NaN from this frame on, NaN states; the host reports FPC_ERR_TIMEOUT
-        if (writer) {
-            const float qnan = __uint_as_float(0x7fc00000u);
-            for (size_t k = (size_t)t * P.fc + tid; k < (size_t)Lf * P.fc; k += NT) y[(size_t)b * Lf * P.fc + k] = qnan;
-            for (int i = tid; i < P.h1; i += NT) h1[(size_t)b * P.h1 + i] = qnan;
-            for (int i = tid; i < P.h2; i += NT) h2[(size_t)b * P.h2 + i] = qnan;
-        }
-        return;
-    }
-    // (the partner read the incoming states before its first publish, which this half has waited for: safe to overwrite)
-    if (writer) {
-        for (int i = tid; i < P.h1; i += NT) h1[(size_t)b * P.h1 + i] = L.h1[i];
-        for (int i = tid; i < P.h2; i += NT) h2[(size_t)b * P.h2 + i] = L.h2[i];
-    }
-}
-
 struct EncArgs {
     const float* feat;
     int Lf;
@@ -919,6 +750,7 @@ struct EncArgs {
     float *c_in, *r, *r_qtz, *r_under, *ind1, *ind2;
     int* idx;
     unsigned long long* hist;
+    const float* mask;  // [B][L][2] indicators handed in (wavernn.py:209-211), or nullptr: the thresholds decide (:201-207)
 };
 
 // The frame's tail of Wavernn.encoder for ONE utterance (wavernn.py:196-252), run by the whole workgroup: residual of the
@@ -932,12 +764,15 @@ __device__ __forceinline__ void encode_frame(SearchLds& L, const float* fo, floa
     const int Cc = P.in, F = P.fc;
     const int off_sl = C.n_hi, off_v0 = off_sl + C.n_lo, off_v1 = off_v0 + C.N_hi0,
               off_vl = off_v1 + (C.S_hi == 2 ? C.N_hi1 : 0);
+    // the input-mask mode (:209-211): the caller's indicators replace the thresholds' (a wave-uniform load, mask mode only)
+    const bool masked = A.mask != nullptr;
+    const float m1 = masked ? A.mask[fi * 2] : 0.0f, m2 = masked ? A.mask[fi * 2 + 1] : 0.0f;
     if (tid < F) L.rs[tid] = fv - fo[tid];  // :196
     __syncthreads();
     float sabs = 0.0f;
     for (int d = 1; d < F; ++d) sabs += fabsf(L.rs[d]);
-    const int i1 = fabsf(L.rs[0]) > A.l1;  // :202
-    const int i2 = sabs > A.l2;            // :206
+    const int i1 = masked ? (m1 != 0.0f) : (fabsf(L.rs[0]) > A.l1);  // :202 | :210 (`if ind1[k, 0]`: any non-zero value)
+    const int i2 = masked ? (m2 != 0.0f) : (sabs > A.l2);            // :206 | :211
     // a NaN / infinite residual (non-finite features or weights) has no nearest entry: the arg-min would come back
     // as 0x7fffffff and be used as an address.  Such a frame is not searched: status bit 1, symbols -2
     // (every thread evaluates the same LDS values: workgroup-uniform without a barrier)
@@ -987,9 +822,10 @@ __device__ __forceinline__ void encode_frame(SearchLds& L, const float* fo, floa
             rv = rs;  // un-thresholded residual (:197)
             ru = 0.0f;
             cn = fo[tid] + rq;  // :242
-        } else {                  // :244-252
-            ru = rs * (float)(1 - ind);
-            rv = rs * (float)ind;
+        } else {                  // :244-252 (mask mode: the products with the mask's own values)
+            const float mv = tid == 0 ? m1 : m2;
+            ru = rs * (masked ? 1.0f - mv : (float)(1 - ind));
+            rv = rs * (masked ? mv : (float)ind);
             cn = fo[tid] + rv;
         }
         if (store) {
@@ -1004,8 +840,8 @@ __device__ __forceinline__ void encode_frame(SearchLds& L, const float* fo, floa
         xn[tid] = fv;
     }
     if (tid == 0 && store) {
-        A.ind1[fi] = (float)i1;
-        A.ind2[fi] = (float)i2;
+        A.ind1[fi] = masked ? 0.0f : (float)i1;  // (the reference fills the indicator outputs from the thresholds only)
+        A.ind2[fi] = masked ? 0.0f : (float)i2;
         if (A.idx) {
             A.idx[fi * 4 + 0] = ix0;
             A.idx[fi * 4 + 1] = ix1;
@@ -1034,25 +870,6 @@ __device__ __forceinline__ void encode_poison(const PredDev& P, const EncArgs& A
         if (A.idx)
             for (int c = 0; c < 4; ++c) A.idx[o * 4 + c] = -2;
     }
-}
-
-__global__ __launch_bounds__(NT) FPC_OCC void k_encode(const PredDev P, const CbDev C, const EncArgs A, const SplitArgs S) {
-    __shared__ PredLds L;
-    const int b = blockIdx.x / S.n, half = blockIdx.x % S.n, tid = threadIdx.x;
-    SplitCtx X = split_ctx(S, P, b, half);
-    const bool writer = half == 0;  // both halves run the same closed loop on the same bits; one stores the outputs
-    for (int i = tid; i < P.h1; i += NT) L.h1[i] = 0.0f;  // h=None -> zeros (wavernn.py:182)
-    for (int i = tid; i < P.h2; i += NT) L.h2[i] = 0.0f;
-    if (tid < P.in) L.x[tid] = 0.0f;  // c_in[:,0,:] is all zero (wavernn.py:177-178)
-    __syncthreads();
-    int i = 0;
-    for (; i < A.Lf; ++i) {
-        const float fv = tid < P.in ? A.feat[((size_t)b * A.Lf + i) * P.in + tid] : 0.0f;
-        pred_step(P, L, tid, &X);  // wavernn.py:194-195
-        if (X.dead) break;         // (workgroup-uniform) a spin of the row split gave up
-        encode_frame(L, L.fo, L.x, P, C, A, S.err, (size_t)b * A.Lf + i, fv, writer, tid);
-    }
-    if (X.dead && writer) encode_poison(P, A, b, i, tid);
 }
 
 // the receiver's frame tail for one utterance: threads (c < Cc) of one wave (k_decode_feat)
@@ -1100,35 +917,6 @@ __device__ __forceinline__ void decode_frame(const float* fo, float* xn, const P
     }
 }
 
-// receiver side of k_encode: the same predictor steps, the residual looked up from the transmitted symbols
-// (float64 entry sums narrowed to float32 exactly as the encoder does), so c_out equals the encoder's c_in.
-// A symbol outside its codebook sets *bad and decodes as "not coded".
-__global__ __launch_bounds__(NT) FPC_OCC void k_decode_feat(const PredDev P, const CbDev C, const float* __restrict__ pitch,
-                                                    const int* __restrict__ idx, int Lf, float* __restrict__ c_out,
-                                                    int* bad, const SplitArgs S) {
-    __shared__ PredLds L;
-    const int b = blockIdx.x / S.n, half = blockIdx.x % S.n, tid = threadIdx.x;
-    SplitCtx X = split_ctx(S, P, b, half);
-    const bool writer = half == 0;
-    const int Cc = P.in;
-    for (int i = tid; i < P.h1; i += NT) L.h1[i] = 0.0f;
-    for (int i = tid; i < P.h2; i += NT) L.h2[i] = 0.0f;
-    if (tid < Cc) L.x[tid] = 0.0f;
-    __syncthreads();
-    int i = 0;
-    for (; i < Lf; ++i) {
-        const size_t fi = (size_t)b * Lf + i;
-        pred_step(P, L, tid, &X);
-        if (X.dead) break;  // (workgroup-uniform) a spin of the row split gave up
-        if (tid < 64) decode_frame(L.fo, L.x, P, C, pitch, idx, c_out, bad, fi, writer, tid);
-        __syncthreads();
-    }
-    if (X.dead && writer) {  // fail loudly: NaN from this frame on; the host reports FPC_ERR_TIMEOUT
-        const float qnan = __uint_as_float(0x7fc00000u);
-        for (size_t k = (size_t)i * Cc + tid; k < (size_t)Lf * Cc; k += NT) c_out[(size_t)b * Lf * Cc + k] = qnan;
-    }
-}
-
 #include "predictor_df.h"
 #include "predictor_ws.h"
 #include "predictor_wsd.h"
@@ -1136,7 +924,7 @@ __global__ __launch_bounds__(NT) FPC_OCC void k_decode_feat(const PredDev P, con
 // stand-alone quantizers: one workgroup per input row
 __global__ __launch_bounds__(NT) void k_vq(const CbDev C, int which, const float* __restrict__ r, double* qr,
                                            int* idx) {
-    __shared__ PredLds L;
+    __shared__ SearchLds L;
     const int n = blockIdx.x, tid = threadIdx.x;
     float rv = 0.0f;
     if (tid < NDIM) L.rs[1 + tid] = rv = r[(size_t)n * NDIM + tid];
@@ -1160,7 +948,7 @@ __global__ __launch_bounds__(NT) void k_vq(const CbDev C, int which, const float
 
 __global__ __launch_bounds__(NT) void k_scl(const CbDev C, int which, const float* __restrict__ x, double* q,
                                             int* idx) {
-    __shared__ PredLds L;
+    __shared__ SearchLds L;
     const int n = blockIdx.x, tid = threadIdx.x;
     if (!(fabsf(x[n]) <= 3.0e38f)) {  // (workgroup-uniform) no nearest code of a NaN: NaN out, symbol -2
         if (tid == 0) {
@@ -1192,80 +980,13 @@ struct TrainBufs {              // per sample n = b*L + t
     double* lossb;                                // [B]
 };
 
-__device__ void gates_save(const float* h_prev_lds, float* h_lds, int K, int H, PredLds& L, size_t n, float* r_, float* z_,
-                           float* n_, float* hn_, float* hout, int tid, int nsplit = 1, int half = 0) {
-    const int Si = segments(K), Sh = segments(H);
-    const int Hs = H / nsplit;
-    for (int ii = tid; ii < Hs; ii += NT) {
-        const int i = half * Hs + ii;
-        const float gir = seg_tree(L.pi, Si, i), giz = seg_tree(L.pi, Si, H + i), gin = seg_tree(L.pi, Si, 2 * H + i);
-        const float ghr = seg_tree(L.ph, Sh, i), ghz = seg_tree(L.ph, Sh, H + i), ghn = seg_tree(L.ph, Sh, 2 * H + i);
-        const float r = fpc_sigmoidf(gir + ghr);
-        const float z = fpc_sigmoidf(giz + ghz);
-        const float nn = fpc_tanhf(fmaf(r, ghn, gin));
-        const float hv = fmaf(z, h_prev_lds[i] - nn, nn);
-        r_[n * H + i] = r;
-        z_[n * H + i] = z;
-        n_[n * H + i] = nn;
-        hn_[n * H + i] = ghn;
-        hout[n * H + i] = hv;
-        h_lds[i] = hv;
-    }
-    __syncthreads();
-}
-
-__global__ __launch_bounds__(NT) void k_train_fwd(const PredDev P, const float* __restrict__ feat, int Lf,
-                                                  const TrainBufs T, const SplitArgs S) {
-    __shared__ PredLds L;
-    const int b = blockIdx.x / S.n, half = blockIdx.x % S.n, tid = threadIdx.x;
-    SplitCtx X = split_ctx(S, P, b, half);
-    const bool writer = half == 0;  // kept activations: every slice stores its own units, the rest by slice 0
-    for (int i = tid; i < P.h1; i += NT) L.h1[i] = 0.0f;
-    for (int i = tid; i < P.h2; i += NT) L.h2[i] = 0.0f;
-    __syncthreads();
-    for (int t = 0; t < Lf; ++t) {
-        const size_t n = (size_t)b * Lf + t;
-        if (tid < P.in) L.x[tid] = feat[n * P.in + tid];
-        if (writer) {
-            for (int i = tid; i < P.h1; i += NT) T.h1p[n * P.h1 + i] = L.h1[i];
-            for (int i = tid; i < P.h2; i += NT) T.h2p[n * P.h2 + i] = L.h2[i];
-        }
-        __syncthreads();
-        gru_rows(P.w1i, P.w1h, P.b1i, P.b1h, L.x, P.in, L.h1, P.h1, L, tid, X.n, X.half);
-        gates_save(L.h1, L.h1, P.in, P.h1, L, n, T.r1, T.z1, T.n1, T.hn1, T.h1, tid, X.n, X.half);
-        if (X.n > 1) exchange_halves(L.h1, P.h1, X, X.g1, tid);
-        gru_rows(P.w2i, P.w2h, P.b2i, P.b2h, L.h1, P.h1, L.h2, P.h2, L, tid, X.n, X.half);
-        gates_save(L.h2, L.h2, P.h1, P.h2, L, n, T.r2, T.z2, T.n2, T.hn2, T.h2, tid, X.n, X.half);
-        if (X.n > 1) exchange_halves(L.h2, P.h2, X, X.g2, tid);
-        for (int i = tid; i < P.h2; i += NT) {
-            const float v = L.h2[i] > 0.0f ? L.h2[i] : 0.0f;
-            L.relu[i] = v;
-            if (writer) T.relu[n * P.h2 + i] = v;
-        }
-        __syncthreads();
-        const int Sf = (P.h2 % 8 == 0 && P.h2 >= 64) ? 8 : 1, lenf = P.h2 / Sf;
-        if (tid < P.fc * Sf) {
-            const int o = tid % P.fc, sg = tid / P.fc;
-            L.pf[sg][o] = chain1(P.fcw + (size_t)sg * lenf * P.fc, L.relu + sg * lenf, lenf, P.fc, o, sg == 0 ? P.fcb[o] : 0.0f);
-        }
-        __syncthreads();
-        if (tid < P.fc) {
-            float acc = L.pf[0][tid];
-            if (Sf == 8)
-                acc = ((L.pf[0][tid] + L.pf[1][tid]) + (L.pf[2][tid] + L.pf[3][tid])) +
-                      ((L.pf[4][tid] + L.pf[5][tid]) + (L.pf[6][tid] + L.pf[7][tid]));
-            if (writer) T.th[n * P.fc + tid] = fpc_tanhf(acc);
-        }
-        __syncthreads();
-    }
-}
-
 // the training forward as two roles (predictor_df.h): k_train_fwd's frames with the latency chain on three waves and the
 // recurrent products streamed by the others; same chains, same kept activations
 __global__ __launch_bounds__(NT) void k_train_fwd_df(const PredDev P, const float* __restrict__ feat, int Lf, const TrainBufs T,
                                                      const SplitArgs S) {
     __shared__ DfLds L;
     const int b = blockIdx.x / S.n, half = blockIdx.x % S.n, tid = threadIdx.x;
+    if (!split_wanted(S, b)) return;
     SplitCtx X = split_ctx(S, P, b, half);
     const bool writer = half == 0;
     for (int i = tid; i < P.h1; i += NT) L.h1[i] = 0.0f;
@@ -1631,9 +1352,10 @@ struct fpc_predictor {
     hipEvent_t last_ev = nullptr;
     hipStream_t last_stream = nullptr;
     bool launched = false;
+    int last_ws_groups = 0;  // groups of the handle's last weights-stationary launch (fpc_predictor_fallback_groups)
     int forced_split = 0;  // fpc_predictor_set_split: 0 automatic, 1 off, 2/4/8 exactly that many workgroups per utterance
     int num_cus = 0;
-    int occ_df = 1, occ_phase = 1;  // workgroups of the two-role / phase kernels that one CU holds (LDS-bound: 1 / 2-3)
+    int occ_df = 1;  // workgroups of the two-role kernels that one CU holds (LDS-bound: 1)
     int fail_epoch = 0;    // failures reported and cleared by fpc_predictor_status so far (a trainer re-reads its step count)
     std::atomic<int> refs{1};  // the creator's handle + one per live fpc_trainer built on it (fpc_predictor_destroy only drops a reference)
     ~fpc_predictor() {
@@ -1671,7 +1393,6 @@ static int after_launch(fpc_predictor* p, hipStream_t st) {
 // Row split (2, 4 or 8 workgroups per utterance) while the batch leaves CUs idle; fpc_predictor_set_split or
 // FPC_PRED_SPLIT=0/1/2/4/8 force it off / to a count (tests run every form).  Prepares the zeroed granule block on the
 // stream.  The automatic choice assumes that this process owns the GPU (every workgroup of a group must be resident).
-static bool two_roles();
 static int split_args(fpc_predictor* p, int B, hipStream_t st, SplitArgs* out) {
     out->n = 1;
     out->g = nullptr;
@@ -1679,6 +1400,7 @@ static int split_args(fpc_predictor* p, int B, hipStream_t st, SplitArgs* out) {
     out->limit = 100000000ull;  // 1 s of s_memrealtime (100 MHz)
     out->withhold = 0;
     out->no_fast = 0;
+    out->only = nullptr;
     if (const char* lim = getenv("FPC_SPIN_LIMIT_US")) {  // test hook: a shorter give-up bound
         const long us = atol(lim);
         if (us > 0) out->limit = (unsigned long long)us * 100ull;
@@ -1694,7 +1416,7 @@ static int split_args(fpc_predictor* p, int B, hipStream_t st, SplitArgs* out) {
     // (forced: every workgroup of the launch must be resident at once -- a group that straddles the residency boundary would
     //  spin for workgroups that are not dispatched yet -- so the bound is what the chosen kernel form's LDS lets a CU hold:
     //  one workgroup of the two-role kernels (~140 kB), two or three of the phase kernels)
-    const int occ = two_roles() ? p->occ_df : p->occ_phase;
+    const int occ = p->occ_df;
     if (f == 1)
         n = 1;
     else if ((f == 2 || f == 4 || f == 8) && p->d.h1 % (4 * f) == 0 && p->d.h2 % (4 * f) == 0 && f * B <= occ * p->num_cus)
@@ -1734,10 +1456,11 @@ static bool ws_wanted(const fpc_predictor* p) {
 }
 struct fpc_codebooks {
     CbDev d;
-    fpc::DevBuf buf[11];
+    fpc::DevBuf buf[8];
     int hist_size = 0;
 };
-// the encoder's frame tail of these kernels (ws_encode_tail) holds two entries of a stage per thread and the scalar codes in LDS
+// the encoder's distributed frame tail (wsd_tail) holds 32 entries of every book per workgroup (1 024 per book over the
+// group's 32 workgroups) and the scalar codes in LDS
 static bool ws_codebooks_fit(const fpc_codebooks* cb) {
     if (!cb) return true;
     const CbDev& c = cb->d;
@@ -1751,17 +1474,25 @@ static int ws_args(fpc_predictor* p, int B, hipStream_t st, WsArgs* out) {
     out->limit = 100000000ull;  // 1 s of s_memrealtime (100 MHz)
     out->withhold = 0;
     out->no_fast = 0;
+    out->hello_limit = 1000000ull;  // 10 ms: the partners of a group that has the chip to itself show up within microseconds
     if (const char* lim = getenv("FPC_SPIN_LIMIT_US")) {  // test hook: a shorter give-up bound
         const long us = atol(lim);
         if (us > 0) out->limit = (unsigned long long)us * 100ull;
     }
-    if (const char* wh = getenv("FPC_TEST_WITHHOLD_PUBLISH")) out->withhold = wh[0] == '1';  // test hook
+    if (const char* lim = getenv("FPC_HELLO_LIMIT_US")) {  // test hook: a shorter / longer residency bound
+        const long us = atol(lim);
+        if (us > 0) out->hello_limit = (unsigned long long)us * 100ull;
+    }
+    // test hooks: 1 the last workgroup of group 0 never publishes a frame's values (the frame loop's give-up), 2 ("hello")
+    // not even its hello (stands for a workgroup that is not resident: the group falls back)
+    if (const char* wh = getenv("FPC_TEST_WITHHOLD_PUBLISH")) out->withhold = wh[0] == '1' ? 1 : (wh[0] == 'h' ? 2 : 0);
     if (const char* fh = getenv("FPC_FAST_HOP")) out->no_fast = fh[0] == '0';  // the write-through path everywhere
     {
         const int rc = before_launch(p, st);
         if (rc != FPC_OK) return rc;
     }
-    const size_t bytes = (size_t)out->ngroups * WGRANULES * sizeof(u32x4);
+    const size_t gbytes = (size_t)out->ngroups * WGRANULES * sizeof(u32x4);
+    const size_t bytes = gbytes + (((size_t)out->ngroups * sizeof(unsigned) + 255) & ~(size_t)255);  // + the decision words
     if (p->wsg.bytes < bytes) {
         if (p->wsg.p) {
             FPC_HIP(hipDeviceSynchronize());  // nothing may still be polling the old block (on any stream)
@@ -1772,7 +1503,23 @@ static int ws_args(fpc_predictor* p, int B, hipStream_t st, WsArgs* out) {
     }
     FPC_HIP(hipMemsetAsync(p->wsg.p, 0, bytes, st));  // tags start at 0; epochs count from 1 within the launch
     out->g = p->wsg.as<u32x4>();
+    out->dec = reinterpret_cast<unsigned*>(static_cast<char*>(p->wsg.p) + gbytes);
+    p->last_ws_groups = out->ngroups;
     return FPC_OK;
+}
+// the launch behind every weights-stationary launch: the row-split kernels, one workgroup per utterance (no partner to
+// wait for), for exactly the groups whose workgroups could not all become resident (ws_hello) -- none, normally: B
+// workgroups that read one word and return
+static SplitArgs ws_fallback_args(const fpc_predictor* p, const WsArgs& wa) {
+    SplitArgs sp;
+    sp.n = 1;
+    sp.g = nullptr;
+    sp.err = p->status_dev;
+    sp.limit = wa.limit;
+    sp.withhold = 0;
+    sp.no_fast = 0;
+    sp.only = wa.dec;
+    return sp;
 }
 #ifdef FPC_WS_PROF
 // diagnostic builds: cycles per frame and stage of workgroup 5 of group 0 (thread 0 = foreground, thread 256 = background)
@@ -1788,13 +1535,6 @@ static void ws_prof_print(fpc_predictor* p, const char* who, int B, hipStream_t 
 #endif
 // 32 workgroups per group, the groups dealt over the XCDs (ws_role): 256 workgroups per round of 8 groups
 static unsigned ws_grid(const WsArgs& a) { return 8u * WNS * (unsigned)((a.ngroups + 7) / 8); }
-
-// the two-role kernels (predictor_df.h) are the shipped form; FPC_PRED_DF=0 runs the phase-after-phase kernels (tests
-// compare the two bit for bit)
-static bool two_roles() {
-    const char* e = getenv("FPC_PRED_DF");
-    return !(e && e[0] == '0');
-}
 
 static void predictor_unref(fpc_predictor* p) {
     if (p && p->refs.fetch_sub(1) <= 1) delete p;
@@ -1864,7 +1604,6 @@ extern "C" int fpc_predictor_create(const fpc_predictor_weights* w, fpc_predicto
         FPC_HIP(hipDeviceGetAttribute(&p->num_cus, hipDeviceAttributeMultiprocessorCount, dev));
         int o = 0;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&o, k_encode_df, NT, 0) == hipSuccess && o > 0) p->occ_df = o;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&o, k_encode, NT, 0) == hipSuccess && o > 0) p->occ_phase = o;
     }
     *out = own.release();
     return FPC_OK;
@@ -1883,6 +1622,8 @@ extern "C" int fpc_predictor_forward(fpc_predictor* p, const float* x_dev, int B
         if (rcw != FPC_OK) return rcw;
         hipLaunchKernelGGL(k_forward_ws<false>, dim3(ws_grid(wa)), dim3(NT), 0, static_cast<hipStream_t>(s), p->d, x_dev, L, h1_dev,
                            h2_dev, y_dev, wa, WsSave{});
+        hipLaunchKernelGGL(k_forward_df, dim3(B), dim3(NT), 0, static_cast<hipStream_t>(s), p->d, x_dev, L, h1_dev, h2_dev, y_dev,
+                           ws_fallback_args(p, wa));
         FPC_HIP(hipGetLastError());
 #ifdef FPC_WS_PROF
         ws_prof_print(p, "k_forward_ws", B, static_cast<hipStream_t>(s));
@@ -1892,24 +1633,16 @@ extern "C" int fpc_predictor_forward(fpc_predictor* p, const float* x_dev, int B
     SplitArgs sp;
     const int rc = split_args(p, B, static_cast<hipStream_t>(s), &sp);
     if (rc != FPC_OK) return rc;
-    if (two_roles())
-        hipLaunchKernelGGL(k_forward_df, dim3(B * sp.n), dim3(NT), 0, static_cast<hipStream_t>(s), p->d, x_dev, L,
-                           h1_dev, h2_dev, y_dev, sp);
-    else
-        hipLaunchKernelGGL(k_forward, dim3(B * sp.n), dim3(NT), 0, static_cast<hipStream_t>(s), p->d, x_dev, L,
-                           h1_dev, h2_dev, y_dev, sp);
+    hipLaunchKernelGGL(k_forward_df, dim3(B * sp.n), dim3(NT), 0, static_cast<hipStream_t>(s), p->d, x_dev, L, h1_dev, h2_dev,
+                       y_dev, sp);
     FPC_HIP(hipGetLastError());
 #ifdef FPC_PRED_PROF
     (void)hipStreamSynchronize(static_cast<hipStream_t>(s));
     {
         const volatile unsigned* w = (const volatile unsigned*)p->status_host;
-        if (two_roles())
-            fprintf(stderr, "k_forward_df B=%d n=%d cycles/frame FG: I %u waitA %u gates1 %u hop1 %u Ashare %u waitB %u waitC %u gates2 %u hop2 %u fc %u"
-                    " | BG: waitH1 %u C %u A %u waitH2 %u B %u\n", B, sp.n, w[1], w[2], w[3], w[4], w[5], w[10], w[6], w[7], w[8], w[9], w[11],
-                    w[12], w[13], w[14], w[15]);
-        else
-        fprintf(stderr, "k_forward B=%d n=%d cycles/frame: next-x %u | rows1 %u gates1 %u xchg1 %u | rows2 %u gates2 %u xchg2 %u | fc %u\n",
-                B, sp.n, w[1], w[2], w[3], w[4], w[5], w[6], w[7], w[8]);
+        fprintf(stderr, "k_forward_df B=%d n=%d cycles/frame FG: I %u waitA %u gates1 %u hop1 %u Ashare %u waitB %u waitC %u gates2 %u hop2 %u fc %u"
+                " | BG: waitH1 %u C %u A %u waitH2 %u B %u\n", B, sp.n, w[1], w[2], w[3], w[4], w[5], w[10], w[6], w[7], w[8], w[9], w[11],
+                w[12], w[13], w[14], w[15]);
     }
 #endif
     return after_launch(p, static_cast<hipStream_t>(s));
@@ -1922,6 +1655,18 @@ extern "C" int fpc_predictor_status(fpc_predictor* p) {
     *(volatile unsigned*)p->status_host = 0u;
     if (rc != FPC_OK) p->fail_epoch += 1;
     return rc;
+}
+
+extern "C" int fpc_predictor_fallback_groups(fpc_predictor* p) {
+    FPC_REQUIRE(p, "fpc_predictor_fallback_groups: null handle");
+    if (p->last_ws_groups <= 0 || !p->wsg.p) return 0;
+    FPC_HIP(hipDeviceSynchronize());
+    std::vector<unsigned> dec((size_t)p->last_ws_groups);
+    const size_t gbytes = (size_t)p->last_ws_groups * WGRANULES * sizeof(u32x4);
+    FPC_HIP(hipMemcpy(dec.data(), static_cast<char*>(p->wsg.p) + gbytes, dec.size() * sizeof(unsigned), hipMemcpyDeviceToHost));
+    int n = 0;
+    for (unsigned d : dec) n += d == WS_FALLBACK;
+    return n;
 }
 
 extern "C" int fpc_predictor_set_split(fpc_predictor* p, int n) {
@@ -1954,28 +1699,22 @@ extern "C" int fpc_codebooks_create(const double* vq_hi, int S_hi, const int* N_
     c->d.N_lo = N_lo;
     c->d.n_hi = n_hi;
     c->d.n_lo = n_lo;
-    auto up_cb = [&](int slot, int pslot, const double* src, int N, const double** dT, const double** dR,
-                     const double** dP) -> hipError_t {
-        std::vector<double> t((size_t)N * NDIM), r(src, src + (size_t)N * NDIM), pr((size_t)(NDIM + 1) * N, 0.0);
+    auto up_cb = [&](int slot, const double* src, int N, const double** dT, const double** dR) -> hipError_t {
+        std::vector<double> t((size_t)N * NDIM), r(src, src + (size_t)N * NDIM);
         for (int e = 0; e < N; ++e)
-            for (int d = 0; d < NDIM; ++d) {
-                t[(size_t)d * N + e] = src[(size_t)e * NDIM + d];
-                pr[((size_t)(d / 2) * N + e) * 2 + (d & 1)] = src[(size_t)e * NDIM + d];
-            }
+            for (int d = 0; d < NDIM; ++d) t[(size_t)d * N + e] = src[(size_t)e * NDIM + d];
         hipError_t e1 = c->buf[slot].upload(t);
         if (e1 != hipSuccess) return e1;
         *dT = c->buf[slot].as<double>();
         e1 = c->buf[slot + 1].upload(r);
         if (e1 != hipSuccess) return e1;
         *dR = c->buf[slot + 1].as<double>();
-        e1 = c->buf[pslot].upload(pr);
-        *dP = c->buf[pslot].as<double>();
         return e1;
     };
-    FPC_HIP(up_cb(0, 8, vq_hi, N_hi[0], &c->d.vq_hi0, &c->d.vq_hi0_r, &c->d.vq_hi0_p));
+    FPC_HIP(up_cb(0, vq_hi, N_hi[0], &c->d.vq_hi0, &c->d.vq_hi0_r));
     if (S_hi == 2)
-        FPC_HIP(up_cb(2, 9, vq_hi + (size_t)N_hi[0] * NDIM, N_hi[1], &c->d.vq_hi1, &c->d.vq_hi1_r, &c->d.vq_hi1_p));
-    if (vq_lo) FPC_HIP(up_cb(4, 10, vq_lo, N_lo, &c->d.vq_lo, &c->d.vq_lo_r, &c->d.vq_lo_p));
+        FPC_HIP(up_cb(2, vq_hi + (size_t)N_hi[0] * NDIM, N_hi[1], &c->d.vq_hi1, &c->d.vq_hi1_r));
+    if (vq_lo) FPC_HIP(up_cb(4, vq_lo, N_lo, &c->d.vq_lo, &c->d.vq_lo_r));
     {
         std::vector<double> v(scl_hi, scl_hi + n_hi);
         FPC_HIP(c->buf[6].upload(v));
@@ -1997,7 +1736,7 @@ extern "C" int fpc_codebooks_hist_size(const fpc_codebooks* c) { return c ? c->h
 extern "C" int fpc_encode(fpc_predictor* p, const fpc_codebooks* cb, const float* feat_dev, int B,
                           int L, float l1, float l2, int qtz, float* c_in_dev, float* r_dev,
                           float* r_qtz_dev, float* r_under_dev, float* ind1_dev, float* ind2_dev,
-                          int32_t* idx_dev, unsigned long long* hist_dev, fpc_stream s) {
+                          int32_t* idx_dev, unsigned long long* hist_dev, const float* mask_dev, fpc_stream s) {
     FPC_REQUIRE(p && feat_dev && c_in_dev && r_dev && r_qtz_dev && r_under_dev && ind1_dev && ind2_dev,
                 "fpc_encode: null argument");
     FPC_REQUIRE(B > 0 && L >= 0, "fpc_encode: bad shape B=%d L=%d", B, L);
@@ -2009,7 +1748,7 @@ extern "C" int fpc_encode(fpc_predictor* p, const fpc_codebooks* cb, const float
     memset(&cd, 0, sizeof cd);
     if (cb) cd = cb->d;
     EncArgs a{feat_dev, L,  l1, l2, qtz ? 1 : 0, c_in_dev, r_dev, r_qtz_dev, r_under_dev, ind1_dev, ind2_dev,
-              idx_dev,  hist_dev};
+              idx_dev,  hist_dev, mask_dev};
     if (ws_wanted(p) && ws_codebooks_fit(cb)) {
         WsArgs wa;
         const int rcw = ws_args(p, B, static_cast<hipStream_t>(s), &wa);
@@ -2026,12 +1765,13 @@ extern "C" int fpc_encode(fpc_predictor* p, const fpc_codebooks* cb, const float
             }
             a.idx = p->wsidx.as<int>();
         }
-        // the frame tail distributed over the group's workgroups (predictor_wsd.h); FPC_WS_TAIL=pair: on the utterance's own pair
-        const char* tl = getenv("FPC_WS_TAIL");
-        if (tl && tl[0] == 'p')
-            hipLaunchKernelGGL(k_encode_ws, dim3(ws_grid(wa)), dim3(NT), 0, static_cast<hipStream_t>(s), p->d, cd, a, wa);
-        else
-            hipLaunchKernelGGL(k_encode_wsd, dim3(ws_grid(wa)), dim3(NT), 0, static_cast<hipStream_t>(s), p->d, cd, a, wa);
+        // (the frame tail is distributed over the group's workgroups: predictor_wsd.h)
+        hipLaunchKernelGGL(k_encode_wsd, dim3(ws_grid(wa)), dim3(NT), 0, static_cast<hipStream_t>(s), p->d, cd, a, wa);
+        {  // (the fallback's symbols are counted with everybody's by k_hist_symbols below, not by its own atomics)
+            EncArgs af = a;
+            af.hist = nullptr;
+            hipLaunchKernelGGL(k_encode_df, dim3(B), dim3(NT), 0, static_cast<hipStream_t>(s), p->d, cd, af, ws_fallback_args(p, wa));
+        }
         FPC_HIP(hipGetLastError());
         if (hist_dev && qtz) {
             const size_t frames = (size_t)B * L;
@@ -2040,7 +1780,7 @@ extern "C" int fpc_encode(fpc_predictor* p, const fpc_codebooks* cb, const float
             FPC_HIP(hipGetLastError());
         }
 #ifdef FPC_WS_PROF
-        ws_prof_print(p, (tl && tl[0] == 'p') ? (qtz ? "k_encode_ws qtz=1" : "k_encode_ws qtz=0") : (qtz ? "k_encode_wsd qtz=1" : "k_encode_wsd qtz=0"), B,
+        ws_prof_print(p, qtz ? "k_encode_wsd qtz=1" : "k_encode_wsd qtz=0", B,
                       static_cast<hipStream_t>(s));
 #endif
         return after_launch(p, static_cast<hipStream_t>(s));
@@ -2048,10 +1788,9 @@ extern "C" int fpc_encode(fpc_predictor* p, const fpc_codebooks* cb, const float
     SplitArgs sp;
     const int rc = split_args(p, B, static_cast<hipStream_t>(s), &sp);
     if (rc != FPC_OK) return rc;
-    if (two_roles())
-        hipLaunchKernelGGL(k_encode_df, dim3(B * sp.n), dim3(NT), 0, static_cast<hipStream_t>(s), p->d, cd, a, sp);
+    hipLaunchKernelGGL(k_encode_df, dim3(B * sp.n), dim3(NT), 0, static_cast<hipStream_t>(s), p->d, cd, a, sp);
 #ifdef FPC_PRED_PROF
-    if (two_roles()) {
+    {
         (void)hipStreamSynchronize(static_cast<hipStream_t>(s));
         const volatile unsigned* w = (const volatile unsigned*)p->status_host;
         fprintf(stderr, "k_encode_df B=%d n=%d qtz=%d cycles/frame FG: I %u waitA %u gates1 %u hop1 %u C %u waitB %u gates2 %u hop2 %u out %u | rendezvous %u"
@@ -2060,8 +1799,6 @@ extern "C" int fpc_encode(fpc_predictor* p, const fpc_codebooks* cb, const float
         for (int k = 1; k < 16; ++k) ((volatile unsigned*)p->status_host)[k] = 0;
     }
 #endif
-    else
-        hipLaunchKernelGGL(k_encode, dim3(B * sp.n), dim3(NT), 0, static_cast<hipStream_t>(s), p->d, cd, a, sp);
     FPC_HIP(hipGetLastError());
     return after_launch(p, static_cast<hipStream_t>(s));
 }
@@ -2085,13 +1822,12 @@ extern "C" int fpc_decode_features(fpc_predictor* p, const fpc_codebooks* cb, co
         if (rcw != FPC_OK) return rcw;
         hipLaunchKernelGGL(k_decode_feat_ws, dim3(ws_grid(wa)), dim3(NT), 0, st, p->d, cb->d, pitch_dev, idx_dev, L, c_out_dev,
                            p->flag.as<int>(), wa);
+        hipLaunchKernelGGL(k_decode_feat_df, dim3(B), dim3(NT), 0, st, p->d, cb->d, pitch_dev, idx_dev, L, c_out_dev,
+                           p->flag.as<int>(), ws_fallback_args(p, wa));
     } else if (const int rc = split_args(p, B, st, &sp)) {
         return rc;
-    } else if (two_roles())
+    } else
         hipLaunchKernelGGL(k_decode_feat_df, dim3(B * sp.n), dim3(NT), 0, st, p->d, cb->d, pitch_dev, idx_dev, L, c_out_dev,
-                           p->flag.as<int>(), sp);
-    else
-        hipLaunchKernelGGL(k_decode_feat, dim3(B * sp.n), dim3(NT), 0, st, p->d, cb->d, pitch_dev, idx_dev, L, c_out_dev,
                            p->flag.as<int>(), sp);
     FPC_HIP(hipGetLastError());
     int h = 0;
@@ -2220,13 +1956,11 @@ extern "C" int fpc_trainer_step(fpc_trainer* t, const float* feat_dev, int B, in
         if (rc != FPC_OK) return rc;
         const WsSave sv{T.h1p, T.r1, T.z1, T.n1, T.hn1, T.h1, T.h2p, T.r2, T.z2, T.n2, T.hn2, T.h2, T.relu, T.th};
         hipLaunchKernelGGL(k_forward_ws<true>, dim3(ws_grid(wa)), dim3(NT), 0, st, P, feat_dev, L, nullptr, nullptr, nullptr, wa, sv);
+        hipLaunchKernelGGL(k_train_fwd_df, dim3(B), dim3(NT), 0, st, P, feat_dev, L, T, ws_fallback_args(p, wa));
     } else {
         const int rc = split_args(p, B, st, &sp);
         if (rc != FPC_OK) return rc;
-        if (two_roles())
-            hipLaunchKernelGGL(k_train_fwd_df, dim3(B * sp.n), dim3(NT), 0, st, P, feat_dev, L, T, sp);
-        else
-            hipLaunchKernelGGL(k_train_fwd, dim3(B * sp.n), dim3(NT), 0, st, P, feat_dev, L, T, sp);
+        hipLaunchKernelGGL(k_train_fwd_df, dim3(B * sp.n), dim3(NT), 0, st, P, feat_dev, L, T, sp);
     }
     const double cnt = (double)B * (L - 1) * F;
     hipLaunchKernelGGL(k_train_loss, dim3(B), dim3(256), sizeof(float) * (size_t)L * F, st, feat_dev, in, F, L,

@@ -461,6 +461,7 @@ __global__ __launch_bounds__(NT) void k_forward_df(const PredDev P, const float*
     const int tid = threadIdx.x;
     int b, half;
     df_block_role(S, b, half);
+    if (!split_wanted(S, b)) return;
     SplitCtx X = split_ctx(S, P, b, half);
     const bool writer = half == 0;
     for (int i = tid; i < P.h1; i += NT) L.h1[i] = h1[(size_t)b * P.h1 + i];
@@ -528,6 +529,7 @@ __global__ __launch_bounds__(NT) void k_encode_df(const PredDev P, const CbDev C
     const int tid = threadIdx.x;
     int b, half;
     df_block_role(S, b, half);
+    if (!split_wanted(S, b)) return;
     SplitCtx X = split_ctx(S, P, b, half);
     const bool writer = half == 0;
     for (int i = tid; i < P.h1; i += NT) L.h1[i] = 0.0f;
@@ -584,6 +586,7 @@ __global__ __launch_bounds__(NT) void k_decode_feat_df(const PredDev P, const Cb
     const int tid = threadIdx.x;
     int b, half;
     df_block_role(S, b, half);
+    if (!split_wanted(S, b)) return;
     SplitCtx X = split_ctx(S, P, b, half);
     const bool writer = half == 0;
     for (int i = tid; i < P.h1; i += NT) L.h1[i] = 0.0f;

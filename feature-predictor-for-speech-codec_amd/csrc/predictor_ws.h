@@ -26,8 +26,9 @@
 // Roles (512 threads): waves 0-3 walk the frame's chain -- I(t) = W1i x(t), GRU1 gates, hop 1, C(t) = W2i h1(t), GRU2
 // gates, hop 2, output layer -- waves 4-7 compute the recurrent products one frame ahead (A(t+1) = W1h h1(t) after hop 1,
 // B(t+1) = W2h h2(t) after hop 2) and take half of hop 1's gather; the roles meet through LDS counters (predictor_df.h).
-// The encoder's frame tail (residual, thresholds, searches: encode_frame) runs on the workgroup that OWNS the utterance
-// (workgroup s < 16 owns utterance s of the group) and the next input row goes round as a third hop.
+// The encoder's frame tail (residual, thresholds, searches) is distributed over the group's workgroups (predictor_wsd.h);
+// the receiver's (a table lookup) runs on the workgroup that OWNS the utterance (workgroup s < 16 owns utterance s of the
+// group) and the next input row goes round as a third hop.
 // Shapes: the reference's production predictor only (20 -> 384 -> 128 -> 18, README.md:26; train_frame.py:198-200);
 // other shapes run the row-split kernels.
 // Reference: Wavernn.forward / Wavernn.encoder (models/wavernn.py:63-102, 165-256).
@@ -47,13 +48,11 @@ constexpr int WQ1 = WV1 / 3, WQ2 = (WV2 + 2) / 3;  // 16-byte granules per workg
 constexpr int WQX = WFC / 3;                     // granules of an utterance's next input row (hop 3): 6
 constexpr int WFG = 4, WBG = 4;                  // waves per role
 constexpr int WFGT = WFG * 64;
-// granule block of a group, in 16-byte units: hello | h1 | h2 | next input
-// | the pairs' search results [utterance][half][stage][5]: {tag, distance (2 dwords), index}
+// granule block of a group, in 16-byte units: hello | h1 | h2 | next input (the receiver's third hop)
 constexpr int WOFF_HELLO = 0, WOFF_H1 = WNS, WOFF_H2 = WOFF_H1 + WNS * WQ1, WOFF_X = WOFF_H2 + WNS * WQ2,
-              WOFF_PAIR = WOFF_X + WG * WQX,
               // | the distributed searches' results [utterance][workgroup][5], first and second stage (predictor_wsd.h)
-              WOFF_G1 = WOFF_PAIR + WG * 2 * 2 * SURV, WOFF_G2 = WOFF_G1 + WG * WNS * SURV,
-              WGRANULES = WOFF_G2 + WG * WNS * SURV;  // 8 320 granules = 133 120 bytes
+              WOFF_G1 = WOFF_X + WG * WQX, WOFF_G2 = WOFF_G1 + WG * WNS * SURV,
+              WGRANULES = WOFF_G2 + WG * WNS * SURV;  // 8 000 granules = 128 000 bytes
 static_assert(NT == 512, "predictor_ws.h is written for 8 waves per workgroup");
 static_assert(WH1 / 4 == 96 && WH2 / 2 == 64 && WFC == NDIM + 1, "production shape");
 enum { WSIG_A = 0, WSIG_B, WSIG_H1, WSIG_H2, WSIG_P1, WSIG_P2, WSIG_C, WSIG_I, WSIG_X, WSIG_FG, WSIG_FB, WNSIG };
@@ -63,8 +62,10 @@ struct WsArgs {
     u32x4* g;                  // [ngroups][WGRANULES], zeroed before the launch
     unsigned* err;             // the handle's status word
     unsigned long long limit;  // give-up bound of one spin, s_memrealtime ticks
-    int withhold;              // test hook: the last workgroup of group 0 never publishes
+    int withhold;              // test hook: the last workgroup of group 0 never publishes (2: not even its hello)
     int no_fast;               // FPC_FAST_HOP=0: always the write-through path (tests run both)
+    unsigned* dec;             // [ngroups] decision words (0 undecided, WS_GO, WS_FALLBACK: ws_hello), zeroed with the granules
+    unsigned long long hello_limit;  // bound of the first wait for the partners' hello (ticks): behind it the group falls back
 };
 
 struct __attribute__((aligned(16))) WsLds : SearchLds {
@@ -87,17 +88,7 @@ struct __attribute__((aligned(16))) WsLds : SearchLds {
     int dead;
     int dead_latch;  // the value every thread acts on at the end of a frame (read once, between two barriers)
     int same_xcd;
-    // scratch of the frame tail's searches (ws_encode_tail)
-    double cand_d[64];           // first-stage entries at or below the bound, in arrival order
-    int cand_i[64];
-    int ncand;
-    double wmin[NW];             // per-wave smallest first-stage distance
-    double ent[SURV][NDIM + 1];  // the survivors' first-stage entries
-    int sv[SURV];                // the survivors
-    double od2[SURV];            // best second-stage entry per survivor
-    int oi2[SURV];
-    double loc_d[2][SURV];       // first-stage lists of the two halves of a pair (this workgroup's, the partner's)
-    int loc_i[2][SURV];
+    int hello;       // the group's decision as this workgroup adopted it (ws_hello)
     // the distributed tail (predictor_wsd.h): every workgroup of a group serves every utterance of the group
     double cbs[3][WNS][NDIM + 1];  // this workgroup's entries 32 m + slice of the books hi stage 1, hi stage 2, lo
     float pFa[8][WFC * WG];        // output-layer segment sums of all 16 utterances [segment][row * 16 + utterance]
@@ -158,8 +149,10 @@ struct WsCtx {
     int slice, nu, b0;          // this workgroup's slice, valid utterances of the group, first utterance
     int own;                    // utterance of the group whose prediction this workgroup needs (-1: none)
     unsigned* err;
-    unsigned long long limit;
-    bool fast, withhold;
+    unsigned long long limit, hello_limit;
+    unsigned* dec;              // this group's decision word
+    bool fast, withhold, withhold_hello;
+    bool fallback;              // the group decided WS_FALLBACK: this launch leaves its utterances to the row-split launch behind it
 };
 
 // The end of a frame in the closed-loop kernels: has any wait of this frame been given up?  Every poll that fails sets
@@ -227,7 +220,7 @@ __device__ __forceinline__ bool ws_poll(const WsCtx& X, WsLds& L, const int (&gi
         if (ws_dead(L)) return false;
         if ((++spins & 63u) == 0) {
             const unsigned long long now = __builtin_amdgcn_s_memrealtime();
-            if (t0 == 0 || now - last > X.limit / 4) t0 = now;  // (a gap that long: this wave was descheduled, await_granule)
+            if (t0 == 0 || now - last > spin_rearm_gap(X.limit)) t0 = now;  // (this wave was descheduled: await_granule)
             last = now;
             if (now - t0 > X.limit || (status_load(X.err) & FPC_ST_TIMEOUT) != 0u) {
                 ws_give_up(X, L);
@@ -330,7 +323,28 @@ __device__ __forceinline__ void ws_load_weights(const PredDev& P, WsLds& L, WsRe
     }
 }
 
-// once per launch (all threads; ends with barriers): X.fast, or L.dead when a partner never shows up
+// Once per launch (all threads; ends with barriers): are all 32 workgroups of the group RESIDENT?  The frame loop needs
+// them all at once (each spins for the others' granules), and nothing guarantees it: another kernel -- of another process,
+// or this library's own vocoder launch on a side stream -- may hold CUs for as long as it runs.  So the group DECIDES, once,
+// before anything is computed or written:
+//   * every workgroup publishes a hello granule {tag, XCD id} and polls the other 31, for at most `hello_limit` (10 ms);
+//   * the first workgroup to see all 31 tries WS_GO on the group's decision word, the first to run out of patience tries
+//     WS_FALLBACK (one compare-and-swap from 0: the first attempt wins, every workgroup adopts the winner);
+//   * GO: all 32 have published, hence are resident and stay so (a workgroup is not preempted out of a running launch
+//     short of a queue preemption, which the spins' clocks allow for): a workgroup that lost patience goes back to waiting
+//     -- for the frame loop's own bound now (1 s), a real failure if it expires (FPC_ERR_TIMEOUT as before);
+//   * FALLBACK: every workgroup of the group returns at once -- also those dispatched later, which find the word set --
+//     and the launch queued behind this one on the stream (the row-split kernels, one workgroup per utterance, no partner
+//     to wait for: SplitArgs.only) serves exactly the groups that decided so.  Slower, never wrong, never a timeout.
+// Also: X.fast (all 32 on one XCD), or L.dead when the handle has failed already.
+__device__ __forceinline__ unsigned ws_dec_load(const WsCtx& X) {
+    return __hip_atomic_load((gu32*)X.dec, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ unsigned ws_dec_try(const WsCtx& X, unsigned want) {  // the decision after this attempt
+    unsigned seen = 0u;
+    (void)__hip_atomic_compare_exchange_strong((gu32*)X.dec, &seen, want, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return seen == 0u ? want : seen;
+}
 __device__ __forceinline__ void ws_hello(WsCtx& X, WsLds& L, const WsArgs& S, int tid) {
     unsigned xcc;
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
@@ -338,19 +352,62 @@ __device__ __forceinline__ void ws_hello(WsCtx& X, WsLds& L, const WsArgs& S, in
     const unsigned tag = 0xffffffffu;  // (no frame's epoch)
     if (tid == 0) {
         L.same_xcd = 1;
-        if (!X.withhold) {  // general path: nothing is known about the placement yet
+        L.hello = 0;
+        if (!X.withhold_hello && !ws_dead(L) && ws_dec_load(X) != WS_FALLBACK) {  // general path: nothing is known about the placement yet
             const u32x4 w = {tag, xcc, 0u, 0u};
             __builtin_amdgcn_raw_buffer_store_b128(w, X.rs, (WOFF_HELLO + X.slice) * 16, 0, 16);
         }
     }
     __syncthreads();
-    if (tid < 64) {
-        int gi[1] = {tid < WNS && tid != X.slice ? WOFF_HELLO + tid : -1};
-        u32x4 v[1];
-        const bool got = ws_poll<1>(X, L, gi, tag, v);
-        if (got && gi[0] >= 0 && v[0].y != xcc) L.same_xcd = 0;
+    if (tid < 64 && !ws_dead(L)) {
+        const int gi = (tid < WNS && tid != X.slice) ? WOFF_HELLO + tid : -1;
+        unsigned dec = 0u;
+        bool patient = false;  // the group has decided GO: the partners exist, wait for them like the frame loop does
+        for (;;) {
+            unsigned spins = 0;
+            unsigned long long t0 = 0, last = 0;
+            bool all = false, out = false;
+            for (;;) {
+                const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(X.rs, (gi < 0 ? 0 : gi) * 16, 0, 16);
+                dec = ws_dec_load(X);
+                // (the test hook's workgroup stands for one that is not resident: it decides nothing, it follows)
+                all = !X.withhold_hello && __all(gi < 0 || v.x == tag);
+                if (all) {
+                    if (gi >= 0 && v.y != xcc) L.same_xcd = 0;
+                    break;
+                }
+                if (dec == WS_FALLBACK) break;
+                if (dec == WS_GO) patient = true;
+                if ((++spins & 63u) == 0) {
+                    const unsigned long long now = __builtin_amdgcn_s_memrealtime();
+                    const unsigned long long lim = (patient || X.withhold_hello) ? X.limit : X.hello_limit;
+                    if (t0 == 0 || now - last > spin_rearm_gap(lim)) t0 = now;
+                    last = now;
+                    if (now - t0 > lim || (status_load(X.err) & FPC_ST_TIMEOUT) != 0u) {
+                        out = true;
+                        break;
+                    }
+                }
+                __builtin_amdgcn_s_sleep(1);
+                asm volatile("" ::: "memory");
+            }
+            if (all) {
+                dec = ws_dec_try(X, WS_GO);
+            } else if (out && !patient && !X.withhold_hello) {
+                dec = ws_dec_try(X, WS_FALLBACK);
+                if (dec == WS_GO) {  // (somebody saw all 32 a moment ago: they are there)
+                    patient = true;
+                    continue;
+                }
+            } else if (out) {  // the partners were there and stopped answering (or the handle failed meanwhile): a real failure
+                ws_give_up(X, L);
+            }
+            break;
+        }
+        if (tid == 0) L.hello = (int)dec;
     }
     __syncthreads();
+    X.fallback = L.hello == (int)WS_FALLBACK;
     X.fast = L.same_xcd != 0 && !ws_dead(L) && S.no_fast == 0;
 }
 
@@ -810,9 +867,13 @@ __device__ __forceinline__ WsCtx ws_ctx(const WsArgs& S, int group, int slice) {
     X.nu = S.B - X.b0 < WG ? S.B - X.b0 : WG;
     X.err = S.err;
     X.limit = S.limit;
+    X.hello_limit = S.hello_limit;
+    X.dec = S.dec + group;
+    X.fallback = false;
     X.fast = false;
-    X.own = slice < X.nu ? slice : -1;  // (the encoder pairs workgroup s + 16 with s: k_encode_ws)
+    X.own = slice < X.nu ? slice : -1;
     X.withhold = S.withhold != 0 && group == 0 && slice == WNS - 1;
+    X.withhold_hello = X.withhold && S.withhold == 2;
     return X;
 }
 
@@ -842,6 +903,7 @@ __global__ __launch_bounds__(NT) void k_forward_ws(const PredDev P, const float*
     }
     __syncthreads();
     ws_prologue(P, X, L, R, S, tid);
+    if (X.fallback) return;  // (workgroup- and group-uniform, nothing written yet) the row-split launch behind this one serves the group
     const bool owner = slice < X.nu;  // this workgroup stores the outputs of utterance `slice` of the group
     // Teacher forcing: every input row is known in advance, so the input product I(t+1) = W1i x(t+1) leaves the chain -- the
     // foreground puts x(t+1) into LDS as soon as frame t begins (I(t) has been taken from x(t) a frame earlier), background
@@ -926,28 +988,7 @@ __device__ __forceinline__ void ws_publish_x(const WsCtx& X, WsLds& L, int lane,
 }
 
 
-// ---- the encoder's frame tail on the workgroup that owns the utterance (wavernn.py:196-252) ------------------------------
-// encode_frame (predictor.hip) restated for a tail that EVERY frame of the group now waits for (the slowest of 16
-// utterances sets the pace, and one of them is almost always above the threshold): same results bit for bit -- every
-// distance is the float64 sum in numpy's pairwise order (vq_func.py:18), every choice the smallest (distance, index) -- in
-// fewer steps on the critical path:
-//   * an entry's coordinates arrive as nine 16-byte loads (pair layout [9][N][2]) instead of seventeen 8-byte ones, issued
-//     before anything else; the scalar search (one wave, codes in LDS) runs in their shadow;
-//   * first stage of a 2-stage search: instead of five rounds of wave-wide arg-min networks per wave and five more to merge
-//     them, a BOUND -- the fifth smallest of the eight per-wave minima, at or below which at least five entries lie -- picks
-//     the few candidates (about seven), which one wave ranks by counting; the second stage's entries are loaded meanwhile;
-//   * the winners' coordinates are written by the threads that hold them (no L2 round trip for the quantized vector).
-// Anything outside the fast path's limits (more than 1 024 entries per stage, more than 256 scalar codes or codes not in
-// LDS, more than 64 candidates at the bound: a degenerate codebook) runs encode_frame itself.
-__device__ __forceinline__ void ws_load_entry(const double* __restrict__ cbP, int N, int e, bool has, double (&c)[NDIM + 1]) {
-#pragma unroll
-    for (int j = 0; j < (NDIM + 1) / 2; ++j) {
-        double2 v = make_double2(0.0, 0.0);
-        if (has) v = reinterpret_cast<const double2*>(cbP)[(size_t)j * N + e];
-        c[2 * j] = v.x;
-        c[2 * j + 1] = v.y;
-    }
-}
+// float64 squared distance in numpy's pairwise order (vq_func.py:18): target in LDS, entry in registers
 __device__ __forceinline__ double ws_dist(const double* x, const double (&c)[NDIM + 1]) {
     double r[8];
 #pragma unroll
@@ -967,446 +1008,6 @@ __device__ __forceinline__ double ws_dist(const double* x, const double (&c)[NDI
     res = res + dd;
     return res;
 }
-__device__ __forceinline__ double wave_min_f64(double d) {  // every lane gets the wave's smallest value
-    double m = d;
-    m = min_f64(m, dpp_mov_f64<0xB1, 0xf, false>(m));
-    m = min_f64(m, dpp_mov_f64<0x4E, 0xf, false>(m));
-    m = min_f64(m, dpp_mov_f64<0x141, 0xf, false>(m));
-    m = min_f64(m, dpp_mov_f64<0x140, 0xf, false>(m));
-    m = min_f64(m, dpp_mov_f64<0x142, 0xa, false>(m));
-    m = min_f64(m, dpp_mov_f64<0x143, 0xc, false>(m));
-    const unsigned long long b = (unsigned long long)__double_as_longlong(m);
-    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)b, 63);
-    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(b >> 32), 63);
-    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
-}
-// scl_quantize (vq_func.py:167-185) by one wave, n <= 256 codes in LDS (scl_search_lds without its barriers)
-__device__ __forceinline__ void ws_scl_wave(WsLds& L, float xv, int off, int n, int lane) {
-    double bd = INFINITY;
-    int bi = 0x7fffffff;
-    const double v = (double)xv;
-    for (int c = lane; c < n; c += 64) {
-        const double df = v - L.sclc[off + c];
-        const double d = df * df;
-        if (d < bd) {
-            bd = d;
-            bi = c;
-        }
-    }
-    wave_argmin(bd, bi);
-    if (lane == 0) {
-        L.res_i[2] = bi;
-        L.qs = L.sclc[off + bi];
-    }
-}
-// a list of up to five (distance, index) results goes to the partner workgroup / comes from it (lanes < 5 of one wave)
-__device__ __forceinline__ void ws_pair_put(const WsCtx& X, int u, int half, int stage, int k, unsigned epoch, double d, int ix) {
-    if (X.withhold) return;
-    const unsigned long long b = (unsigned long long)__double_as_longlong(d);
-    const u32x4 w = {epoch, (unsigned)b, (unsigned)(b >> 32), (unsigned)ix};
-    const int g = WOFF_PAIR + ((u * 2 + half) * 2 + stage) * SURV + k;
-    if (X.fast)
-        __builtin_amdgcn_raw_buffer_store_b128(w, X.rs, g * 16, 0, 0);
-    else
-        __builtin_amdgcn_raw_buffer_store_b128(w, X.rs, g * 16, 0, 16);
-}
-__device__ __forceinline__ bool ws_pair_get(const WsCtx& X, WsLds& L, int u, int half, int stage, int lane, unsigned epoch,
-                                            double& d, int& ix) {
-    int gi[1] = {lane < SURV ? WOFF_PAIR + ((u * 2 + half) * 2 + stage) * SURV + lane : -1};
-    u32x4 v[1];
-    if (!ws_poll<1>(X, L, gi, epoch, v)) return false;
-    d = __longlong_as_double((long long)(((unsigned long long)v[0].z << 32) | v[0].y));
-    ix = (int)v[0].w;
-    return true;
-}
-// The tail for utterance `u` of the group on its PAIR of workgroups: half 0 (workgroup u, the owner: scalar search, outputs,
-// next input row) and half 1 (workgroup u + 16, the helper).  Each half holds the entries [half NT, half NT + NT) of a stage,
-// one per thread: half of the loads, half of the float64 arithmetic, 36 registers of coordinates instead of 72.  A stage with
-// more than NT entries is searched by both halves and their results meet through 16-byte granules: after the first stage both
-// halves exchange their five best and rank the ten (so both know the survivors), after the second the helper hands its best
-// entry per survivor to the owner.  A stage that fits one half is searched by the owner alone.
-// false: an exchange was given up (the launch is dead).
-__device__ __forceinline__ bool ws_encode_tail(const WsCtx& X, WsLds& L, const float* fo, float* xn, const PredDev& P, const CbDev& C,
-                                               const EncArgs& A, unsigned* err, size_t fi, float fv, int tid0, bool scl_in_lds,
-                                               int u, int half, unsigned epoch) {
-    const int wave = tid0 >> 6, tid = tid0 + ws_opaque_zero(), lane = tid & 63;
-    const int Cc = WIN, F = WFC;
-    const bool owner = half == 0;
-    if (tid < F) L.rs[tid] = fv - fo[tid];  // :196
-    if (tid == 0) L.ncand = 0;
-    if (tid < 2 * SURV) {
-        L.loc_d[tid / SURV][tid % SURV] = INFINITY;
-        L.loc_i[tid / SURV][tid % SURV] = 0x7fffffff;
-    }
-    lds_barrier();
-    WSTAMP(13)
-    float sabs = 0.0f;
-    for (int d = 1; d < F; ++d) sabs += fabsf(L.rs[d]);
-    const int i1 = fabsf(L.rs[0]) > A.l1;  // :202
-    const int i2 = sabs > A.l2;            // :206
-    const bool nonfinite = !(fabsf(L.rs[0]) <= 3.0e38f) || !(sabs <= 3.0e38f);
-    const bool do_scl = A.qtz && !nonfinite && (i1 || C.scl_lo);
-    const bool do_vq = A.qtz && !nonfinite && (i2 || C.vq_lo);
-    const int S = i2 ? C.S_hi : 1, N0 = i2 ? C.N_hi0 : C.N_lo, N1 = (i2 && C.S_hi == 2) ? C.N_hi1 : 0;
-    WSTAMP(14)
-    // (the host launches this kernel only within the tail's limits -- ws_codebooks_fit in predictor.hip: at most 2 NT entries
-    //  per stage, at most 256 codes per scalar codebook, all of them in LDS)
-    const bool pair0 = N0 > NT, pair1 = N1 > NT;  // stages that both halves search
-    if (!owner && !(do_vq && (pair0 || pair1))) return true;  // (workgroup-uniform) nothing for the helper in this frame
-    if (owner && nonfinite && A.qtz && tid == 0) status_or(err, FPC_ST_NONFINITE);
-    // which entry of its half a thread holds rotates with the utterance, so that the workgroups of an XCD, which sweep the
-    // same codebook at the same time, ask different L2 channels at any moment (any assignment gives the same result: every
-    // choice below is a minimum over (distance, index))
-    const int e = half * NT + ((tid + 64 * (u & (NW - 1))) & (NT - 1));
-    if (do_vq) {
-        const double* p0 = i2 ? C.vq_hi0_p : C.vq_lo_p;
-        const double* cb0R = i2 ? C.vq_hi0_r : C.vq_lo_r;
-        double c[NDIM + 1];
-        const bool h0 = e < N0;
-        ws_load_entry(p0, N0, e, h0, c);
-        WSTAMP(15)
-        if (tid < NDIM) L.xq[0][tid] = (double)L.rs[1 + tid];
-        if (owner && do_scl && wave == NW - 1) ws_scl_wave(L, L.rs[0], i1 ? 0 : C.n_hi, i1 ? C.n_hi : C.n_lo, lane);
-        lds_barrier();
-        WSTAMP(25)
-        const double d0 = h0 ? ws_dist(L.xq[0], c) : INFINITY;
-        if (S == 1) {  // the nearest entry is all a 1-stage search returns (vq_func.py:93-95)
-            double db = d0;
-            int eb = h0 ? e : 0x7fffffff;
-            wave_argmin(db, eb);
-            if (lane == 0) {
-                L.wd[0][wave][0] = db;
-                L.wi[0][wave][0] = eb;
-            }
-            lds_barrier();
-            double gd = L.wd[0][0][0];
-            int gi = L.wi[0][0][0];
-#pragma unroll
-            for (int w = 1; w < NW; ++w) take_min(gd, gi, L.wd[0][w][0], L.wi[0][w][0]);
-            if (pair0) {
-                if (!owner) {  // the helper's best goes to the owner: done
-                    if (tid == 0) ws_pair_put(X, u, 1, 0, 0, epoch, gd, gi);
-                    return true;
-                }
-                bool ok = true;
-                if (wave == 0) {
-                    double pd = INFINITY;
-                    int pi = 0x7fffffff;
-                    ok = ws_pair_get(X, L, u, 1, 0, lane < 1 ? lane : SURV, epoch, pd, pi);
-                    if (lane == 0) {
-                        L.loc_d[1][0] = pd;
-                        L.loc_i[1][0] = pi;
-                    }
-                }
-                (void)ok;  // (given up: the flag is set, the frame ends with the owner's own best and is thrown away)
-                lds_barrier();
-                take_min(gd, gi, L.loc_d[1][0], L.loc_i[1][0]);
-            }
-            if (gi == e && h0) {  // the winner's thread holds its coordinates
-#pragma unroll
-                for (int d = 0; d < NDIM; ++d) L.qv[d] = c[d];
-            } else if (gi / NT != half && tid < NDIM) {  // (the helper's entry won)
-                L.qv[tid] = cb0R[(size_t)gi * NDIM + tid];
-            }
-            if (tid == 0) {
-                L.res_i[0] = gi;
-                L.res_i[1] = -1;
-            }
-        } else {
-            // ---- first stage: the five smallest by (distance, index) (vq_quantize_mbest, vq_func.py:10-24) ----
-            const double wm = wave_min_f64(d0);
-            if (lane == 0) L.wmin[wave] = wm;
-            // the second stage's entry replaces the first stage's in the registers while the survivors are sorted out
-            const bool g0 = e < N1;
-            ws_load_entry(C.vq_hi1_p, N1, e, g0, c);
-            lds_barrier();
-            WSTAMP(26)
-            double T;  // the fifth smallest per-wave minimum: at least five of this half's entries are at or below it (or
-            {          // all of them, where it is infinite), so its five smallest are, and everything at or below it is ranked
-                const int j = lane & (NW - 1);
-                const double m = L.wmin[j];
-                int cnt = 0;
-#pragma unroll
-                for (int k = 0; k < NW; ++k) {
-                    const double mk = L.wmin[k];
-                    cnt += (mk < m) | ((mk == m) & (k < j));
-                }
-                const unsigned long long pick = __ballot(cnt == SURV - 1 && lane < NW);
-                const int src = __builtin_ctzll(pick);
-                const unsigned long long b = (unsigned long long)__double_as_longlong(m);
-                const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)b, src);
-                const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(b >> 32), src);
-                T = __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
-            }
-            if (h0 && d0 <= T) {
-                const int pos = __hip_atomic_fetch_add(&L.ncand, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                if (pos < 64) {
-                    L.cand_d[pos] = d0;
-                    L.cand_i[pos] = e;
-                }
-            }
-            lds_barrier();
-            WSTAMP(27)
-            const int n = L.ncand;
-            if (n <= 64) {  // (workgroup-uniform) rank by counting: the candidates are few
-                if (wave == 0 && lane < n) {
-                    const double dj = L.cand_d[lane];
-                    const int ij = L.cand_i[lane];
-                    int rank = 0;
-                    for (int k = 0; k < n; ++k) {
-                        const double dk = L.cand_d[k];
-                        const int ik = L.cand_i[k];
-                        rank += (dk < dj) | ((dk == dj) & (ik < ij));
-                    }
-                    if (rank < SURV) {
-                        L.loc_d[0][rank] = dj;
-                        L.loc_i[0][rank] = ij;
-                    }
-                }
-                lds_barrier();
-            } else {  // many entries at the bound (a degenerate codebook): five rounds of arg-min, each winner struck out
-                bool x0 = !h0;
-#pragma unroll 1
-                for (int r = 0; r < SURV; ++r) {
-                    double d = x0 ? INFINITY : d0;
-                    int ee = x0 ? 0x7fffffff : e;
-                    wave_argmin(d, ee);
-                    if (lane == 0) {
-                        L.wd[0][wave][0] = d;
-                        L.wi[0][wave][0] = ee;
-                    }
-                    lds_barrier();
-                    double gd = L.wd[0][0][0];
-                    int gi = L.wi[0][0][0];
-#pragma unroll
-                    for (int w = 1; w < NW; ++w) take_min(gd, gi, L.wd[0][w][0], L.wi[0][w][0]);
-                    if (gi == e) x0 = true;
-                    if (tid == 0) {
-                        L.loc_d[0][r] = gd;
-                        L.loc_i[0][r] = gi;
-                    }
-                    lds_barrier();
-                }
-            }
-            // this half's five best are in loc[0] (fewer: padded with infinite distances); the two halves exchange theirs
-            if (wave == 0) {
-                bool ok = true;
-                if (pair0 || pair1) {
-                    if (lane < SURV) ws_pair_put(X, u, half, 0, lane, epoch, L.loc_d[0][lane], L.loc_i[0][lane]);
-                    double pd = INFINITY;
-                    int pi = 0x7fffffff;
-                    ok = ws_pair_get(X, L, u, half ^ 1, 0, lane, epoch, pd, pi);
-                    if (lane < SURV) {
-                        L.loc_d[1][lane] = pd;
-                        L.loc_i[1][lane] = pi;
-                    }
-                }
-                (void)ok;
-                // rank the ten (the same on both halves): the survivors
-                if (lane < 2 * SURV) {
-                    const double dj = L.loc_d[lane / SURV][lane % SURV];
-                    const int ij = L.loc_i[lane / SURV][lane % SURV];
-                    int rank = 0;
-#pragma unroll
-                    for (int k = 0; k < 2 * SURV; ++k) {
-                        const double dk = L.loc_d[k / SURV][k % SURV];
-                        const int ik = L.loc_i[k / SURV][k % SURV];
-                        rank += (dk < dj) | ((dk == dj) & (ik < ij));
-                    }
-                    if (rank < SURV && ij != 0x7fffffff) L.sv[rank] = ij;
-                }
-            }
-            lds_barrier();
-            WSTAMP(28)
-            // ---- second stage: residual of every survivor (vq_func.py:103-108); total errors compared ----
-            if (tid < SURV * NDIM) {
-                const int k = tid / NDIM, d = tid - k * NDIM;
-                // (a launch that is already dead may get here without five survivors: the index stays inside the book)
-                const int sk = L.sv[k] < 0 ? 0 : (L.sv[k] < N0 ? L.sv[k] : N0 - 1);
-                const double en = cb0R[(size_t)sk * NDIM + d];
-                L.ent[k][d] = en;
-                L.xq[k][d] = (double)L.rs[1 + d] - en;
-            }
-            lds_barrier();
-            WSTAMP(29)
-#pragma unroll 1
-            for (int k = 0; k < SURV; ++k) {
-                double qb = g0 ? ws_dist(L.xq[k], c) : INFINITY;
-                int qe = g0 ? e : 0x7fffffff;
-                wave_argmin(qb, qe);
-                if (lane == 0) {
-                    L.wd[k][wave][0] = qb;
-                    L.wi[k][wave][0] = qe;
-                }
-            }
-            lds_barrier();
-            WSTAMP(30)
-            if (tid < SURV) {
-                double d = L.wd[tid][0][0];
-                int ix = L.wi[tid][0][0];
-                for (int w = 1; w < NW; ++w) take_min(d, ix, L.wd[tid][w][0], L.wi[tid][w][0]);
-                if (pair1) {
-                    if (!owner) {
-                        ws_pair_put(X, u, 1, 1, tid, epoch, d, ix);
-                    } else {
-                        double pd = INFINITY;
-                        int pi = 0x7fffffff;
-                        if (ws_pair_get(X, L, u, 1, 1, tid, epoch, pd, pi)) take_min(d, ix, pd, pi);
-                    }
-                }
-                L.od2[tid] = d;
-                L.oi2[tid] = ix;
-            }
-            if (!owner) return true;  // (the helper's part ends here)
-            lds_barrier();
-            // head of the merge-insert of candidate paths (vq_func.py:110-125): a later survivor replaces the running best
-            // only if its total error is strictly smaller
-            int bk = 0;
-            double g = L.od2[0];
-#pragma unroll
-            for (int k = 1; k < SURV; ++k) {
-                const double gk = L.od2[k];
-                if (gk < g) {
-                    g = gk;
-                    bk = k;
-                }
-            }
-            const int w1 = L.oi2[bk];
-            if (w1 == e && g0) {  // :127-129; the winner's thread holds its coordinates
-#pragma unroll
-                for (int d = 0; d < NDIM; ++d) L.qv[d] = L.ent[bk][d] + c[d];
-            } else if (w1 / NT != half && tid < NDIM) {  // (the helper's entry won)
-                L.qv[tid] = L.ent[bk][tid] + C.vq_hi1_r[(size_t)w1 * NDIM + tid];
-            }
-            if (tid == 0) {
-                L.res_i[0] = L.sv[bk];
-                L.res_i[1] = w1;
-            }
-        }
-        lds_barrier();
-    } else if (do_scl) {
-        if (wave == 0) ws_scl_wave(L, L.rs[0], i1 ? 0 : C.n_hi, i1 ? C.n_hi : C.n_lo, lane);
-        lds_barrier();
-    }
-    WSTAMP(31)
-    // ---- the frame's outputs and the next input row (encode_frame's last part) ----
-    float rq = 0.0f;
-    int ix0 = -1, ix1 = -1, ix2 = -1, ix3 = -1;
-    if (nonfinite) ix0 = ix1 = ix2 = ix3 = -2;
-    // (the usage histograms are counted from the frame's symbols by k_hist_symbols after this kernel: an atomic here costs the
-    //  closed loop a memory round trip per frame)
-    if (do_scl && tid == 0) {
-        rq = (float)L.qs;
-        ix0 = L.res_i[2] + (i1 ? 0 : C.n_hi);
-    }
-    if (do_vq) {
-        if (tid >= 1 && tid < F) rq = (float)L.qv[tid - 1];
-        if (tid == 0) {
-            if (i2) {
-                ix1 = L.res_i[0];
-                ix2 = L.res_i[1];
-            } else {
-                ix3 = L.res_i[0];
-            }
-        }
-    }
-    if (tid < F) {
-        const float rs = L.rs[tid];
-        const int ind = tid == 0 ? i1 : i2;
-        float rv, ru, cn;
-        if (A.qtz) {
-            rv = rs;  // un-thresholded residual (:197)
-            ru = 0.0f;
-            cn = fo[tid] + rq;  // :242
-        } else {                  // :244-252
-            ru = rs * (float)(1 - ind);
-            rv = rs * (float)ind;
-            cn = fo[tid] + rv;
-        }
-        A.r[fi * F + tid] = rv;
-        A.r_qtz[fi * F + tid] = rq;
-        A.r_under[fi * F + tid] = ru;
-        A.c_in[fi * Cc + tid] = cn;
-        xn[tid] = cn;
-    } else if (tid < Cc) {  // pitch columns pass through (:178)
-        A.c_in[fi * Cc + tid] = fv;
-        xn[tid] = fv;
-    }
-    if (tid == 0) {
-        A.ind1[fi] = (float)i1;
-        A.ind2[fi] = (float)i2;
-        *reinterpret_cast<int4*>(&A.idx[fi * 4]) = make_int4(ix0, ix1, ix2, ix3);  // (never null here: fpc_encode)
-    }
-    WSTAMP(17)
-    lds_barrier();  // (the next input row is in LDS; the frame's global stores need not have landed)
-    WSTAMP(18)
-    return true;
-}
-
-__global__ __launch_bounds__(NT) void k_encode_ws(const PredDev P, const CbDev C, const EncArgs A, const WsArgs S) {
-    __shared__ WsLds L;
-    const int tid = threadIdx.x;
-    int group, slice;
-    if (!ws_role(S.ngroups, group, slice)) return;
-    WsCtx X = ws_ctx(S, group, slice);
-    // utterance u of the group is coded by workgroups u (owner) and u + 16 (helper): both need its prediction
-    const int u = slice & (WG - 1), half = slice / WG;
-    const bool member = u < X.nu, owner = member && half == 0;
-    X.own = member ? u : -1;
-    WsRegs R;
-    for (int i = tid; i < WH1 * WG; i += NT) L.h1[i] = 0.0f;  // h = None -> zeros (wavernn.py:182)
-    for (int i = tid; i < WH2 * WG; i += NT) L.h2[i] = 0.0f;
-    for (int i = tid; i < WIN * WG; i += NT) L.x[i] = 0.0f;   // c_in[:, 0, :] is all zero (wavernn.py:177-178)
-    const bool scl_in_lds = C.n_hi + C.n_lo <= SCLC;
-    if (scl_in_lds) {
-        for (int k = tid; k < C.n_hi; k += NT) L.sclc[k] = C.scl_hi[k];
-        for (int k = tid; k < C.n_lo; k += NT) L.sclc[C.n_hi + k] = C.scl_lo[k];
-    }
-    __syncthreads();
-    ws_prologue(P, X, L, R, S, tid);
-    const int b = X.b0 + u;  // the pair's utterance
-    int fg_epoch = 0;
-    int i = 0;
-    WPROF_INIT()
-    for (; i < A.Lf; ++i) {
-        const unsigned epoch = (unsigned)i + 1u;
-        // this frame's feature row of the pair's utterance (one column per thread), and the pitch columns of every
-        // utterance of the group, which pass through to the next input (wavernn.py:178): fetched before the step
-        const float fv = (member && tid < WIN) ? A.feat[((size_t)b * A.Lf + i) * WIN + tid] : 0.0f;
-        float pv = 0.0f;
-        if (tid < (WIN - WFC) * WG) {
-            const int uu = tid / (WIN - WFC), k = WFC + tid % (WIN - WFC);
-            if (uu < X.nu) pv = A.feat[((size_t)(X.b0 + uu) * A.Lf + i) * WIN + k];
-        }
-        if (tid < WFGT) {
-            __builtin_amdgcn_s_setprio(FPC_FG_PRIO);
-            (void)ws_foreground(X, L, R, i, tid, fg_epoch);
-            __builtin_amdgcn_s_setprio(0);
-        } else {
-            (void)ws_background(X, L, R, i, i + 1 == A.Lf, tid - WFGT);
-        }
-        WBSTAMP(19)
-        lds_barrier();  // both roles meet: the searches take the whole workgroup
-        WSTAMP(20)
-        // (a launch that is dead by now runs the frame to its end on whatever the chain left behind -- every index stays inside
-        //  its codebook, a missing partner counts as "no entry" -- and leaves the loop below)
-        if (member) {
-            (void)ws_encode_tail(X, L, L.fo[u], L.xn, P, C, A, S.err, (size_t)b * A.Lf + i, fv, tid, scl_in_lds, u, half, epoch);
-            if (owner && tid < 64) ws_publish_x(X, L, tid, epoch);
-        }
-        WSTAMP(21)
-        if (tid < (WIN - WFC) * WG) {
-            const int uu = tid / (WIN - WFC), k = WFC + tid % (WIN - WFC);
-            if (!(owner && uu == u)) L.x[k * WG + uu] = pv;
-        }
-        if (tid < 128) (void)ws_gather3(X, L, tid, epoch);
-        if (ws_frame_dead(L, tid)) break;
-        WSTAMP(22)
-        WBSTAMP(23)
-    }
-    WPROF_DUMP(A.Lf)
-    if (i < A.Lf && owner) encode_poison(P, A, b, i, tid);
-}
 
 __global__ __launch_bounds__(NT) void k_decode_feat_ws(const PredDev P, const CbDev C, const float* __restrict__ pitch,
                                                        const int* __restrict__ idx, int Lf, float* __restrict__ c_out,
@@ -1422,6 +1023,7 @@ __global__ __launch_bounds__(NT) void k_decode_feat_ws(const PredDev P, const Cb
     for (int i = tid; i < WIN * WG; i += NT) L.x[i] = 0.0f;
     __syncthreads();
     ws_prologue(P, X, L, R, S, tid);
+    if (X.fallback) return;  // (workgroup- and group-uniform, nothing written yet) the row-split launch behind this one serves the group
     const bool owner = slice < X.nu;
     const int b = X.b0 + slice;
     int fg_epoch = 0;

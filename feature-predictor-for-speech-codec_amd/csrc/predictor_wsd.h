@@ -1,9 +1,9 @@
 // predictor_wsd.h -- the encoder's frame tail DISTRIBUTED over the 32 workgroups of a group (included after predictor_ws.h).
 //
-// With the tail on the utterance's own workgroups (ws_encode_tail: owner + helper) a frame of the group lasts as long as its
-// slowest utterance, and one of 16 is almost always above the threshold: 2 x (1 024 + 5 x 1 024 entries x 51 float64
-// operations) on two CUs while 30 others wait, plus 16 x 139 kB of codebook per stage through the XCD's L2 -- 24.7k cycles
-// per frame (profiles/r04_ablations.txt).  Here every workgroup keeps 1/32 of every codebook in LDS for the launch (entries
+// With the tail on the utterance's own workgroups (round 4's owner + helper pairs, since removed) a frame of the group lasts
+// as long as its slowest utterance, and one of 16 is almost always above the threshold: 2 x (1 024 + 5 x 1 024 entries x 51
+// float64 operations) on two CUs while 30 others wait, plus 16 x 139 kB of codebook per stage through the XCD's L2 -- 24.7k
+// cycles per frame (profiles/r04_ablations.txt).  Here every workgroup keeps 1/32 of every codebook in LDS for the launch (entries
 // 32 m + slice: 32 per book, 13.8 kB) and serves EVERY utterance of the group: the TARGETS move, not the codebooks.
 //   thread (u = tid >> 5, m = tid & 31): utterance u of the group, entry m of this workgroup's slice -- or, when results
 //   come back, the list of workgroup m for utterance u: a half-wave per utterance throughout.
@@ -18,7 +18,7 @@
 //   5. every workgroup forms every utterance's quantized residual and next input row itself (no third hop); workgroup u
 //      stores utterance u's outputs.
 // Every choice is a minimum over (float64 distance in numpy's pairwise order, index) exactly as vq_func.py:10-24,110-125
-// makes it: results are bit-identical to encode_frame and ws_encode_tail (tests).
+// makes it: results are bit-identical to encode_frame (the row-split kernels' tail) and to the oracle (tests).
 
 // (distance, index) minimum over each HALF of the wave (lanes 0-31, 32-63), ties to the lower index; every lane gets its
 // half's.  The distance: one float64 pass (four steps inside the 16-lane rows, one row broadcast).  The index: where exactly
@@ -158,9 +158,10 @@ __device__ __forceinline__ void wsd_F(WsLds& L, const WsRegs& R, int fw, int lan
     L.pFa[rsg][row * WG + ru] = a;
 }
 
-// the frame's tail for all utterances of the group (all 512 threads); `fv`: feat[u][frame][m] of thread (u, m < 20)
+// the frame's tail for all utterances of the group (all 512 threads); `fv`: feat[u][frame][m] of thread (u, m < 20);
+// `mk`: the frame's two mask values of utterance u (mask mode, wavernn.py:209-211)
 __device__ __forceinline__ void wsd_tail(const WsCtx& X, WsLds& L, const CbDev& C, const EncArgs& A, unsigned* err, int frame,
-                                         float fv, int tid0, unsigned epoch) {
+                                         float fv, float2 mk, int tid0, unsigned epoch) {
     const int tid = tid0 + ws_opaque_zero(), lane = tid & 63, u = tid >> 5, m = tid & 31;
     const bool uv = u < X.nu;
     // ---- prediction, residual, first-stage target of utterance u: lane m < 18 = row m (wavernn.py:195-196).  Everything an
@@ -183,7 +184,8 @@ __device__ __forceinline__ void wsd_tail(const WsCtx& X, WsLds& L, const CbDev& 
     float sabs = 0.0f;
     for (int d = 1; d < WFC; ++d) sabs += fabsf(L.rsa[u][d]);
     const float r0 = L.rsa[u][0];
-    const int i1 = fabsf(r0) > A.l1, i2 = sabs > A.l2;
+    const bool masked = A.mask != nullptr;  // (`if ind1[k, 0]`, :218: any non-zero value)
+    const int i1 = masked ? (mk.x != 0.0f) : (fabsf(r0) > A.l1), i2 = masked ? (mk.y != 0.0f) : (sabs > A.l2);
     const bool nonfinite = !(fabsf(r0) <= 3.0e38f) || !(sabs <= 3.0e38f);
     const bool live = uv && A.qtz && !nonfinite;
     const bool do_scl = live && (i1 || C.scl_lo), do_vq = live && (i2 || C.vq_lo);
@@ -357,9 +359,10 @@ __device__ __forceinline__ void wsd_tail(const WsCtx& X, WsLds& L, const CbDev& 
             rv = rs;  // un-thresholded residual (:197)
             ru = 0.0f;
             cn = f + rq;
-        } else {
-            ru = rs * (float)(1 - ind);
-            rv = rs * (float)ind;
+        } else {  // (:244-252; mask mode: the products with the mask's own values)
+            const float mv = m == 0 ? mk.x : mk.y;
+            ru = rs * (masked ? 1.0f - mv : (float)(1 - ind));
+            rv = rs * (masked ? mv : (float)ind);
             cn = f + rv;
         }
         L.x[m * WG + u] = uv ? cn : 0.0f;
@@ -372,8 +375,8 @@ __device__ __forceinline__ void wsd_tail(const WsCtx& X, WsLds& L, const CbDev& 
     }
     if (owner && m >= WFC && m < WIN) A.c_in[fi * WIN + m] = fv;
     if (owner && m == 0) {
-        A.ind1[fi] = (float)i1;
-        A.ind2[fi] = (float)i2;
+        A.ind1[fi] = masked ? 0.0f : (float)i1;  // (the reference fills the indicator outputs from the thresholds only)
+        A.ind2[fi] = masked ? 0.0f : (float)i2;
         int o0 = ix0, o1 = -1, o2 = -1, o3 = -1;
         if (do_vq) {
             if (i2) {
@@ -409,16 +412,20 @@ __global__ __launch_bounds__(NT) void k_encode_wsd(const PredDev P, const CbDev 
     }
     __syncthreads();
     ws_prologue(P, X, L, R, S, tid);
+    if (X.fallback) return;  // (workgroup- and group-uniform, nothing written yet) the row-split launch behind this one serves the group
     int fg_epoch = 0;
     int i = 0;
     // this thread's feature value of a frame: thread (u, m) = column m < 20 of utterance u -- rows 0-17 for the residuals, the
     // pitch columns pass through to the next input (wavernn.py:178) -- where it is in frame 0 (nullptr: none)
     const float* fvp = nullptr;
     if ((tid & 31) < WIN && (tid >> 5) < X.nu) fvp = A.feat + (size_t)(X.b0 + (tid >> 5)) * A.Lf * WIN + (tid & 31);
+    const float2* mkp = nullptr;  // mask mode: the utterance's two indicators of a frame (every lane of its half-wave)
+    if (A.mask != nullptr && (tid >> 5) < X.nu) mkp = reinterpret_cast<const float2*>(A.mask) + (size_t)(X.b0 + (tid >> 5)) * A.Lf;
     WPROF_INIT()
     for (; i < A.Lf; ++i) {
         const unsigned epoch = (unsigned)i + 1u;
         const float fv = fvp != nullptr ? fvp[i * WIN] : 0.0f;  // fetched before the step
+        const float2 mk = mkp != nullptr ? mkp[i] : make_float2(0.0f, 0.0f);
         if (tid < WFGT) {
             __builtin_amdgcn_s_setprio(FPC_FG_PRIO);
             (void)ws_foreground<false, true>(X, L, R, i, tid, fg_epoch);
@@ -429,7 +436,7 @@ __global__ __launch_bounds__(NT) void k_encode_wsd(const PredDev P, const CbDev 
         WBSTAMP(19)
         lds_barrier();  // both roles meet: the tail takes the whole workgroup
         WSTAMP(20)
-        wsd_tail(X, L, C, A, S.err, i, fv, tid, epoch);
+        wsd_tail(X, L, C, A, S.err, i, fv, mk, tid, epoch);
         WSTAMP(21)
         // The frame's last barrier (the next input rows are in LDS) carries the give-up flag as well: one thread copies it
         // before the barrier, everybody acts on the copy behind it.  A wait given up behind the copy shows a frame later, or in
@@ -439,7 +446,13 @@ __global__ __launch_bounds__(NT) void k_encode_wsd(const PredDev P, const CbDev 
         if (L.dead_latch != 0) break;
         WSTAMP(22)
     }
-    if (i == A.Lf && A.Lf > 0 && ws_frame_dead(L, tid)) i = A.Lf - 1;  // (given up in the last frame's tail)
+    // A wait given up BEHIND a frame's copy of the flag (a wave still in the tail's gathers when thread 0 copied) has written
+    // that frame's outputs from a failed gather and shows in the next frame's copy only: a launch that leaves the loop at
+    // frame i poisons from frame i - 1 on (fpcodec.h: NaN / -2 "from that frame on", and such frames in no histogram).
+    if (i < A.Lf)
+        i = i > 0 ? i - 1 : 0;
+    else if (A.Lf > 0 && ws_frame_dead(L, tid))
+        i = A.Lf - 1;  // (given up in the last frame's tail, behind its copy)
     WPROF_DUMP(A.Lf)
     if (i < A.Lf && slice < X.nu) encode_poison(P, A, X.b0 + slice, i, tid);
 }

@@ -101,6 +101,17 @@ def load_codebooks(cb_path, scl_cb_path, bl_cb_path=None, bl_scl_cb_path=None):
 
 
 _single = {}
+_stages = {}
+
+
+def vq_file_stages(path):
+    """number of stages in a VQ codebook file, cached by (path, mtime) like the parsed books (Wavernn.encoder asks on
+    every call which route a below-threshold book takes)"""
+    k = _key(path)
+    if k not in _stages:
+        _stages[k] = len(read_vq_file(path))
+    return _stages[k]
+
 
 
 def _single_vq(cb_path):

@@ -176,15 +176,23 @@ class Wavernn:
         if self._h is not None:
             _lib.check(_lib.lib().fpc_predictor_status(self._h), "fpc_predictor_status")
 
+    def fallback_groups(self):
+        """groups of 16 utterances of the last weights-stationary launch that were served by the row-split fallback because
+        their 32 workgroups could not all become resident (a busy or shared GPU); synchronises (fpcodec.h)"""
+        n = _lib.lib().fpc_predictor_fallback_groups(self._handle())
+        if n < 0:
+            _lib.check(n, "fpc_predictor_fallback_groups")
+        return n
+
     def set_split(self, n):
         """workgroups per utterance: 0 automatic (the process owns the GPU), 1 never split (shared GPU), 2 / 4 / 8"""
         _lib.check(_lib.lib().fpc_predictor_set_split(self._handle(), int(n)), "fpc_predictor_set_split")
 
     def _encoder_host_loop(self, cfg, feat, mask, l1, l2, vq_quantize, scl_quantize, qtz):
         """The reference's loop (wavernn.py:192-252) frame by frame for the cases the fused kernels do not cover:
-        quantizer callables that are not this package's own (:165), the input-mask mode (:209-211, `mask` of shape
-        (B, L, 2, 1): `mask[:, i, 0]` must index like the thresholds' (B, 1) indicator), and a below-threshold VQ file
-        with more than one stage (:235-240).  The predictor step runs on the device, indicators and the callables on the
+        quantizer callables that are not this package's own (:165) and a below-threshold VQ file with more than one stage
+        (:235-240), either with or without the input mask (:209-211, `mask` of shape (B, L, 2, 1): `mask[:, i, 0]` must
+        index like the thresholds' (B, 1) indicator; with the package's own quantizers the mask rides the fused kernel).  The predictor step runs on the device, indicators and the callables on the
         host with exactly the rows, paths and accumulation of wavernn.py:217-252."""
         dev = self.device
         B, L, Cc = feat.shape
@@ -254,12 +262,12 @@ class Wavernn:
             (scl_quantize is None or scl_quantize is _vq.scl_quantize)
         # the fused kernels code the below-threshold residual with ONE stage (the production file, 1 x 512 x 17); a file with
         # more stages takes the reference's own route: quantize_mstage over all of them (wavernn.py:235-240)
-        lo_stages = len(_vq.read_vq_file(cfg["bl_cb_path"])) if (qtz and cfg.get("bl_cb_path")) else 1
-        if mask is not None or (qtz and not own) or lo_stages > 1:
-            # served frame by frame (wavernn.py:165: the reference calls whatever it is handed; :209-211 the mask mode)
+        lo_stages = _vq.vq_file_stages(cfg["bl_cb_path"]) if (qtz and cfg.get("bl_cb_path")) else 1
+        if (qtz and not own) or lo_stages > 1:
+            # served frame by frame (wavernn.py:165: the reference calls whatever it is handed)
             if return_indices:
-                raise _lib.FpcError("Wavernn.encoder: return_indices needs the fused path (thresholds, the built-in "
-                                    "quantizers, a 1-stage below-threshold book)")
+                raise _lib.FpcError("Wavernn.encoder: return_indices needs the fused path (the built-in quantizers, a "
+                                    "1-stage below-threshold book)")
             if qtz and not own and (vq_quantize is None or scl_quantize is None):
                 raise _lib.FpcError("Wavernn.encoder: pass both vq_quantize and scl_quantize or neither "
                                     "(wavernn.py:219,230 call both)")
@@ -276,6 +284,14 @@ class Wavernn:
         ind1 = torch.empty(B, L, 1, device=dev)
         ind2 = torch.empty(B, L, 1, device=dev)
         idx = torch.empty(B, L, 4, device=dev, dtype=torch.int32)
+        mk = None
+        if mask is not None:  # the input-mask mode (wavernn.py:209-211) rides the fused kernel: fpc_encode's mask_dev
+            mk = torch.as_tensor(mask).to(dev, torch.float32)
+            if mk.dim() == 4:  # (B, L, 2, 1): the shape the reference's indexing needs (mask[:, i, 0] must be (B, 1))
+                mk = mk.squeeze(-1)
+            if tuple(mk.shape) != (B, L, 2):
+                raise _lib.FpcError(f"Wavernn.encoder: mask of shape {tuple(mask.shape)}; (B, L, 2) or (B, L, 2, 1) expected")
+            mk = mk.contiguous()
         cb = None
         hist = None
         if qtz:
@@ -286,7 +302,7 @@ class Wavernn:
             h, cb.handle if cb else None, feat.data_ptr(), B, L, float(l1), float(l2), int(bool(qtz)),
             c_in.data_ptr(), r.data_ptr(), r_qtz.data_ptr(), r_under.data_ptr(), ind1.data_ptr(),
             ind2.data_ptr(), idx.data_ptr(), hist.data_ptr() if hist is not None else None,
-            _lib.stream_ptr()), "fpc_encode")
+            mk.data_ptr() if mk is not None else None, _lib.stream_ptr()), "fpc_encode")
         if qtz:
             cb_tot = cb.split_hist(hist.cpu().numpy().astype(np.float64))  # (synchronises: the launch has reported)
             self.check()

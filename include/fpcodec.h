@@ -25,7 +25,10 @@
 extern "C" {
 #endif
 
-#define FPC_ABI_VERSION 1
+/* 2: fpc_encode takes the input mask (mask_dev, NULL = thresholds); exports fpc_build_info, fpc_lpcnet_set_chunk_frames
+ *    (fpc_lpcnet_workspace_bytes follows the handle's chunk setting).  A binding compares fpc_abi_version() with the
+ *    FPC_ABI_VERSION it was written against BEFORE any other call: the symbol sets of versions differ. */
+#define FPC_ABI_VERSION 2
 #define FPC_API __attribute__((visibility("default")))
 
 typedef enum {
@@ -129,6 +132,10 @@ FPC_API void fpc_predictor_destroy(fpc_predictor* p);
  * row-split exchange gave up) or FPC_ERR_NONFINITE (a NaN / infinite residual reached a quantizer in fpc_encode: those
  * frames carry the symbols -2 and were not searched); clears the condition. */
 FPC_API int fpc_predictor_status(fpc_predictor* p);
+/* Diagnostic: how many groups of 16 utterances of the handle's LAST weights-stationary launch could not get their 32
+ * workgroups resident within the bound and were served by the row-split launch behind it ("Kernel forms" below: correct
+ * either way, slower).  Synchronises the device; >= 0, or a negative fpc_status.  (No reference counterpart.) */
+FPC_API int fpc_predictor_fallback_groups(fpc_predictor* p);
 /* workgroups per utterance: 0 automatic (default), 1 never split, 2 / 4 / 8 exactly that many when the shape allows */
 FPC_API int fpc_predictor_set_split(fpc_predictor* p, int n);
 
@@ -158,7 +165,7 @@ FPC_API void fpc_codebooks_destroy(fpc_codebooks* c);
  * codebooks contribute zero-length segments. */
 FPC_API int fpc_codebooks_hist_size(const fpc_codebooks* c);
 
-/* Wavernn.encoder (wavernn.py:165-256), mask=None.  Device pointers.
+/* Wavernn.encoder (wavernn.py:165-256).  Device pointers.
  *   feat   [B,L,20]   normalised features (cepstrum/24.1, pitch/24.1)
  *   c_in   [B,L,20]   = reference c_in[:,1:,:]
  *   r, r_qtz, r_under [B,L,18]
@@ -167,11 +174,17 @@ FPC_API int fpc_codebooks_hist_size(const fpc_codebooks* c);
  *                     -1 where not coded; scalar idx is offset by +n_hi when it
  *                     came from the below-threshold scalar codebook. May be NULL.
  *   hist   see above; ADDED to (caller zeroes). May be NULL.
+ *   mask   [B,L,2]    float, or NULL.  NULL: the thresholds l1 / l2 decide per frame what is coded with the
+ *                     above-threshold books (wavernn.py:201-207).  Not NULL: the input-mask mode (wavernn.py:209-211) --
+ *                     mask[b,i,0] != 0 selects the above-threshold scalar book for c0, mask[b,i,1] != 0 the
+ *                     above-threshold VQ for c1..c17 (`if ind1[k,0]`, :218), l1 / l2 are ignored, ind1 / ind2 are
+ *                     written as zeros (the reference fills them from the thresholds only) and, with qtz=0, r and
+ *                     r_under are the products with the mask's own values (r_s * mask, r_s * (1 - mask), :245-249).
  * qtz=0 reproduces the un-quantised branch (wavernn.py:244-252); cb may then be NULL. */
 FPC_API int fpc_encode(fpc_predictor* p, const fpc_codebooks* cb, const float* feat_dev, int B, int L,
                float l1, float l2, int qtz, float* c_in_dev, float* r_dev, float* r_qtz_dev,
                float* r_under_dev, float* ind1_dev, float* ind2_dev, int32_t* idx_dev,
-               unsigned long long* hist_dev, fpc_stream s);
+               unsigned long long* hist_dev, const float* mask_dev, fpc_stream s);
 
 /* Receiver side of fpc_encode (the reference's own Wavernn.decoder, wavernn.py:367-379,
  * is dead code): rebuilds c_in [B,L,20] from the symbols alone -- idx [B,L,4] exactly as fpc_encode wrote

@@ -15,14 +15,20 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = None
 
 
+def _san():
+    # FPC_ORACLE_SAN=1: the sanitizer build (make SAN=1); the process must have been started with the ASan runtime
+    # preloaded (tests/test_oracle_sanitized.py does that for a child pytest)
+    return os.environ.get("FPC_ORACLE_SAN") == "1"
+
+
 def build():
-    subprocess.check_call(["make", "-s", "-C", _HERE])
+    subprocess.check_call(["make", "-s", "-C", _HERE] + (["SAN=1"] if _san() else []))
 
 
 def lib():
     global _LIB
     if _LIB is None:
-        path = os.path.join(_HERE, "libfpc_oracle.so")
+        path = os.path.join(_HERE, "libfpc_oracle_san.so" if _san() else "libfpc_oracle.so")
         if not os.path.exists(path):
             build()
         _LIB = C.CDLL(path)

@@ -103,7 +103,8 @@ def test_predictor_other_dimensions_bit_identical_to_oracle(torch_cuda, synth, o
     """the predictor kernels are generic in the layer sizes (in <= 64, gru_units1 <= 512, gru_units2 <= 256, fc <= 32): forward
     incl. carried states at five other shapes -- different segment counts per row (1, 2, 4), the input product from its LDS
     copy or streamed, row quads that do not fill a wave -- and the closed-loop encoder at the shapes it supports (20 inputs, 18
-    outputs), against the CPU oracle bit for bit, on 1 / 2 / 4 workgroups per utterance, in both kernel forms"""
+    outputs), against the CPU oracle bit for bit, on 1 / 2 / 4 workgroups per utterance (the row-split two-role kernels: the
+    generic-shape family)"""
     from fpcodec_amd.wavernn import Wavernn
     torch = torch_cuda
     c = synth.codebooks()
@@ -126,24 +127,19 @@ def test_predictor_other_dimensions_bit_identical_to_oracle(torch_cuda, synth, o
         m = Wavernn(inf, h1, h2, fc)
         m.load_state_dict(sd)
         x = torch.from_numpy(feat).cuda()
-        for df in ("1", "0"):
-            for n in ("0", "2", "4"):
-                if int(n) and (h1 % (4 * int(n)) or h2 % (4 * int(n))):
-                    continue
-                monkeypatch.setenv("FPC_PRED_SPLIT", n)
-                if df == "0":
-                    monkeypatch.setenv("FPC_PRED_DF", "0")
-                else:
-                    monkeypatch.delenv("FPC_PRED_DF", raising=False)
-                y, a, b = m.forward(x)
-                y2, a2, b2 = m.forward(x[:, :4].contiguous(), a, b)
-                for got, ref in ((y, y0), (a, a0), (b, b0), (y2, y1), (a2, a1), (b2, b1)):
-                    assert np.array_equal(got.cpu().numpy().reshape(ref.shape), ref), (dims, df, n)
-                if enc0 is not None:
-                    out = m.encoder(cfg, x, None, 0.09, 0.28, qtz=True, return_indices=True)
-                    assert np.array_equal(out[7].cpu().numpy(), enc0["idx"]), (dims, df, n)
-                    for k, v in (("c_in", out[0]), ("r", out[1]), ("r_qtz", out[2])):
-                        assert np.array_equal(v.cpu().numpy(), enc0[k]), (dims, df, n, k)
+        for n in ("0", "2", "4"):
+            if int(n) and (h1 % (4 * int(n)) or h2 % (4 * int(n))):
+                continue
+            monkeypatch.setenv("FPC_PRED_SPLIT", n)
+            y, a, b = m.forward(x)
+            y2, a2, b2 = m.forward(x[:, :4].contiguous(), a, b)
+            for got, ref in ((y, y0), (a, a0), (b, b0), (y2, y1), (a2, a1), (b2, b1)):
+                assert np.array_equal(got.cpu().numpy().reshape(ref.shape), ref), (dims, n)
+            if enc0 is not None:
+                out = m.encoder(cfg, x, None, 0.09, 0.28, qtz=True, return_indices=True)
+                assert np.array_equal(out[7].cpu().numpy(), enc0["idx"]), (dims, n)
+                for k, v in (("c_in", out[0]), ("r", out[1]), ("r_qtz", out[2])):
+                    assert np.array_equal(v.cpu().numpy(), enc0[k]), (dims, n, k)
 
 
 def test_quantizers_vs_golden(torch_cuda, synth, golden, cb_paths):
@@ -767,11 +763,11 @@ def test_predictor_row_split_equals_single_workgroup_form(torch_cuda, model, syn
                 assert np.array_equal(a, b), (B, L, mode)
 
 
-def test_predictor_two_roles_equal_phase_form(torch_cuda, model, synth, cb_paths, monkeypatch):
-    """the shipped two-role kernels (csrc/predictor_df.h: three waves walk the frame's latency chain, six stream the next
-    frame's recurrent products, LDS counters instead of workgroup barriers) against the phase-after-phase kernels
-    (FPC_PRED_DF=0, one workgroup per utterance): forward incl. carried states, encoder with and without quantisation incl.
-    symbols and histograms, receiver -- bit for bit at 1 / 7 / 128 / 200 utterances on 1, 2, 4 and 8 workgroups each
+def test_row_split_forms_equal_oracle_and_each_other(torch_cuda, model, synth, oracle, cb_paths, monkeypatch):
+    """the generic-shape family (csrc/predictor_df.h: three waves walk the frame's latency chain, the others stream the next
+    frame's recurrent products, LDS counters instead of workgroup barriers) on 1, 2, 4 and 8 workgroups per utterance:
+    forward incl. carried states, encoder with and without quantisation incl. symbols and histograms, receiver -- against
+    the CPU oracle at 7 utterances and against the one-workgroup form bit for bit at 1 / 7 / 128 / 200 utterances
     (1 workgroup: the input product streams from L2; 2-8: from its LDS copy)"""
     torch = torch_cuda
     cfg = dict(scl_cb_path=cb_paths["scl_hi"], cb_path=cb_paths["vq_hi"], bl_scl_cb_path=cb_paths["scl_lo"],
@@ -787,14 +783,22 @@ def test_predictor_two_roles_equal_phase_form(torch_cuda, model, synth, cb_paths
         return ([t.cpu().numpy() for t in (y, h1, h2, y2, h1b, h2b)] + [t.cpu().numpy() for t in enc[:6]] + list(enc[6]) +
                 [enc[7].cpu().numpy()] + [t.cpu().numpy() for t in enc2[:6]] + [dec.cpu().numpy()])
 
+    c = synth.codebooks()
+    CB = oracle.Codebooks(c["vq_hi"], c["scl_hi"], c["vq_lo"], c["scl_lo"])
+    P = oracle.Predictor(synth.predictor_state_dict())
     for B, L in ((1, 30), (7, 40), (128, 60), (200, 20)):
-        feat = torch.from_numpy(synth.predictor_features(B, L, utt0=7000)).cuda()
+        f = synth.predictor_features(B, L, utt0=7000)
+        feat = torch.from_numpy(f).cuda()
         monkeypatch.setenv("FPC_PRED_SPLIT", "0")
-        monkeypatch.setenv("FPC_PRED_DF", "0")
         ref = run(feat)
-        monkeypatch.delenv("FPC_PRED_DF")
-        for n in ("0", "2", "4", "8"):
-            if B * max(int(n), 1) > 512:
+        if B == 7:
+            y0, a0, b0 = P.forward(f)
+            o = P.encode(f, CB, 0.09, 0.28, True)
+            assert np.array_equal(ref[0], y0) and np.array_equal(ref[1].reshape(a0.shape), a0)
+            assert np.array_equal(ref[6], o["c_in"]) and np.array_equal(ref[8], o["r_qtz"]) and np.array_equal(ref[17], o["idx"])
+            assert np.array_equal(ref[-1], o["c_in"])  # the receiver closes the loop
+        for n in ("2", "4", "8"):
+            if B * int(n) > 512:
                 continue
             monkeypatch.setenv("FPC_PRED_SPLIT", n)
             got = run(feat)
@@ -839,21 +843,17 @@ def test_predictor_row_split_under_uneven_load(torch_cuda, model, vocoder, synth
 def test_train_step_row_split_equals_single_workgroup_form(torch_cuda, synth, monkeypatch):
     """the training step with forward and backward on 2 / 4 / 8 workgroups per utterance (slices of the states and of the
     back-propagated vectors exchanged as granules) against one workgroup per utterance: losses, every gradient and the
-    parameters after two steps, bit for bit -- with the forward as the shipped two-role kernel and (modes "p0", "p2":
-    FPC_PRED_DF=0) as the phase kernel, and (mode "ws", the default) on the weights-stationary kernel"""
+    parameters after two steps, bit for bit -- with the forward as the two-role row-split kernel and (mode "ws", the default)
+    on the weights-stationary kernels"""
     from fpcodec_amd.train_frame import Trainer
     from fpcodec_amd.wavernn import Wavernn
     feat = synth.predictor_features(6, 40, utt0=4200)
     out = {}
-    for mode in ("0", "2", "4", "8", "p0", "p2", "ws"):
-        if mode == "ws":  # the shipped default: the forward on the weights-stationary kernel (one part-filled group of 16)
+    for mode in ("0", "2", "4", "8", "ws"):
+        if mode == "ws":  # the shipped default: the weights-stationary kernels (one part-filled group of 16)
             monkeypatch.delenv("FPC_PRED_SPLIT", raising=False)
         else:
-            monkeypatch.setenv("FPC_PRED_SPLIT", mode[-1])
-        if mode[0] == "p":
-            monkeypatch.setenv("FPC_PRED_DF", "0")
-        else:
-            monkeypatch.delenv("FPC_PRED_DF", raising=False)
+            monkeypatch.setenv("FPC_PRED_SPLIT", mode)
         m = Wavernn(20, 384, 128, 18)
         m.load_state_dict(synth.predictor_state_dict())
         tr = Trainer(m, lr=1e-3, max_batch=6, max_frames=40)
@@ -862,14 +862,14 @@ def test_train_step_row_split_equals_single_workgroup_form(torch_cuda, synth, mo
         l1 = tr.step(feat)
         sd = m.state_dict()
         out[mode] = ([np.float32(l0), np.float32(l1)] + [g[k] for k in sorted(g)] + [sd[k].numpy() for k in sorted(sd)])
-    for mode in ("2", "4", "8", "p0", "p2", "ws"):
+    for mode in ("2", "4", "8", "ws"):
         for a, b in zip(out["0"], out[mode]):
             assert not np.isnan(b).any() and np.array_equal(a, b), mode
 
 
-@pytest.mark.parametrize("two_roles", ["1", "0"])
-def test_row_split_timeout_is_an_error_not_garbage(torch_cuda, synth, cb_paths, monkeypatch, two_roles):
-    """(both kernel forms: the shipped two-role kernels and, FPC_PRED_DF=0, the phase kernels)
+@pytest.mark.parametrize("hop", ["fast", "general"])
+def test_row_split_timeout_is_an_error_not_garbage(torch_cuda, synth, cb_paths, monkeypatch, hop):
+    """(both exchange paths of the row-split kernels: plain stores on one XCD and, FPC_FAST_HOP=0, write-through)
     a row-split exchange that gives up must fail loudly at the ABI (round-2 review item 3): with the test hooks
     (FPC_TEST_WITHHOLD_PUBLISH: the last slice of utterance 0 never publishes; FPC_SPIN_LIMIT_US: 20 ms instead of 1 s)
     the partner's spin times out ONCE, deterministically.  The asynchronous entry point itself returns FPC_OK; the
@@ -888,9 +888,7 @@ def test_row_split_timeout_is_an_error_not_garbage(torch_cuda, synth, cb_paths, 
     B, L = 2, 30
     feat = torch.from_numpy(synth.predictor_features(B, L, utt0=5100)).cuda()
     monkeypatch.setenv("FPC_PRED_SPLIT", "2")
-    if two_roles == "0":
-        monkeypatch.setenv("FPC_PRED_DF", "0")
-    if two_roles == "general_hop":  # the two-role kernels on the write-through exchange
+    if hop == "general":  # the write-through exchange
         monkeypatch.setenv("FPC_FAST_HOP", "0")
     good = m.encoder(cfg, feat, None, 0.09, 0.28, qtz=True, return_indices=True)
     yg, _, _ = m.forward(feat)
@@ -905,7 +903,7 @@ def test_row_split_timeout_is_an_error_not_garbage(torch_cuda, synth, cb_paths, 
     monkeypatch.setenv("FPC_TEST_WITHHOLD_PUBLISH", "1")
     monkeypatch.setenv("FPC_SPIN_LIMIT_US", "20000")
     rc = L_.fpc_encode(h, cb.handle, feat.data_ptr(), B, L, 0.09, 0.28, 1, *[b.data_ptr() for b in bufs], idx.data_ptr(),
-                       hist.data_ptr(), _lib.stream_ptr())
+                       hist.data_ptr(), None, _lib.stream_ptr())
     assert rc == 0  # asynchronous: the launch itself is accepted
     torch.cuda.synchronize()
     monkeypatch.delenv("FPC_TEST_WITHHOLD_PUBLISH")
@@ -1153,8 +1151,8 @@ def _ws_cfgs(cb_paths, tmp):
 
 def test_weights_stationary_kernels_equal_row_split_forms(torch_cuda, model, synth, oracle, cb_paths, monkeypatch, tmp_path):
     """the shipped predictor kernels for the production shape (groups of 16 utterances on the 32 workgroups of an XCD, weights
-    resident in LDS, gate rows on f32 MFMA, 16-byte granule hops, the encoder's tail on owner + helper pairs) against the
-    phase-after-phase kernels (FPC_PRED_WS=0, FPC_PRED_DF=0, one workgroup per utterance) and the oracle: forward incl.
+    resident in LDS, gate rows on f32 MFMA, 16-byte granule hops, the encoder's tail distributed over the group) against the
+    generic-shape family (FPC_PRED_WS=0: the two-role row-split kernels, one workgroup per utterance) and the oracle: forward incl.
     carried states, encoder with and without quantisation incl. symbols and histograms, receiver -- bit for bit, for 1 / 7 /
     16 / 33 / 128 / 200 utterances (partly filled groups, two rounds of groups), on BOTH hop paths (FPC_FAST_HOP=0: write-through
     stores, the path a placement on several XCDs takes) and for six codebook configurations (the last two live on the
@@ -1179,22 +1177,16 @@ def test_weights_stationary_kernels_equal_row_split_forms(torch_cuda, model, syn
             cfg = cfgs[name]
             monkeypatch.setenv("FPC_PRED_WS", "0")
             monkeypatch.setenv("FPC_PRED_SPLIT", "0")
-            monkeypatch.setenv("FPC_PRED_DF", "0")
             ref = run(feat, cfg)
             monkeypatch.delenv("FPC_PRED_WS")
             monkeypatch.delenv("FPC_PRED_SPLIT")
-            monkeypatch.delenv("FPC_PRED_DF")
-            # the encoder's tail in both forms: distributed over the group's 32 workgroups (the shipped one), and on the
-            # utterance's own pair of workgroups (FPC_WS_TAIL=pair)
-            for fast, tail in (("1", ""), ("0", ""), ("1", "pair"), ("0", "pair")):
+            for fast in ("1", "0"):
                 monkeypatch.setenv("FPC_FAST_HOP", fast)
-                monkeypatch.setenv("FPC_WS_TAIL", tail)
                 got = run(feat, cfg)
                 assert len(got) == len(ref)
                 for k, (a, b) in enumerate(zip(ref, got)):
-                    assert np.array_equal(a, b), (B, L, name, fast, tail, k)
+                    assert np.array_equal(a, b), (B, L, name, fast, k)
             monkeypatch.delenv("FPC_FAST_HOP")
-            monkeypatch.delenv("FPC_WS_TAIL")
     # ... and the oracle itself (one partly filled group, the reference's four codebooks)
     feat = synth.predictor_features(5, 50, utt0=7100)
     c = synth.codebooks()
@@ -1245,7 +1237,7 @@ def test_weights_stationary_timeout_is_an_error_not_garbage(torch_cuda, synth, c
     hist = torch.zeros(cb.hist_size, device="cuda", dtype=torch.int64)
     assert L_.fpc_predictor_status(m._handle()) in (0, -5)  # (whatever the failed decode left: cleared)
     rc = L_.fpc_encode(m._handle(), cb.handle, feat.data_ptr(), B, L, 0.09, 0.28, 1, *[b.data_ptr() for b in bufs],
-                       idx.data_ptr(), hist.data_ptr(), _lib.stream_ptr())
+                       idx.data_ptr(), hist.data_ptr(), None, _lib.stream_ptr())
     assert rc == 0
     torch.cuda.synchronize()
     assert torch.isnan(bufs[0][:16]).all() and torch.isnan(bufs[1][:16]).all() and (idx[:16] == -2).all()
@@ -1261,6 +1253,90 @@ def test_weights_stationary_timeout_is_an_error_not_garbage(torch_cuda, synth, c
     for a, b in zip(good[:6] + (good[7], yg, dg), again[:6] + (again[7], ya, da)):
         assert torch.equal(a, b)
     for a, b in zip(good[6], again[6]):
+        assert np.array_equal(a, b)
+
+
+def test_ws_group_that_cannot_become_resident_falls_back_not_fails(torch_cuda, model, synth, cb_paths, monkeypatch):
+    """the co-residency assumption of the weights-stationary kernels fails SAFE (fpcodec.h "Kernel forms"): with the test hook
+    FPC_TEST_WITHHOLD_PUBLISH=hello the last workgroup of group 0 stands for one that never becomes resident -- its 31
+    partners run out of patience (FPC_HELLO_LIMIT_US: 3 ms instead of 10), the group decides WS_FALLBACK, every workgroup of
+    it returns before anything is written, and the row-split launch queued behind serves exactly that group: forward incl.
+    carried states, encoder incl. symbols and histograms, receiver and two training steps are bit-identical to the quiet
+    run, nothing raises, and the diagnostic counts one group (of two) -- group 1 stays on the weights-stationary kernels"""
+    from fpcodec_amd.train_frame import Trainer
+    from fpcodec_amd.wavernn import Wavernn
+    torch = torch_cuda
+    cfg = dict(scl_cb_path=cb_paths["scl_hi"], cb_path=cb_paths["vq_hi"], bl_scl_cb_path=cb_paths["scl_lo"],
+               bl_cb_path=cb_paths["vq_lo"])
+    B, L = 20, 30
+    f = synth.predictor_features(B, L, utt0=7300)
+    feat = torch.from_numpy(f).cuda()
+
+    def run():
+        y, h1, h2 = model.forward(feat)
+        nfb = [model.fallback_groups()]
+        y2, h1b, h2b = model.forward(feat[:, :5], h1, h2)
+        enc = model.encoder(cfg, feat, None, 0.09, 0.28, qtz=True, return_indices=True)
+        nfb.append(model.fallback_groups())
+        dec = model.decode_indices(cfg, enc[7], feat[:, :, 18:].contiguous())
+        nfb.append(model.fallback_groups())
+        m = Wavernn(20, 384, 128, 18)
+        m.load_state_dict(synth.predictor_state_dict())
+        tr = Trainer(m, lr=1e-3, max_batch=B, max_frames=L)
+        losses = [tr.step(f), tr.step(f)]
+        nfb.append(m.fallback_groups())
+        sd = m.state_dict()
+        return ([t.cpu().numpy() for t in (y, h1, h2, y2, h1b, h2b)] + [t.cpu().numpy() for t in enc[:6]] + list(enc[6]) +
+                [enc[7].cpu().numpy(), dec.cpu().numpy(), np.float32(losses)] + [sd[k].numpy() for k in sorted(sd)]), nfb
+
+    quiet, n0 = run()
+    assert n0 == [0, 0, 0, 0]
+    monkeypatch.setenv("FPC_TEST_WITHHOLD_PUBLISH", "hello")
+    monkeypatch.setenv("FPC_HELLO_LIMIT_US", "3000")
+    for fast in ("1", "0"):
+        monkeypatch.setenv("FPC_FAST_HOP", fast)
+        busy, n1 = run()
+        model.check()  # nothing was reported: a fallback is not a failure
+        assert n1 == [1, 1, 1, 1], n1
+        assert len(busy) == len(quiet)
+        for k, (a, b) in enumerate(zip(quiet, busy)):
+            assert np.array_equal(a, b), (fast, k)
+
+
+def test_encode_beside_the_librarys_own_long_decode(torch_cuda, model, vocoder, synth, oracle, cb_paths, monkeypatch):
+    """the pipeline the package itself suggests -- encode batch k + 1 while batch k is being decoded on a side stream: a
+    200-stream vocoder launch holds 200 of the 256 CUs for ~35 ms, far longer than the give-up bounds (shortened to 2 ms /
+    4 ms by the hooks), so an fpc_encode of 128 utterances issued beside it gets 7 of each group's 32 workgroups placed.  It
+    must return the quiet run's bits -- not FPC_ERR_TIMEOUT, not NaN -- by deciding for the fallback (round-4 review item 5)"""
+    import time
+    torch = torch_cuda
+    voc, w = vocoder
+    cfg = dict(scl_cb_path=cb_paths["scl_hi"], cb_path=cb_paths["vq_hi"], bl_scl_cb_path=cb_paths["scl_lo"],
+               bl_cb_path=cb_paths["vq_lo"])
+    B, L = 128, 40
+    feat = torch.from_numpy(synth.predictor_features(B, L, utt0=7400)).cuda()
+    quiet = model.encoder(cfg, feat, None, 0.09, 0.28, qtz=True, return_indices=True)
+    assert model.fallback_groups() == 0
+    T = 150
+    vf = torch.from_numpy(np.tile(_voc_features(synth, oracle, 4, T), (50, 1, 1)).copy()).cuda()
+    sd = torch.from_numpy(synth.seeds(200).astype(np.int64)).cuda()
+    pcm = torch.empty(200, T * 160, dtype=torch.int16, device="cuda")
+    voc.synthesize(vf, sd, out=pcm)  # (warm: workspace allocated)
+    torch.cuda.synchronize()
+    monkeypatch.setenv("FPC_HELLO_LIMIT_US", "2000")
+    monkeypatch.setenv("FPC_SPIN_LIMIT_US", "4000")
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        voc.synthesize(vf, sd, out=pcm)
+    time.sleep(0.004)  # the decode kernel is on the chip by now (its frame-rate kernels take < 1 ms)
+    busy = model.encoder(cfg, feat, None, 0.09, 0.28, qtz=True, return_indices=True)  # (raises on any reported failure)
+    nfb = model.fallback_groups()
+    torch.cuda.synchronize()
+    model.check()
+    assert nfb > 0, "the decode did not crowd the encoder out: the test exercised nothing"
+    for a, b in zip(quiet[:6] + (quiet[7],), busy[:6] + (busy[7],)):
+        assert torch.equal(a, b)
+    for a, b in zip(quiet[6], busy[6]):
         assert np.array_equal(a, b)
 
 
@@ -1309,14 +1385,14 @@ def test_trainer_step_that_gives_up_updates_nothing_and_the_count_follows(torch_
         assert np.array_equal(v.numpy(), ref[k]), k
 
 
-def test_encoder_mask_mode_and_multi_stage_lo_vs_reference_golden(torch_cuda, model, cb_paths, tmp_path):
-    """the two reference behaviours the fused kernels do not cover, served by the host loop of Wavernn.encoder (predictor step
-    and searches on the device, one frame at a time) against golden G12, generated by tests/golden/make_golden_modes.py from
-    the reference's own `encoder`: the input-mask mode (wavernn.py:209-211) with and without quantisation, and a 2-stage
-    below-threshold codebook (wavernn.py:235-240: quantize_mstage over both stages, cb_tot[4] += the last stage's histogram)"""
+def test_encoder_mask_mode_and_multi_stage_lo_vs_reference_golden(torch_cuda, model, cb_paths, tmp_path, monkeypatch):
+    """golden G12, generated by tests/golden/make_golden_modes.py from the reference's own `encoder`: the input-mask mode
+    (wavernn.py:209-211) with and without quantisation -- on the fused kernels through fpc_encode's mask_dev (ABI 2), in both
+    kernel families (weights-stationary and, FPC_PRED_WS=0, row-split: same bits), and through the host loop that serves
+    injected quantizer callables -- and a 2-stage below-threshold codebook (wavernn.py:235-240: quantize_mstage over both
+    stages, cb_tot[4] += the last stage's histogram; host loop)"""
     torch = torch_cuda
-    import sys
-    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    from fpcodec_amd import vq_func
     g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "g12_encoder_modes.npz"))
     import fpcodec_amd
     synth = fpcodec_amd.synth
@@ -1328,14 +1404,35 @@ def test_encoder_mask_mode_and_multi_stage_lo_vs_reference_golden(torch_cuda, mo
     np.save(p_lo2, lo2)
     cfg = dict(scl_cb_path=cb_paths["scl_hi"], cb_path=cb_paths["vq_hi"], bl_scl_cb_path=cb_paths["scl_lo"],
                bl_cb_path=cb_paths["vq_lo"])
-    runs = {"mask_qtz": (cfg, mask, True), "mask_raw": (cfg, mask, False), "lo2": (dict(cfg, bl_cb_path=p_lo2), None, True)}
-    for tag, (c, m, qtz) in runs.items():
-        out = model.encoder(c, torch.from_numpy(feat), None if m is None else torch.from_numpy(m), 0.09, 0.28, qtz=qtz)
-        for n, v in zip(["c_in", "r", "r_qtz", "r_under"], out[:4]):
-            assert np.abs(v.cpu().numpy() - g[f"{tag}_{n}"]).max() <= 1e-5, (tag, n)  # the north_star's tolerance
-        for n, v in zip(["ind1", "ind2"], out[4:6]):
-            assert np.array_equal(v.cpu().numpy(), g[f"{tag}_{n}"]), (tag, n)
-        for i, h in enumerate(out[6]):
-            assert np.array_equal(np.asarray(h, dtype=np.float64), g[f"{tag}_hist{i}"]), (tag, i)  # symbols: exact
+    wrapped = dict(vq_quantize=lambda r, p: vq_func.vq_quantize(r, p), scl_quantize=lambda d, p: vq_func.scl_quantize(d, p))
+    runs = {"mask_qtz": (cfg, mask, True, {}), "mask_raw": (cfg, mask, False, {}), "lo2": (dict(cfg, bl_cb_path=p_lo2), None, True, {}),
+            "mask_qtz/host loop": (cfg, mask, True, wrapped), "mask_qtz/(B, L, 2)": (cfg, mask[..., 0], True, {})}
+    fused = {}
+    for name, (c, m, qtz, kw) in runs.items():
+        tag = name.split("/")[0]
+        for ws in ("1", "0"):
+            if ws == "0":
+                if name in ("lo2", "mask_qtz/host loop"):
+                    continue
+                monkeypatch.setenv("FPC_PRED_WS", "0")
+            out = model.encoder(c, torch.from_numpy(feat), None if m is None else torch.from_numpy(m), 0.09, 0.28, qtz=qtz, **kw)
+            monkeypatch.delenv("FPC_PRED_WS", raising=False)
+            for n, v in zip(["c_in", "r", "r_qtz", "r_under"], out[:4]):
+                assert np.abs(v.cpu().numpy() - g[f"{tag}_{n}"]).max() <= 1e-5, (name, ws, n)  # the north_star's tolerance
+            for n, v in zip(["ind1", "ind2"], out[4:6]):
+                assert np.array_equal(v.cpu().numpy().reshape(g[f"{tag}_{n}"].shape), g[f"{tag}_{n}"]), (name, ws, n)
+            for i, h in enumerate(out[6]):
+                assert np.array_equal(np.asarray(h, dtype=np.float64), g[f"{tag}_hist{i}"]), (name, ws, i)  # symbols: exact
+            if name in ("mask_qtz", "mask_raw"):  # the two kernel families agree bit for bit
+                got = [v.cpu().numpy() for v in out[:6]]
+                if ws == "1":
+                    fused[name] = got
+                else:
+                    for a, b in zip(fused[name], got):
+                        assert np.array_equal(a, b), (name, "ws vs row split")
     # the mask mode leaves the indicator outputs at zero (the reference only fills them from the thresholds)
     assert not g["mask_qtz_ind1"].any() and g["lo2_ind1"].any()
+    # a mask of the wrong shape is refused, not reinterpreted
+    from fpcodec_amd._lib import FpcError
+    with pytest.raises(FpcError, match="mask of shape"):
+        model.encoder(cfg, torch.from_numpy(feat), torch.zeros(3, 30), 0.09, 0.28)

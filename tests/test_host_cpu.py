@@ -29,9 +29,24 @@ def test_abi_exports_every_declared_symbol(built):
     L = built.lib()
     for s in declared:
         assert hasattr(L, s), s
-    assert L.fpc_abi_version() == 1
+    m = re.search(r"#define FPC_ABI_VERSION (\d+)", hdr)
+    assert m and L.fpc_abi_version() == int(m.group(1)) == built.ABI_VERSION == 2
     # the shipped library is built without -D tunables and says so (a variant build lists them: tools/build_variant.sh)
-    assert L.fpc_build_info() == b"fpcodec abi 1 gfx950"
+    assert L.fpc_build_info() == b"fpcodec abi 2 gfx950"
+
+
+def test_binding_names_a_library_of_another_abi_version(built, tmp_path, monkeypatch):
+    """a library of another ABI version (an older build reached through FPC_LIB_PATH) is refused by VERSION, before any
+    other symbol is looked up: a stand-in .so that exports nothing but fpc_abi_version() = 1"""
+    import subprocess
+    src = tmp_path / "old.c"
+    src.write_text("int fpc_abi_version(void) { return 1; }\n")
+    so = tmp_path / "libold.so"
+    subprocess.check_call(["gcc", "-shared", "-fPIC", "-o", str(so), str(src)])
+    monkeypatch.setattr(built, "LIB_PATH", str(so))
+    monkeypatch.setattr(built, "_lib", None)
+    with pytest.raises(built.FpcError, match="ABI version 1, this binding needs 2"):
+        built.lib()
 
 
 def test_no_cpu_fallback(built):
