@@ -72,6 +72,19 @@ __device__ __forceinline__ bool df_wait(int* s, int target, int* dead) {
     }
     return true;
 }
+// two counters in one poll loop (both loads in flight together: one LDS round trip per round)
+__device__ __forceinline__ bool df_wait2(int* s0, int t0, int* s1, int t1, int* dead) {
+    unsigned spins = 0;
+    for (;;) {
+        const int a = __hip_atomic_load(s0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        const int b = __hip_atomic_load(s1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (a >= t0 && b >= t1) break;
+        if ((++spins & 7u) == 0 && __hip_atomic_load(dead, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0) return false;
+        __builtin_amdgcn_s_sleep(1);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    return true;
+}
 // barrier of the foreground waves only
 __device__ __forceinline__ void fg_sync(DfLds& L, int& fg_epoch) {
     ++fg_epoch;

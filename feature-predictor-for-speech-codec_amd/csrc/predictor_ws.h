@@ -36,6 +36,9 @@
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4ws __attribute__((ext_vector_type(4)));
 
+#ifndef FPC_WS_A_SPLIT
+#define FPC_WS_A_SPLIT 0  // the teacher-forced forward's A(t+1): first unit's chain beside C(t), the rest behind it (ws_A)
+#endif
 #ifndef FPC_WS_POLL_DELAY
 #define FPC_WS_POLL_DELAY 0  // x 64 cycles before the first poll of a hop
 #endif
@@ -47,12 +50,19 @@ constexpr int WV1 = WU1 * WG, WV2 = WU2 * WG;    // state values per workgroup a
 constexpr int WQ1 = WV1 / 3, WQ2 = (WV2 + 2) / 3;  // 16-byte granules per workgroup and hop: 64, 22
 constexpr int WQX = WFC / 3;                     // granules of an utterance's next input row (hop 3): 6
 constexpr int WFG = 4, WBG = 4;                  // waves per role
+constexpr int W1G = WIN * WU1 + 20;                // pitch of a gate's block of W1i in LDS
+constexpr int WPF = 20;                          // pitch of an utterance's 18 output rows in pFa (16-byte stores, 8 lanes: 8 bank quads)
 constexpr int WFGT = WFG * 64;
 // granule block of a group, in 16-byte units: hello | h1 | h2 | next input (the receiver's third hop)
-constexpr int WOFF_HELLO = 0, WOFF_H1 = WNS, WOFF_H2 = WOFF_H1 + WNS * WQ1, WOFF_X = WOFF_H2 + WNS * WQ2,
+// (the state hops have TWO granule sets each, used by frame parity: a workgroup publishes h1(t+1) once its gather of h1(t) is
+//  complete, i.e. once every partner has published h1(t) -- which a partner does only with h1(t-1) whole in its LDS: the set
+//  of parity t+1 is free.  Likewise h2(t+1) follows the own gather of h2(t), the partners' h2(t) their gather of h2(t-1).
+//  With ONE set the publish of a frame had to wait for the previous frame's OTHER hop to prove that, which put hop 2 on the
+//  teacher-forced forward's loop although nothing on that loop needs h2: profiles/r05_ablations.txt)
+constexpr int WOFF_HELLO = 0, WOFF_H1 = WNS, WOFF_H2 = WOFF_H1 + 2 * WNS * WQ1, WOFF_X = WOFF_H2 + 2 * WNS * WQ2,
               // | the distributed searches' results [utterance][workgroup][5], first and second stage (predictor_wsd.h)
               WOFF_G1 = WOFF_X + WG * WQX, WOFF_G2 = WOFF_G1 + WG * WNS * SURV,
-              WGRANULES = WOFF_G2 + WG * WNS * SURV;  // 8 000 granules = 128 000 bytes
+              WGRANULES = WOFF_G2 + WG * WNS * SURV;  // 10 752 granules = 172 032 bytes
 static_assert(NT == 512, "predictor_ws.h is written for 8 waves per workgroup");
 static_assert(WH1 / 4 == 96 && WH2 / 2 == 64 && WFC == NDIM + 1, "production shape");
 enum { WSIG_A = 0, WSIG_B, WSIG_H1, WSIG_H2, WSIG_P1, WSIG_P2, WSIG_C, WSIG_I, WSIG_X, WSIG_FG, WSIG_FB, WNSIG };
@@ -69,29 +79,34 @@ struct WsArgs {
 };
 
 struct __attribute__((aligned(16))) WsLds : SearchLds {
-    float x[WIN * WG];        // state images [k][utterance]
+    float x[WIN * WG];        // input image [k][utterance, swizzled: ws_xi]; state images [k][utterance]
     float h1[WH1 * WG];
     float h2[WH2 * WG];
-    float pI[2][3][256];      // segment sums as the MFMA leaves them: [frame parity][gate][unit * 16 + utterance]
+    float pI[2][3][256];      // segment sums as the MFMA leaves them: [frame parity][gate][ws_tile(unit, utterance)]
     float pA[4][3][256];      // [segment][gate][...]
-    float pC[4][256];         // [segment][(gate * 4 + unit) * 16 + utterance]
+    float pC[4][256];         // [segment][ws_tile(gate * 4 + unit, utterance)]
     float pB[2][256];
     float pF[8][2][16];       // [segment][tile][row in tile]: the owned utterance only
     float pFl[2][8][2][16];   // the same for the forward's off-chain output layer, by frame parity
     float fo[WG][WIN];        // predictions [utterance][row < 18]
     float xn[MAX_IN];         // the owner's next input row
-    float w1i[3 * WIN * WU1];  // [gate][k][unit]
+    float w1i[3 * W1G];        // [gate][k][unit], gates 260 floats apart (240: gates 0 and 2 in the same banks for ws_I_own's lanes)
     float w2i[WH1 * 3 * WU2];  // [k / 16][k % 4][gate * 4 + unit][(k % 16) / 4]
     float w2h[WH2 * 3 * WU2];
-    float fcw[WH2 * WFC];      // [k][row]
+    float fcw[WH2 * 16];       // output layer [k][row < 16] (an MFMA tile's B operand: lanes (k % 4, row) read 32 banks)
+    float fcw2[2 * WH2];       // ... rows 16, 17: [row - 16][k] (16-byte reads of four k)
+    float h2own[WH2];          // the owned utterance's column of the h2 image, as it arrives (ws_F / ws_F_late: rows 16, 17)
+    float fcb[WIN];            // ... bias [row < 18]
     int sig[WNSIG];
     int dead;
     int dead_latch;  // the value every thread acts on at the end of a frame (read once, between two barriers)
     int same_xcd;
     int hello;       // the group's decision as this workgroup adopted it (ws_hello)
     // the distributed tail (predictor_wsd.h): every workgroup of a group serves every utterance of the group
-    double cbs[3][WNS][NDIM + 1];  // this workgroup's entries 32 m + slice of the books hi stage 1, hi stage 2, lo
-    float pFa[8][WFC * WG];        // output-layer segment sums of all 16 utterances [segment][row * 16 + utterance]
+    double cbs[3][WNS][NDIM + 1];  // this workgroup's entries 32 m + slice of the books hi stage 1, hi stage 2, lo (18 doubles
+                                   // apart: 16-byte reads of coordinate pairs, conflict-free; 17 apart was measured slower --
+                                   // 17 eight-byte reads per distance instead of 9 reads: profiles/r05_ablations.txt)
+    float pFa[8][WG * WPF];        // output-layer segment sums of all 16 utterances [segment][utterance * 20 + row]
     float rsa[WG][WIN];            // residuals [utterance][row]
     double xs[WG][NDIM + 1];       // first-stage targets
     double xq2[WG][SURV][NDIM + 1];  // second-stage targets
@@ -112,8 +127,11 @@ struct __attribute__((aligned(16))) WsLds : SearchLds {
 #ifdef FPC_WS_PROF_TAIL
 #define WBSTAMP(k)
 #else
+#ifndef FPC_WS_BSTAMP_WAVE
+#define FPC_WS_BSTAMP_WAVE 1
+#endif
 #define WBSTAMP(k)                                           \
-    if (threadIdx.x == WFGT + 64) {                          \
+    if (threadIdx.x == WFGT + 64 * FPC_WS_BSTAMP_WAVE) {     \
         const long long now_ = __builtin_readcyclecounter(); \
         L.wprof[k] += now_ - L.wlast_bg;                     \
         L.wlast_bg = now_;                                   \
@@ -273,7 +291,7 @@ __device__ __forceinline__ void ws_load_weights(const PredDev& P, WsLds& L, WsRe
     const int wave = tid >> 6, lane = tid & 63, c = lane & 15;
     for (int i = tid; i < 3 * WIN * WU1; i += NT) {
         const int g = i / (WIN * WU1), r = i - g * WIN * WU1, k = r / WU1, u = r - k * WU1;
-        L.w1i[i] = P.w1i[(size_t)k * 3 * WH1 + g * WH1 + WU1 * slice + u];
+        L.w1i[g * W1G + r] = P.w1i[(size_t)k * 3 * WH1 + g * WH1 + WU1 * slice + u];
     }
     for (int i = tid; i < WH1 * 12; i += NT) {
         const int k = i / 12, r = i - k * 12, g = r / WU2, u = r - g * WU2;
@@ -283,7 +301,14 @@ __device__ __forceinline__ void ws_load_weights(const PredDev& P, WsLds& L, WsRe
         const int k = i / 12, r = i - k * 12, g = r / WU2, u = r - g * WU2;
         L.w2h[i] = P.w2h[(size_t)k * 3 * WH2 + g * WH2 + WU2 * slice + u];
     }
-    for (int i = tid; i < WH2 * WFC; i += NT) L.fcw[i] = P.fcw[i];
+    for (int i = tid; i < WH2 * WFC; i += NT) {
+        const int k = i / WFC, r = i - k * WFC;
+        if (r < 16)
+            L.fcw[k * 16 + r] = P.fcw[i];
+        else
+            L.fcw2[(r - 16) * WH2 + k] = P.fcw[i];
+    }
+    if (tid < WIN) L.fcb[tid] = tid < WFC ? P.fcb[tid] : 0.0f;
     const int fw = wave, bw = wave - WFG;
     R.bA[0] = R.bA[1] = R.bA[2] = 0.0f;
 #pragma unroll
@@ -293,7 +318,7 @@ __device__ __forceinline__ void ws_load_weights(const PredDev& P, WsLds& L, WsRe
     R.bB = R.bI = R.bIo = R.bC = 0.0f;
     R.bI3[0] = R.bI3[1] = R.bI3[2] = 0.0f;
     R.bF[0] = P.fcb[c];
-    R.bF[1] = P.fcb[16 + (lane & 1)];  // (rows 16, 17 are evaluated by lanes 0-15: row = 16 + (lane & 1))
+    R.bF[1] = P.fcb[16 + (lane & 1)];  // (rows 16, 17 = columns 0, 1 of the second tile; its other columns are dropped)
     R.bF16[0] = P.fcb[16];
     R.bF16[1] = P.fcb[17];
     if (wave >= WFG) {
@@ -340,9 +365,11 @@ __device__ __forceinline__ void ws_load_weights(const PredDev& P, WsLds& L, WsRe
 __device__ __forceinline__ unsigned ws_dec_load(const WsCtx& X) {
     return __hip_atomic_load((gu32*)X.dec, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-__device__ __forceinline__ unsigned ws_dec_try(const WsCtx& X, unsigned want) {  // the decision after this attempt
+__device__ __forceinline__ unsigned ws_dec_try(const WsCtx& X, unsigned want) {  // the decision after this attempt (whole wave)
     unsigned seen = 0u;
-    (void)__hip_atomic_compare_exchange_strong((gu32*)X.dec, &seen, want, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if ((threadIdx.x & 63) == 0)  // ONE compare-and-swap per workgroup (64 lanes' worth on one word took 0.16 ms per launch)
+        (void)__hip_atomic_compare_exchange_strong((gu32*)X.dec, &seen, want, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    seen = (unsigned)__builtin_amdgcn_readfirstlane((int)seen);
     return seen == 0u ? want : seen;
 }
 __device__ __forceinline__ void ws_hello(WsCtx& X, WsLds& L, const WsArgs& S, int tid) {
@@ -413,8 +440,18 @@ __device__ __forceinline__ void ws_hello(WsCtx& X, WsLds& L, const WsArgs& S, in
 
 // ---- the matrix products (one wave each; `lane` = c + 16 q) ----
 __device__ __forceinline__ f32x4ws ws_mfma(float a, float b, f32x4ws c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+// A product tile in LDS: [column c][16 utterances], the four-utterance blocks of a column XOR-swizzled by the column.  The
+// accumulator of lane (c, q) = utterances 4 q .. 4 q + 3 of column c goes out as ONE 16-byte store: the 8 lanes of a store
+// group (c = 0..7 of one q) hit 8 different bank quads (a plain 16-float pitch: two, a 4-way conflict on every store of every
+// product); a gate thread's 4-byte read covers two columns of different parity x 16 utterances = 32 different banks.
+__device__ __forceinline__ int ws_tile(int c, int u) { return c * 16 + (u ^ (((c >> 1) & 3) << 2)); }
+// The input image x: [k][16 utterances] with the utterance XOR-swizzled by the row pair (k < 20: ten different values).  As an
+// MFMA operand lane (utterance, k % 4) reads 2 rows of different parity x 16 utterances = 32 banks per half; the closed
+// loops WRITE it one utterance per half-wave, lane m = row m: 16 m + u puts the 18 rows into two banks (a 9-way conflict),
+// 16 m + (u ^ (m >> 1)) into 18 different ones.
+__device__ __forceinline__ int ws_xi(int k, int u) { return k * 16 + (u ^ ((k >> 1) & 15)); }
 __device__ __forceinline__ void ws_put(float* p, int lane, const f32x4ws& acc) {
-    *reinterpret_cast<f32x4ws*>(&p[(lane & 15) * 16 + 4 * (lane >> 4)]) = acc;  // utterances 4 q .. 4 q + 3 of column c
+    *reinterpret_cast<f32x4ws*>(&p[ws_tile(lane & 15, 4 * (lane >> 4))]) = acc;  // utterances 4 q .. 4 q + 3 of column c
 }
 // A = W1h h1 on the background waves 1-3 (wave 0 of the role does no matrix work: it shares its SIMD with the foreground
 // wave that evaluates the GRU2 gates and polls the hops).  The f32 MFMA runs at the vector ALU's rate and keeps the SIMD's
@@ -422,7 +459,12 @@ __device__ __forceinline__ void ws_put(float* p, int lane, const f32x4ws& acc) {
 // product 1.0k -> 3.4k cycles, the gates 0.8k -> 2.7k, a poll loop 1.4k -> 3.3k) -- so the 12 (segment, gate tile) units of
 // this product go to three SIMDs, 4 units = 96 MFMAs each: wave bw takes the three gate tiles of input segment bw - 1 and gate
 // tile bw - 1 of segment 3, four independent accumulators per k-step, state operands read up front, weights one step ahead.
-__device__ __forceinline__ void ws_A(WsLds& L, const WsRegs& R, int bw, int lane) {
+// SPLIT (the teacher-forced forward, whose frame loop runs THROUGH this product: gates1 -> hop 1 -> A(t+1) -> gates1): the
+// first unit as ONE dependent chain while the foreground's C(t) uses the same matrix pipe (a single chain leaves every second
+// slot to the other wave; the four interleaved chains took four of five and stretched C from 1.0k to 3.4k cycles), the
+// other three units interleaved once C(t) is through (`mid` waits for it).
+template <bool SPLIT = false, class F>
+__device__ __forceinline__ bool ws_A(WsLds& L, const WsRegs& R, int bw, int lane, F&& mid) {
     const int sg = bw - 1;  // 0..2
     f32x4ws acc[4];
 #pragma unroll
@@ -436,15 +478,31 @@ __device__ __forceinline__ void ws_A(WsLds& L, const WsRegs& R, int bw, int lane
         a[j] = hs[64 * j];
         b[j] = h3[64 * j];
     }
+    if (SPLIT) {
 #pragma unroll
-    for (int j = 0; j < 24; ++j) {
+        for (int j = 0; j < 24; ++j) acc[0] = ws_mfma(a[j], R.wA[0][j], acc[0]);
+        if (!mid()) return false;
 #pragma unroll
-        for (int g = 0; g < 3; ++g) acc[g] = ws_mfma(a[j], R.wA[g][j], acc[g]);
-        acc[3] = ws_mfma(b[j], R.wA[3][j], acc[3]);
+        for (int j = 0; j < 24; ++j) {
+#pragma unroll
+            for (int g = 1; g < 3; ++g) acc[g] = ws_mfma(a[j], R.wA[g][j], acc[g]);
+            acc[3] = ws_mfma(b[j], R.wA[3][j], acc[3]);
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < 24; ++j) {
+#pragma unroll
+            for (int g = 0; g < 3; ++g) acc[g] = ws_mfma(a[j], R.wA[g][j], acc[g]);
+            acc[3] = ws_mfma(b[j], R.wA[3][j], acc[3]);
+        }
     }
 #pragma unroll
     for (int g = 0; g < 3; ++g) ws_put(L.pA[sg][g], lane, acc[g]);
     ws_put(L.pA[3][sg], lane, acc[3]);
+    return true;
+}
+__device__ __forceinline__ void ws_A(WsLds& L, const WsRegs& R, int bw, int lane) {
+    (void)ws_A<false>(L, R, bw, lane, [] { return true; });
 }
 // B(t) = W2h h2(t-1), both input segments of 64 (two independent chains), by background wave 0 while hop 1 is in the air:
 // its SIMD partner, the foreground's wave 0, only sleeps on a counter then
@@ -471,23 +529,21 @@ __device__ __forceinline__ void ws_B(WsLds& L, const WsRegs& R, int lane) {
 __device__ __forceinline__ void ws_I(WsLds& L, float bias, int g, int lane, int buf) {
     const int c = lane & 15, q = lane >> 4, cc = c < WU1 ? c : WU1 - 1;
     f32x4ws acc = {bias, bias, bias, bias};
-    const float* xs = L.x + lane;
-    const float* ws = L.w1i + (g * WIN + q) * WU1 + cc;
+    const float* ws = L.w1i + g * W1G + q * WU1 + cc;
 #pragma unroll
-    for (int j = 0; j < WIN / 4; ++j) acc = ws_mfma(xs[64 * j], ws[4 * WU1 * j], acc);
+    for (int j = 0; j < WIN / 4; ++j) acc = ws_mfma(L.x[ws_xi(4 * j + q, c)], ws[4 * WU1 * j], acc);
     ws_put(L.pI[buf][g], lane, acc);
 }
 // The closed loop's form of I (x(t) is the previous frame's result: I is on the chain): foreground wave fw evaluates the
 // columns ITS gate threads need -- 3 gates x units 3 fw .. 3 fw + 2 = 9 columns of one tile -- so the gates follow in the same
-// wave without a barrier of the role.  Sums at p[(gate * 3 + unit - 3 fw) * 16 + utterance], p = the wave's 144 floats.
+// wave without a barrier of the role.  Sums at p[ws_tile(gate * 3 + unit - 3 fw, utterance)], p = the wave's 144 floats.
 __device__ __forceinline__ void ws_I_own(WsLds& L, float bias, int fw, int lane, float* p) {
     const int c = lane & 15, q = lane >> 4, cc = c < 9 ? c : 8;
     f32x4ws acc = {bias, bias, bias, bias};
-    const float* xs = L.x + lane;
-    const float* ws = L.w1i + ((cc / 3) * WIN + q) * WU1 + 3 * fw + cc % 3;
+    const float* ws = L.w1i + (cc / 3) * W1G + q * WU1 + 3 * fw + cc % 3;
 #pragma unroll
-    for (int j = 0; j < WIN / 4; ++j) acc = ws_mfma(xs[64 * j], ws[4 * WU1 * j], acc);
-    if (c < 9) *reinterpret_cast<f32x4ws*>(&p[c * 16 + 4 * q]) = acc;
+    for (int j = 0; j < WIN / 4; ++j) acc = ws_mfma(L.x[ws_xi(4 * j + q, c)], ws[4 * WU1 * j], acc);
+    if (c < 9) *reinterpret_cast<f32x4ws*>(&p[ws_tile(c, 4 * q)]) = acc;
 }
 // C = W2i h1: foreground wave fw = input segment of 96 (one chain of 24 dependent MFMAs: operands read ahead)
 // (ws_C_weights: this lane's B operands, read while hop 1 is still in the air)
@@ -507,9 +563,29 @@ __device__ __forceinline__ void ws_C(WsLds& L, const WsRegs& R, int fw, int lane
     for (int j = 0; j < 24; ++j) acc = ws_mfma(a[j], w[j >> 2][j & 3], acc);
     ws_put(L.pC[fw], lane, acc);
 }
+// rows 16, 17 of the output layer for the owned utterance: 16 lanes = (row, input segment of 16), k-ordered fmaf chains from
+// the bias (segment 0) or 0 -- what an f32 MFMA accumulates.  Operands by 16-byte reads from L.h2own (the utterance's column
+// of the state image, copied as it arrives: in the image its 128 values live in TWO banks, and round 4's reads from there
+// were 8-way conflicts, 40 % of the forward's conflict cycles) and from the weights transposed to [row][k].
+__device__ __forceinline__ void ws_F_rows(WsLds& L, const WsRegs& R, float (&pF)[8][2][16], int lane) {
+    const int row = lane & 1, rsg = (lane >> 1) & 7;
+    f32x4ws h[4], w[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        h[i] = *reinterpret_cast<const f32x4ws*>(&L.h2own[16 * rsg + 4 * i]);
+        w[i] = *reinterpret_cast<const f32x4ws*>(&L.fcw2[row * WH2 + 16 * rsg + 4 * i]);
+    }
+    float a = rsg == 0 ? R.bF[1] : 0.0f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) a = fmaf(h[i][k] > 0.0f ? h[i][k] : 0.0f, w[i][k], a);
+    if (lane < 16) pF[rsg][1][row] = a;
+}
 // output layer on relu(h2) for the owned utterance: rows 0-15 as one MFMA tile (foreground wave fw = input segments 2 fw,
 // 2 fw + 1 of 16 inputs; the other 15 utterances of the M tile come for free and are dropped), rows 16, 17 as fmaf chains
-// on 16 lanes of wave 0 (a second tile would double the MFMAs for two rows; an f32 MFMA accumulates exactly such a chain)
+// on 16 lanes of wave 0 (a second tile would double the MFMAs for two rows -- measured: the forward's background waves come
+// late to the next hop, profiles/r05_ablations.txt)
 __device__ __forceinline__ void ws_F(WsLds& L, const WsRegs& R, int fw, int lane, int own) {
     const int c = lane & 15, q = lane >> 4;
     float hv[2][4], wv[2][4];  // (all operands first: two chains of four dependent MFMAs, not eight LDS round trips)
@@ -520,16 +596,7 @@ __device__ __forceinline__ void ws_F(WsLds& L, const WsRegs& R, int fw, int lane
         for (int j = 0; j < 4; ++j) {
             const float h = L.h2[(16 * sg + 4 * j) * WG + lane];
             hv[s2][j] = h > 0.0f ? h : 0.0f;  // (the rectified state, formed in the chain)
-            wv[s2][j] = L.fcw[(16 * sg + 4 * j + q) * WFC + c];
-        }
-    }
-    float rh[16], rw[16];
-    const int row = 16 + (lane & 1), rsg = (lane >> 1) & 7;
-    if (fw == 0) {
-#pragma unroll
-        for (int k = 0; k < 16; ++k) {
-            rh[k] = L.h2[(16 * rsg + k) * WG + own];
-            rw[k] = L.fcw[(16 * rsg + k) * WFC + row];
+            wv[s2][j] = L.fcw[(16 * sg + 4 * j + q) * 16 + c];
         }
     }
 #pragma unroll
@@ -544,19 +611,16 @@ __device__ __forceinline__ void ws_F(WsLds& L, const WsRegs& R, int fw, int lane
             L.pF[sg][0][c] = r == 0 ? a0[0] : (r == 1 ? a0[1] : (r == 2 ? a0[2] : a0[3]));
         }
     }
-    if (fw == 0 && lane < 2 * 8) {
-        float a = rsg == 0 ? R.bF[1] : 0.0f;
-#pragma unroll
-        for (int k = 0; k < 16; ++k) a = fmaf(rh[k] > 0.0f ? rh[k] : 0.0f, rw[k], a);
-        L.pF[rsg][1][row - 16] = a;
-    }
+    if (fw == 0) ws_F_rows(L, R, L.pF, lane);
 }
 
 // The teacher-forced forward's output layer, off the chain: nothing of frame t + 1 depends on the prediction of frame t, so
 // background waves 1-3 evaluate it behind A(t + 1), when hop 2 of frame t is over -- h2(t) stays whole in LDS until the GRU2
 // gates of frame t + 1, which come behind hop 1 of that frame, i.e. behind these waves' own gather -- while the foreground
-// waits for hop 2 and starts the next frame (its SIMDs run no matrix product then).
+// starts the next frame (its SIMDs run no matrix product then).
 // Wave w3 = 0, 1, 2: input segments {0, 1, 2}, {3, 4, 5}, {6, 7} (independent chains of four MFMAs), rows 16, 17 on wave 2.
+// (One wave for all eight segments -- background wave 0, behind a hop-2 gather of its own -- was measured: that wave becomes
+// the frame's pole, 15.8k cycles; a second MFMA tile for rows 16, 17: the waves come late to hop 1: profiles/r05_ablations.txt)
 __device__ __forceinline__ void ws_F_late(WsLds& L, const WsRegs& R, float (&pF)[8][2][16], int w3, int lane, int own) {
     const int c = lane & 15, q = lane >> 4;
     const int s0 = 3 * w3, ns = w3 == 2 ? 2 : 3;
@@ -568,16 +632,7 @@ __device__ __forceinline__ void ws_F_late(WsLds& L, const WsRegs& R, float (&pF)
         for (int j = 0; j < 4; ++j) {
             const float h = L.h2[(16 * sg + 4 * j) * WG + lane];
             hv[s2][j] = h > 0.0f ? h : 0.0f;
-            wv[s2][j] = L.fcw[(16 * sg + 4 * j + q) * WFC + c];
-        }
-    }
-    float rh[16], rw[16];
-    const int row = 16 + (lane & 1), rsg = (lane >> 1) & 7;
-    if (w3 == 2) {
-#pragma unroll
-        for (int k = 0; k < 16; ++k) {
-            rh[k] = L.h2[(16 * rsg + k) * WG + own];
-            rw[k] = L.fcw[(16 * rsg + k) * WFC + row];
+            wv[s2][j] = L.fcw[(16 * sg + 4 * j + q) * 16 + c];
         }
     }
 #pragma unroll
@@ -594,12 +649,7 @@ __device__ __forceinline__ void ws_F_late(WsLds& L, const WsRegs& R, float (&pF)
             }
         }
     }
-    if (w3 == 2 && lane < 2 * 8) {
-        float a = rsg == 0 ? R.bF[1] : 0.0f;
-#pragma unroll
-        for (int k = 0; k < 16; ++k) a = fmaf(rh[k] > 0.0f ? rh[k] : 0.0f, rw[k], a);
-        pF[rsg][1][row - 16] = a;
-    }
+    if (w3 == 2) ws_F_rows(L, R, pF, lane);
 }
 // ... and its last step for row `row` < 18 (the segment sums are complete: every wave of ws_F_late has passed a barrier since)
 template <bool TANH_ONLY = false>
@@ -616,11 +666,12 @@ __device__ __forceinline__ float ws_F_out(const float (&pF)[8][2][16], int row) 
 template <class F>
 __device__ __forceinline__ bool ws_gather1(const WsCtx& X, WsLds& L, int p, unsigned epoch, bool guard_A, int t, F&& mid) {
     constexpr int NG = (WNS * WQ1 + 383) / 384;
+    const int set = WOFF_H1 + (t & 1) * WNS * WQ1;
     int gi[NG];
 #pragma unroll
     for (int j = 0; j < NG; ++j) {
         const int i = p + 384 * j;
-        gi[j] = (i < WNS * WQ1 && i / WQ1 != X.slice) ? WOFF_H1 + i : -1;
+        gi[j] = (i < WNS * WQ1 && i / WQ1 != X.slice) ? set + i : -1;
     }
     u32x4 v[NG];
     if (!ws_poll_over<NG>(X, L, gi, epoch, v, mid)) return false;
@@ -629,7 +680,7 @@ __device__ __forceinline__ bool ws_gather1(const WsCtx& X, WsLds& L, int p, unsi
 #pragma unroll
     for (int j = 0; j < NG; ++j) {
         if (gi[j] >= 0) {
-            float* d = L.h1 + 3 * (gi[j] - WOFF_H1);  // granule e of slice s holds values 3 e .. 3 e + 2 of that slice
+            float* d = L.h1 + 3 * (gi[j] - set);  // granule e of slice s holds values 3 e .. 3 e + 2 of that slice
             d[0] = __uint_as_float(v[j].y);
             d[1] = __uint_as_float(v[j].z);
             d[2] = __uint_as_float(v[j].w);
@@ -640,26 +691,35 @@ __device__ __forceinline__ bool ws_gather1(const WsCtx& X, WsLds& L, int p, unsi
 __device__ __forceinline__ bool ws_gather1(const WsCtx& X, WsLds& L, int p, unsigned epoch, bool guard_A, int t) {
     return ws_gather1(X, L, p, epoch, guard_A, t, [] {});
 }
-// hop 2 gather by the two waves of SIMD 0 (foreground wave 0 and background wave 0): p < 128, six granules each
+// hop 2 gather: SHARE = 2: by the two waves of SIMD 0 (foreground wave 0 and background wave 0: p < 128, six granules each);
+// SHARE = 1: by background wave 0 alone (p < 64, eleven granules: the teacher-forced forward, whose foreground does not need
+// h2(t) and whose frame is as long as its wave 0's path).  The owned utterance's values also go to L.h2own (ws_F_rows).
+template <int SHARE>
 __device__ __forceinline__ bool ws_gather2(const WsCtx& X, WsLds& L, int p, unsigned epoch) {
-    constexpr int NG = (WNS * WQ2 + 127) / 128;
+    constexpr int NP = 64 * SHARE, NG = (WNS * WQ2 + NP - 1) / NP;
+    const int set = WOFF_H2 + (int)((epoch - 1u) & 1u) * WNS * WQ2;  // (epoch = frame + 1)
     int gi[NG], sl[NG], e[NG];
 #pragma unroll
     for (int j = 0; j < NG; ++j) {
-        const int i = p + 128 * j;
+        const int i = p + NP * j;
         sl[j] = i / WQ2;
         e[j] = i - sl[j] * WQ2;
-        gi[j] = (i < WNS * WQ2 && sl[j] != X.slice) ? WOFF_H2 + i : -1;
+        gi[j] = (i < WNS * WQ2 && sl[j] != X.slice) ? set + i : -1;
     }
     u32x4 v[NG];
     if (!ws_poll<NG>(X, L, gi, epoch, v)) return false;
 #pragma unroll
     for (int j = 0; j < NG; ++j) {
         if (gi[j] >= 0) {
-            float* d = L.h2 + sl[j] * WV2 + 3 * e[j];
-            d[0] = __uint_as_float(v[j].y);
-            if (3 * e[j] + 1 < WV2) d[1] = __uint_as_float(v[j].z);
-            if (3 * e[j] + 2 < WV2) d[2] = __uint_as_float(v[j].w);
+            const int w0 = 3 * e[j];  // the granule's values w0 .. w0 + 2 of that slice, value w = unit * 16 + utterance
+            float* d = L.h2 + sl[j] * WV2 + w0;
+            const float v0 = __uint_as_float(v[j].y), v1 = __uint_as_float(v[j].z), v2 = __uint_as_float(v[j].w);
+            d[0] = v0;
+            if (w0 + 1 < WV2) d[1] = v1;
+            if (w0 + 2 < WV2) d[2] = v2;
+            // (three consecutive values = three consecutive utterances: at most one is the owned one)
+            const int i = (X.own - w0) & 15;
+            if (X.own >= 0 && i < 3 && w0 + i < WV2) L.h2own[WU2 * sl[j] + ((w0 + i) >> 4)] = i == 0 ? v0 : (i == 1 ? v1 : v2);
         }
     }
     return true;
@@ -678,28 +738,31 @@ __device__ __forceinline__ bool ws_foreground(const WsCtx& X, WsLds& L, const Ws
     const int ft = ft0 + ws_opaque_zero();
     const int fw = ft0 >> 6, lane = ft & 63;
     const unsigned epoch = (unsigned)t + 1u;
-    if (EARLY_I) {
-        if (!df_wait(&L.sig[WSIG_I], t + 1, &L.dead)) return false;
-    } else {
+    // (EARLY_I: the caller has waited for I(t) AND A(t) in one poll loop -- k_forward_ws at the top of its frame loop, before x(t + 1)
+    //  goes into the image)
+    if (!EARLY_I) {
         ws_I_own(L, R.bIo, fw, lane, &L.pI[0][0][0] + 144 * fw);
+        WSTAMP(0)
+        if (!df_wait(&L.sig[WSIG_A], 3 * (t + 1), &L.dead)) return false;  // A(t): prologue, then one round per frame
     }
-    WSTAMP(0)
-    if (!df_wait(&L.sig[WSIG_A], 3 * (t + 1), &L.dead)) return false;  // A(t): prologue, then one round per frame
     WSTAMP(1)
     // ---- GRU1 gates of this workgroup's 12 units x 16 utterances: 48 values per wave; torch.nn.GRU rows [r; z; n]
     {
         const int base = X.slice * WV1 + 48 * fw;
         if (lane < 48) {
-            const int v = 48 * fw + lane;
+            const int j = lane >> 4, u = lane & 15;
+            const int v = ws_tile(3 * fw + j, u);  // unit 3 fw + j of the workgroup's 12, utterance u
             const float ghr = (L.pA[0][0][v] + L.pA[1][0][v]) + (L.pA[2][0][v] + L.pA[3][0][v]);
             const float ghz = (L.pA[0][1][v] + L.pA[1][1][v]) + (L.pA[2][1][v] + L.pA[3][1][v]);
             const float ghn = (L.pA[0][2][v] + L.pA[1][2][v]) + (L.pA[2][2][v] + L.pA[3][2][v]);
-            // (I: by gate tile a frame ahead, or this wave's own tile -- read back by the wave that wrote it)
-            const float* pi = EARLY_I ? &L.pI[t & 1][0][v] : &L.pI[0][0][0] + 144 * fw + lane;
-            constexpr int PG = EARLY_I ? 256 : 48;
-            const float r = fpc_sigmoidf(pi[0] + ghr);
-            const float z = fpc_sigmoidf(pi[PG] + ghz);
-            const float n = fpc_tanhf(fmaf(r, ghn, pi[2 * PG]));
+            // (I: by gate tile a frame ahead, or this wave's own tile -- columns gate * 3 + j -- read back by the wave that wrote it)
+            const float* pw = &L.pI[0][0][0] + 144 * fw;
+            const float ir = EARLY_I ? L.pI[t & 1][0][v] : pw[ws_tile(j, u)];
+            const float iz = EARLY_I ? L.pI[t & 1][1][v] : pw[ws_tile(3 + j, u)];
+            const float in = EARLY_I ? L.pI[t & 1][2][v] : pw[ws_tile(6 + j, u)];
+            const float r = fpc_sigmoidf(ir + ghr);
+            const float z = fpc_sigmoidf(iz + ghz);
+            const float n = fpc_tanhf(fmaf(r, ghn, in));
             const float hp = L.h1[base + lane];
             const float hn = fmaf(z, hp - n, n);
             L.h1[base + lane] = hn;
@@ -716,7 +779,7 @@ __device__ __forceinline__ bool ws_foreground(const WsCtx& X, WsLds& L, const Ws
         // (the same wave reads what it has just written: one in-order LDS queue per wave)
         if (lane < 16) {
             const float* s = &L.h1[base + 3 * lane];
-            ws_store(X, WOFF_H1 + X.slice * WQ1 + 16 * fw + lane, epoch, s[0], s[1], s[2]);
+            ws_store(X, WOFF_H1 + (t & 1) * WNS * WQ1 + X.slice * WQ1 + 16 * fw + lane, epoch, s[0], s[1], s[2]);
         }
     }
     df_signal(&L.sig[WSIG_P1]);  // (the background starts polling now, not before)
@@ -731,26 +794,29 @@ __device__ __forceinline__ bool ws_foreground(const WsCtx& X, WsLds& L, const Ws
     if (!df_wait(&L.sig[WSIG_H1], 6 * (t + 1), &L.dead)) return false;  // h1(t) whole in LDS
     WSTAMP(4)
     ws_C(L, R, fw, lane, wC);
-    df_signal(&L.sig[WSIG_C]);  // (A(t+1) starts behind C(t): side by side on one matrix pipe the chain's product took 3.4k cycles)
-    ws_fg_sync(L, fg_epoch);
+    df_signal(&L.sig[WSIG_C]);  // (closed loops: A(t+1) starts behind C(t) -- side by side on one matrix pipe the chain's product took 3.4k cycles)
     WSTAMP(5)
-    if (!df_wait(&L.sig[WSIG_B], t + 1, &L.dead)) return false;  // B(t)
+    // the GRU2 gates need all four segments of C(t) and B(t); only their wave waits (one poll loop for both counters; round 4
+    // had a barrier of the role and a second wait here: two LDS round trips on every wave)
+    if (fw == 0 && !df_wait2(&L.sig[WSIG_C], WFG * (t + 1), &L.sig[WSIG_B], t + 1, &L.dead)) return false;
     WSTAMP(6)
     if (fw == 0) {  // GRU2 gates: 4 units x 16 utterances
         const int base = X.slice * WV2;
         const int v = lane;
-        const float gir = (L.pC[0][v] + L.pC[1][v]) + (L.pC[2][v] + L.pC[3][v]);
-        const float giz = (L.pC[0][64 + v] + L.pC[1][64 + v]) + (L.pC[2][64 + v] + L.pC[3][64 + v]);
-        const float gin = (L.pC[0][128 + v] + L.pC[1][128 + v]) + (L.pC[2][128 + v] + L.pC[3][128 + v]);
-        const float ghr = L.pB[0][v] + L.pB[1][v];
-        const float ghz = L.pB[0][64 + v] + L.pB[1][64 + v];
-        const float ghn = L.pB[0][128 + v] + L.pB[1][128 + v];
+        const int vr = ws_tile(v >> 4, v & 15), vz = ws_tile(4 + (v >> 4), v & 15), vn = ws_tile(8 + (v >> 4), v & 15);  // columns gate * 4 + unit
+        const float gir = (L.pC[0][vr] + L.pC[1][vr]) + (L.pC[2][vr] + L.pC[3][vr]);
+        const float giz = (L.pC[0][vz] + L.pC[1][vz]) + (L.pC[2][vz] + L.pC[3][vz]);
+        const float gin = (L.pC[0][vn] + L.pC[1][vn]) + (L.pC[2][vn] + L.pC[3][vn]);
+        const float ghr = L.pB[0][vr] + L.pB[1][vr];
+        const float ghz = L.pB[0][vz] + L.pB[1][vz];
+        const float ghn = L.pB[0][vn] + L.pB[1][vn];
         const float r = fpc_sigmoidf(gir + ghr);
         const float z = fpc_sigmoidf(giz + ghz);
         const float n = fpc_tanhf(fmaf(r, ghn, gin));
         const float hp = L.h2[base + v];
         const float hn = fmaf(z, hp - n, n);
         L.h2[base + v] = hn;
+        if ((v & 15) == X.own) L.h2own[WU2 * X.slice + (v >> 4)] = hn;
         if (SAVE && (v & 15) < X.nu) {
             const size_t o = ((size_t)(X.b0 + (v & 15)) * X.Lf + t) * WH2 + WU2 * X.slice + (v >> 4);
             sv->h2p[o] = hp;
@@ -763,21 +829,24 @@ __device__ __forceinline__ bool ws_foreground(const WsCtx& X, WsLds& L, const Ws
         }
         if (lane < WQ2) {
             const int i0 = 3 * lane, i1 = i0 + 1 < WV2 ? i0 + 1 : WV2 - 1, i2 = i0 + 2 < WV2 ? i0 + 2 : WV2 - 1;
-            ws_store(X, WOFF_H2 + X.slice * WQ2 + lane, epoch, L.h2[base + i0], L.h2[base + i1], L.h2[base + i2]);
+            ws_store(X, WOFF_H2 + (t & 1) * WNS * WQ2 + X.slice * WQ2 + lane, epoch, L.h2[base + i0], L.h2[base + i1], L.h2[base + i2]);
         }
         df_signal(&L.sig[WSIG_P2]);
     }
     WSTAMP(7)
     if (fw == 0) {
-        if (!ws_gather2(X, L, lane, epoch)) return false;
+        if (!ws_gather2<2>(X, L, lane, epoch)) return false;
         df_signal(&L.sig[WSIG_H2]);
     }
     WSTAMP(8)
-    if (!df_wait(&L.sig[WSIG_H2], 2 * (t + 1), &L.dead)) return false;  // h2(t) whole in LDS
+    // h2(t) whole in LDS: for the output layer of the closed loops.  The teacher-forced forward's foreground needs nothing of
+    // it (the background evaluates the output layer and B(t+1) = W2h h2(t), behind its own waits for both halves of the
+    // gather; the granule sets of the two frame parities make the next frame's publish independent of this hop: WOFF_H1)
+    if (FC_LATE) return true;  // (a launch that died shows at the next frame's first wait)
+    if (!df_wait(&L.sig[WSIG_H2], 2 * (t + 1), &L.dead)) return false;
     WSTAMP(9)
     if (FC_ALL) {
         wsd_F(L, R, fw, lane, ft);
-    } else if (FC_LATE) {
     } else if (X.own >= 0) {  // the output layer: only the workgroup that owns an utterance needs its prediction
         ws_F(L, R, fw, lane, X.own);
         ws_fg_sync(L, fg_epoch);
@@ -803,8 +872,10 @@ __device__ __forceinline__ bool ws_background(const WsCtx& X, WsLds& L, const Ws
     if (!df_wait(&L.sig[WSIG_P1], WFG * (t + 1), &L.dead)) return false;
     WBSTAMP(13)
     if (bw == 0) {  // the two waves of SIMD 0 run no matrix product beside the chain: B(t) under hop 1, then hop 2's gather
+        if (!df_wait(&L.sig[WSIG_H2], 2 * t, &L.dead)) return false;  // h2(t-1) whole (the foreground's half of the gather too)
         ws_B(L, R, lane);
         df_signal(&L.sig[WSIG_B]);
+        WBSTAMP(14)
         if (EARLY_I) {  // the next frame's input product, still under hop 1 (x(t+1) has been in LDS since the frame began)
             if (!df_wait(&L.sig[WSIG_X], WFG * (t + 1), &L.dead)) return false;
             if (!last) {
@@ -813,8 +884,10 @@ __device__ __forceinline__ bool ws_background(const WsCtx& X, WsLds& L, const Ws
             }
             df_signal(&L.sig[WSIG_I]);
         }
+        WBSTAMP(15)
         if (!df_wait(&L.sig[WSIG_P2], t + 1, &L.dead)) return false;
-        if (!ws_gather2(X, L, 64 + lane, (unsigned)t + 1u)) return false;
+        WBSTAMP(17)
+        if (!ws_gather2<2>(X, L, 64 + lane, (unsigned)t + 1u)) return false;
         df_signal(&L.sig[WSIG_H2]);
         return true;
     }
@@ -823,9 +896,15 @@ __device__ __forceinline__ bool ws_background(const WsCtx& X, WsLds& L, const Ws
     WBSTAMP(14)
     if (!df_wait(&L.sig[WSIG_H1], 6 * (t + 1), &L.dead)) return false;
     WBSTAMP(15)
-    if (!df_wait(&L.sig[WSIG_C], WFG * (t + 1), &L.dead)) return false;  // (behind C(t): the chain's product comes first)
-    WBSTAMP(17)
-    if (!last) ws_A(L, R, bw, lane);
+    // Closed loops: behind C(t) -- the chain's product comes first, A(t+1) has the whole frame tail to finish in.  Teacher-forced
+    // forward (FPC_WS_A_SPLIT): the first unit's chain beside C(t), the rest behind it.
+    if (FC_LATE && FPC_WS_A_SPLIT) {
+        if (!last && !ws_A<true>(L, R, bw, lane, [&] { return df_wait(&L.sig[WSIG_C], WFG * (t + 1), &L.dead); })) return false;
+    } else {
+        if (!df_wait(&L.sig[WSIG_C], WFG * (t + 1), &L.dead)) return false;
+        WBSTAMP(17)
+        if (!last) ws_A(L, R, bw, lane);
+    }
     df_signal(&L.sig[WSIG_A]);
     WBSTAMP(16)
     if (FC_LATE && X.own >= 0) {
@@ -837,6 +916,7 @@ __device__ __forceinline__ bool ws_background(const WsCtx& X, WsLds& L, const Ws
             if (lane < WFC) y_late[lane] = ws_F_out<TANH_ONLY>(L.pFl[t & 1], lane);
         }
     }
+    WBSTAMP(18)
     return true;
 }
 
@@ -899,7 +979,7 @@ __global__ __launch_bounds__(NT) void k_forward_ws(const PredDev P, const float*
     }
     for (int i = tid; i < WIN * WG; i += NT) {
         const int u = i / WIN, k = i - u * WIN;
-        L.x[k * WG + u] = (u < X.nu && Lf > 0) ? x[(size_t)(X.b0 + u) * Lf * WIN + k] : 0.0f;
+        L.x[ws_xi(k, u)] = (u < X.nu && Lf > 0) ? x[(size_t)(X.b0 + u) * Lf * WIN + k] : 0.0f;
     }
     __syncthreads();
     ws_prologue(P, X, L, R, S, tid);
@@ -921,7 +1001,7 @@ __global__ __launch_bounds__(NT) void k_forward_ws(const PredDev P, const float*
         const int i = tid + WFGT * j, u = i / WIN, k = i - u * WIN;
         const bool have = tid < WFGT && i < WIN * WG;
         xsrc[j] = (have && u < X.nu) ? x + (size_t)(X.b0 + u) * Lf * WIN + k : nullptr;
-        xdst[j] = have ? k * WG + u : -1;
+        xdst[j] = have ? ws_xi(k, u) : -1;
     }
     auto x_row = [&](int t, float (&xr)[2]) {  // (0 beyond the end and for the utterances a part-filled group lacks)
 #pragma unroll
@@ -934,7 +1014,7 @@ __global__ __launch_bounds__(NT) void k_forward_ws(const PredDev P, const float*
         x_row(1, xa);
         for (int t = 0; t < Lf; ++t) {
             // x(t+1) into LDS (x(t) is not read any more: I(t) is done), then the row after it on its way
-            if (!df_wait(&L.sig[WSIG_I], t + 1, &L.dead)) break;
+            if (!df_wait2(&L.sig[WSIG_I], t + 1, &L.sig[WSIG_A], 3 * (t + 1), &L.dead)) break;  // I(t) and A(t)
 #pragma unroll
             for (int j = 0; j < 2; ++j)
                 if (xdst[j] >= 0) L.x[xdst[j]] = xa[j];
@@ -975,16 +1055,16 @@ __device__ __forceinline__ bool ws_gather3(const WsCtx& X, WsLds& L, int p, unsi
     u32x4 v[1];
     if (!ws_poll<1>(X, L, gi, epoch, v)) return false;
     if (gi[0] >= 0) {
-        L.x[(3 * e + 0) * WG + u] = __uint_as_float(v[0].y);
-        L.x[(3 * e + 1) * WG + u] = __uint_as_float(v[0].z);
-        L.x[(3 * e + 2) * WG + u] = __uint_as_float(v[0].w);
+        L.x[ws_xi(3 * e + 0, u)] = __uint_as_float(v[0].y);
+        L.x[ws_xi(3 * e + 1, u)] = __uint_as_float(v[0].z);
+        L.x[ws_xi(3 * e + 2, u)] = __uint_as_float(v[0].w);
     }
     return true;
 }
 // the owner's next input row L.xn goes out and into its own column of the x image (threads of wave 0)
 __device__ __forceinline__ void ws_publish_x(const WsCtx& X, WsLds& L, int lane, unsigned epoch) {
     if (lane < WQX) ws_store(X, WOFF_X + X.slice * WQX + lane, epoch, L.xn[3 * lane], L.xn[3 * lane + 1], L.xn[3 * lane + 2]);
-    if (lane < WIN) L.x[lane * WG + X.slice] = L.xn[lane];
+    if (lane < WIN) L.x[ws_xi(lane, X.slice)] = L.xn[lane];
 }
 
 
@@ -1049,7 +1129,7 @@ __global__ __launch_bounds__(NT) void k_decode_feat_ws(const PredDev P, const Cb
         }
         if (tid < (WIN - WFC) * WG) {
             const int u = tid / (WIN - WFC), k = WFC + tid % (WIN - WFC);
-            if (!(owner && u == slice)) L.x[k * WG + u] = pv;
+            if (!(owner && u == slice)) L.x[ws_xi(k, u)] = pv;
         }
         if (tid >= 64 && tid < 192) (void)ws_gather3(X, L, tid - 64, epoch);
         if (ws_frame_dead(L, tid)) break;

@@ -133,29 +133,37 @@ __device__ __forceinline__ void wsd_F(WsLds& L, const WsRegs& R, int fw, int lan
         for (int j = 0; j < 4; ++j) {
             const float h = L.h2[(16 * sg + 4 * j) * WG + lane];
             hv[s2][j] = h > 0.0f ? h : 0.0f;
-            wv[s2][j] = L.fcw[(16 * sg + 4 * j + q) * WFC + c];
+            wv[s2][j] = L.fcw[(16 * sg + 4 * j + q) * 16 + c];
         }
     }
     const int rsg = ft >> 5, row = 16 + ((ft >> 4) & 1), ru = ft & 15;  // item ft: (segment, row 16 | 17, utterance)
     float rh[16], rw[16];
 #pragma unroll
-    for (int k = 0; k < 16; ++k) {
-        rh[k] = L.h2[(16 * rsg + k) * WG + ru];
-        rw[k] = L.fcw[(16 * rsg + k) * WFC + row];
+    for (int k = 0; k < 16; ++k) rh[k] = L.h2[(16 * rsg + k) * WG + ru];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const f32x4ws w4 = *reinterpret_cast<const f32x4ws*>(&L.fcw2[(row - 16) * WH2 + 16 * rsg + 4 * i]);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) rw[4 * i + k] = w4[k];
     }
+    // The tile TRANSPOSED -- weights as the A operand, states as B (the two operand layouts are the same: lane = (index, k)),
+    // same products in the same k order, same bits -- so that lane (c, q) ends up with rows 4 q .. 4 q + 3 of UTTERANCE c:
+    // one 16-byte store per lane to [utterance][row], where the tail's half-wave (lane m = row m of its utterance) reads 18
+    // consecutive floats.  (Rows of 16 utterances at a 16-float pitch put one utterance's 18 rows into two banks: a 9-way
+    // conflict on each of the tail's eight reads, by all eight waves at once -- 1.1k cycles of the LDS pipe per frame.)
 #pragma unroll
     for (int s2 = 0; s2 < 2; ++s2) {
         const int sg = 2 * fw + s2;
-        const float b0 = sg == 0 ? R.bF[0] : 0.0f;
-        f32x4ws a0 = {b0, b0, b0, b0};
+        f32x4ws a0 = {0.f, 0.f, 0.f, 0.f};
+        if (sg == 0) a0 = *reinterpret_cast<const f32x4ws*>(&L.fcb[4 * q]);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) a0 = ws_mfma(hv[s2][j], wv[s2][j], a0);
-        ws_put(L.pFa[sg], lane, a0);  // [row c][utterances 4 q .. 4 q + 3]
+        for (int j = 0; j < 4; ++j) a0 = ws_mfma(wv[s2][j], hv[s2][j], a0);
+        *reinterpret_cast<f32x4ws*>(&L.pFa[sg][c * WPF + 4 * q]) = a0;  // utterance c, rows 4 q .. 4 q + 3
     }
     float a = rsg == 0 ? (row == 16 ? R.bF16[0] : R.bF16[1]) : 0.0f;  // (no indexed access: the struct stays in registers)
 #pragma unroll
     for (int k = 0; k < 16; ++k) a = fmaf(rh[k] > 0.0f ? rh[k] : 0.0f, rw[k], a);
-    L.pFa[rsg][row * WG + ru] = a;
+    L.pFa[rsg][ru * WPF + row] = a;
 }
 
 // the frame's tail for all utterances of the group (all 512 threads); `fv`: feat[u][frame][m] of thread (u, m < 20);
@@ -167,7 +175,7 @@ __device__ __forceinline__ void wsd_tail(const WsCtx& X, WsLds& L, const CbDev& 
     // ---- prediction, residual, first-stage target of utterance u: lane m < 18 = row m (wavernn.py:195-196).  Everything an
     // utterance's half-wave reads from here on it has written itself (one in-order LDS queue per wave): no barrier.
     if (m < WFC) {
-        const int o = m * WG + u;
+        const int o = u * WPF + m;
         const float acc = ((L.pFa[0][o] + L.pFa[1][o]) + (L.pFa[2][o] + L.pFa[3][o])) +
                           ((L.pFa[4][o] + L.pFa[5][o]) + (L.pFa[6][o] + L.pFa[7][o]));
         const float tt = fpc_tanhf(acc);
@@ -177,7 +185,7 @@ __device__ __forceinline__ void wsd_tail(const WsCtx& X, WsLds& L, const CbDev& 
         L.rsa[u][m] = r;
         if (m >= 1) L.xs[u][m - 1] = (double)r;
     } else if (m < WIN) {  // the pitch columns pass through (wavernn.py:178; stored with the other outputs: a store here
-        L.x[m * WG + u] = fv;  // would stand in front of the next wait for a load)
+        L.x[ws_xi(m, u)] = fv;  // would stand in front of the next wait for a load)
     }
     WSTAMP(25)
     // ---- thresholds (:202,:206): every lane of the utterance's half-wave evaluates the same values ----
@@ -365,7 +373,7 @@ __device__ __forceinline__ void wsd_tail(const WsCtx& X, WsLds& L, const CbDev& 
             rv = rs * (masked ? mv : (float)ind);
             cn = f + rv;
         }
-        L.x[m * WG + u] = uv ? cn : 0.0f;
+        L.x[ws_xi(m, u)] = uv ? cn : 0.0f;
         if (owner) {
             A.r[fi * WFC + m] = rv;
             A.r_qtz[fi * WFC + m] = rq;
