@@ -1101,6 +1101,7 @@ __global__ __launch_bounds__(NT) void k_train_bwd(const PredDev P, const BwdW W,
                                                   const SplitArgs Sp) {
     __shared__ BwdLds S;
     const int b = blockIdx.x / Sp.n, half = blockIdx.x % Sp.n, tid = threadIdx.x;
+    if (!split_wanted(Sp, b)) return;
     SplitCtx X = split_ctx(Sp, P, b, half);
     const bool writer = half == 0;
     const int ns = X.n;  // row split: each workgroup owns a slice of the columns k of the three transposed products
@@ -1178,6 +1179,8 @@ __global__ __launch_bounds__(NT) void k_train_bwd(const PredDev P, const BwdW W,
         __syncthreads();  // (dh1n is only ever read at this workgroup's own columns: it stays local)
     }
 }
+
+#include "predictor_bwd_ws.h"
 
 // C[k][r] = sum over n (ascending, fmaf chain from 0 = what the f32 MFMA accumulates) of A[n][k] * D[n][r]:
 // the gradient of a weight matrix in the transposed layout.  One wave = 16 k-rows x 64 r-columns
@@ -1319,6 +1322,8 @@ void predictor_build_info(std::string& out) {
     FPC_TUNE("FPC_DFW", FPC_DFW, 16)
     FPC_TUNE("FPC_FG_PRIO", FPC_FG_PRIO, 2)
     FPC_TUNE("FPC_BSTAMP_WAVE", FPC_BSTAMP_WAVE, 0)
+    FPC_TUNE("FPC_WS_A_SPLIT", FPC_WS_A_SPLIT, 0)
+    FPC_TUNE("FPC_WS_POLL_DELAY", FPC_WS_POLL_DELAY, 0)
 #undef FPC_TUNE
 #ifdef FPC_WAVES_EU
     out += " FPC_WAVES_EU";
@@ -1353,6 +1358,7 @@ struct fpc_predictor {
     hipStream_t last_stream = nullptr;
     bool launched = false;
     int last_ws_groups = 0;  // groups of the handle's last weights-stationary launch (fpc_predictor_fallback_groups)
+    size_t last_ws_gbytes = 0;  // ... and where its decision words start in wsg
     int forced_split = 0;  // fpc_predictor_set_split: 0 automatic, 1 off, 2/4/8 exactly that many workgroups per utterance
     int num_cus = 0;
     int occ_df = 1;  // workgroups of the two-role kernels that one CU holds (LDS-bound: 1)
@@ -1467,7 +1473,7 @@ static bool ws_codebooks_fit(const fpc_codebooks* cb) {
     return c.N_hi0 <= 2 * NT && c.N_hi1 <= 2 * NT && c.N_lo <= 2 * NT && c.n_hi <= 256 && c.n_lo <= 256 && c.n_hi + c.n_lo <= SCLC;
 }
 // granule blocks zeroed on the stream, test hooks read; the grid is ws_grid(args) workgroups
-static int ws_args(fpc_predictor* p, int B, hipStream_t st, WsArgs* out) {
+static int ws_args(fpc_predictor* p, int B, hipStream_t st, WsArgs* out, int granules = WGRANULES) {
     out->B = B;
     out->ngroups = (B + WG - 1) / WG;
     out->err = p->status_dev;
@@ -1491,7 +1497,7 @@ static int ws_args(fpc_predictor* p, int B, hipStream_t st, WsArgs* out) {
         const int rc = before_launch(p, st);
         if (rc != FPC_OK) return rc;
     }
-    const size_t gbytes = (size_t)out->ngroups * WGRANULES * sizeof(u32x4);
+    const size_t gbytes = (size_t)out->ngroups * granules * sizeof(u32x4);
     const size_t bytes = gbytes + (((size_t)out->ngroups * sizeof(unsigned) + 255) & ~(size_t)255);  // + the decision words
     if (p->wsg.bytes < bytes) {
         if (p->wsg.p) {
@@ -1505,6 +1511,7 @@ static int ws_args(fpc_predictor* p, int B, hipStream_t st, WsArgs* out) {
     out->g = p->wsg.as<u32x4>();
     out->dec = reinterpret_cast<unsigned*>(static_cast<char*>(p->wsg.p) + gbytes);
     p->last_ws_groups = out->ngroups;
+    p->last_ws_gbytes = gbytes;
     return FPC_OK;
 }
 // the launch behind every weights-stationary launch: the row-split kernels, one workgroup per utterance (no partner to
@@ -1662,8 +1669,7 @@ extern "C" int fpc_predictor_fallback_groups(fpc_predictor* p) {
     if (p->last_ws_groups <= 0 || !p->wsg.p) return 0;
     FPC_HIP(hipDeviceSynchronize());
     std::vector<unsigned> dec((size_t)p->last_ws_groups);
-    const size_t gbytes = (size_t)p->last_ws_groups * WGRANULES * sizeof(u32x4);
-    FPC_HIP(hipMemcpy(dec.data(), static_cast<char*>(p->wsg.p) + gbytes, dec.size() * sizeof(unsigned), hipMemcpyDeviceToHost));
+    FPC_HIP(hipMemcpy(dec.data(), static_cast<char*>(p->wsg.p) + p->last_ws_gbytes, dec.size() * sizeof(unsigned), hipMemcpyDeviceToHost));
     int n = 0;
     for (unsigned d : dec) n += d == WS_FALLBACK;
     return n;
@@ -1966,11 +1972,28 @@ extern "C" int fpc_trainer_step(fpc_trainer* t, const float* feat_dev, int B, in
     hipLaunchKernelGGL(k_train_loss, dim3(B), dim3(256), sizeof(float) * (size_t)L * F, st, feat_dev, in, F, L,
                        (float)(2.0 / cnt), T);
     const BwdW bw{t->wt[0].as<float>(), t->wt[1].as<float>(), t->wt[2].as<float>()};
-    {
+    if (ws_wanted(p) && !getenv("FPC_TRAIN_BWD_ROWSPLIT")) {
+        // back-propagation on the weights-stationary kernel (predictor_bwd_ws.h); behind it, for the groups whose workgroups
+        // could not all become resident, the row-split kernel with one workgroup per utterance
+        WsArgs wb;
+        const int rc = ws_args(p, B, st, &wb, BGRANULES);  // fresh granules (zeroed behind the forward launches on the stream)
+        if (rc != FPC_OK) return rc;
+        hipLaunchKernelGGL(k_train_bwd_ws, dim3(ws_grid(wb)), dim3(NT), 0, st, P, bw, L, T, wb);
+#ifdef FPC_WS_PROF
+        {
+            (void)hipStreamSynchronize(st);
+            volatile unsigned* w = (volatile unsigned*)p->status_host;
+            fprintf(stderr, "k_train_bwd_ws B=%d cycles/step (thread %d of workgroup 5, group 0): phase 1 %u poll %u image writes %u barriers %u "
+                    "prefetch issue %u products %u stage + barrier %u | before the loop %u kcycles, loop %u kcycles, kernel %u us\n", B, FPC_BW_STAMP_TID, w[44], w[45], w[46], w[47], 0u, w[48], w[49], w[50], w[51], w[52]);
+            for (int k2 = 40; k2 < 56; ++k2) w[k2] = 0;
+        }
+#endif
+        hipLaunchKernelGGL(k_train_bwd, dim3(B), dim3(NT), 0, st, P, bw, L, T, ws_fallback_args(p, wb));
+    } else {
         const int rc = split_args(p, B, st, &sp);  // fresh granules (zeroed behind the forward launch on the stream)
         if (rc != FPC_OK) return rc;
+        hipLaunchKernelGGL(k_train_bwd, dim3(B * sp.n), dim3(NT), 0, st, P, bw, L, T, sp);
     }
-    hipLaunchKernelGGL(k_train_bwd, dim3(B * sp.n), dim3(NT), 0, st, P, bw, L, T, sp);
     struct G {
         const float* A;
         int K;

@@ -176,7 +176,8 @@ struct WsCtx {
 // The end of a frame in the closed-loop kernels: has any wait of this frame been given up?  Every poll that fails sets
 // L.dead first; the answer must be the same for every thread (they leave the frame loop together), so one thread latches
 // the flag between two barriers (__syncthreads_or costs three barriers and a cross-lane reduction: ~900 cycles per use).
-__device__ __forceinline__ bool ws_frame_dead(WsLds& L, int tid) {
+template <class LT>
+__device__ __forceinline__ bool ws_frame_dead(LT& L, int tid) {
     lds_barrier();
     if (tid == 0) L.dead_latch = __hip_atomic_load(&L.dead, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     lds_barrier();
@@ -190,10 +191,12 @@ __device__ __forceinline__ int ws_opaque_zero() {
     asm volatile("" : "+v"(z));
     return z;
 }
-__device__ __forceinline__ bool ws_dead(WsLds& L) {
+template <class LT>
+__device__ __forceinline__ bool ws_dead(LT& L) {
     return __hip_atomic_load(&L.dead, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0;
 }
-__device__ __forceinline__ void ws_give_up(const WsCtx& X, WsLds& L) {
+template <class LT>
+__device__ __forceinline__ void ws_give_up(const WsCtx& X, LT& L) {
     status_or(X.err, FPC_ST_TIMEOUT);
     __hip_atomic_store(&L.dead, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
@@ -213,8 +216,8 @@ __device__ __forceinline__ void ws_store(const WsCtx& X, int granule, unsigned e
 }
 // N granules per lane (granule index, or -1: none), polled until every wanted tag of the WAVE equals `epoch`; false: the
 // wait was given up (timeout, or the workgroup is dead already)
-template <int N>
-__device__ __forceinline__ bool ws_poll(const WsCtx& X, WsLds& L, const int (&gi)[N], unsigned epoch, u32x4 (&v)[N]) {
+template <int N, class LT>
+__device__ __forceinline__ bool ws_poll(const WsCtx& X, LT& L, const int (&gi)[N], unsigned epoch, u32x4 (&v)[N]) {
     {  // (nothing wanted by any lane: no round trip)
         bool none = true;
 #pragma unroll
@@ -372,7 +375,8 @@ __device__ __forceinline__ unsigned ws_dec_try(const WsCtx& X, unsigned want) { 
     seen = (unsigned)__builtin_amdgcn_readfirstlane((int)seen);
     return seen == 0u ? want : seen;
 }
-__device__ __forceinline__ void ws_hello(WsCtx& X, WsLds& L, const WsArgs& S, int tid) {
+template <class LT>
+__device__ __forceinline__ void ws_hello(WsCtx& X, LT& L, const WsArgs& S, int tid) {
     unsigned xcc;
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
     xcc = (xcc & 0xfu) + 1u;
@@ -938,9 +942,9 @@ __device__ __forceinline__ void ws_prologue(const PredDev& P, WsCtx& X, WsLds& L
     __syncthreads();
 }
 
-__device__ __forceinline__ WsCtx ws_ctx(const WsArgs& S, int group, int slice) {
+__device__ __forceinline__ WsCtx ws_ctx(const WsArgs& S, int group, int slice, int granules = WGRANULES) {
     WsCtx X;
-    X.rs = __builtin_amdgcn_make_buffer_rsrc((void*)(S.g + (size_t)group * WGRANULES), 0, WGRANULES * 16, 0x00020000);
+    X.rs = __builtin_amdgcn_make_buffer_rsrc((void*)(S.g + (size_t)group * granules), 0, granules * 16, 0x00020000);
     X.slice = slice;
     X.Lf = 0;
     X.b0 = group * WG;

@@ -555,6 +555,47 @@ def test_train_step_vs_torch_golden_and_oracle(torch_cuda, synth, golden, oracle
     assert np.array_equal(y, yo)
 
 
+def test_train_backward_weights_stationary_equals_row_split_and_oracle(torch_cuda, synth, oracle, monkeypatch):
+    """back-propagation on the weights-stationary kernel (csrc/predictor_bwd_ws.h: 16 utterances a group on the 32
+    workgroups of an XCD, the transposed slices resident, W^T d on f32 MFMA, one hop per step) against the row-split kernel
+    (FPC_TRAIN_BWD_ROWSPLIT=1: one utterance per workgroup) -- loss, every gradient, every parameter after two steps, bit for
+    bit -- for 2 full groups + a part-filled one, for the shortest sequence (2 frames) and on both hop paths; and against
+    the CPU oracle at 19 x 9 (a full and a part-filled group)"""
+    from fpcodec_amd.train_frame import Trainer
+    from fpcodec_amd.wavernn import Wavernn
+
+    def run(feat, steps=2):
+        m = Wavernn(20, 384, 128, 18)
+        m.load_state_dict(synth.predictor_state_dict())
+        tr = Trainer(m, lr=1e-3, max_batch=feat.shape[0], max_frames=feat.shape[1])
+        losses = [tr.step(feat) for _ in range(steps)]
+        g = tr.gradients()
+        tr.sync()
+        sd = m.state_dict()
+        return [np.float32(losses)] + [g[k] for k in sorted(g)] + [sd[k].numpy() for k in sorted(sd)]
+
+    for B, L in ((37, 21), (16, 2), (3, 5)):
+        feat = synth.predictor_features(B, L, utt0=4400)
+        monkeypatch.setenv("FPC_TRAIN_BWD_ROWSPLIT", "1")
+        ref = run(feat)
+        monkeypatch.delenv("FPC_TRAIN_BWD_ROWSPLIT")
+        for fast in ("1", "0"):
+            monkeypatch.setenv("FPC_FAST_HOP", fast)
+            got = run(feat)
+            for k, (a, b) in enumerate(zip(ref, got)):
+                assert not np.isnan(b).any() and np.array_equal(a, b), (B, L, fast, k)
+        monkeypatch.delenv("FPC_FAST_HOP")
+    feat = synth.predictor_features(19, 9, utt0=4500)
+    got = run(feat, steps=1)
+    ref = oracle.Trainer(synth.predictor_state_dict(), lr=1e-3)
+    l0 = ref.step(feat)
+    assert np.float32(l0) == got[0][0]
+    for k, name in enumerate(sorted(ref.g)):
+        assert np.array_equal(got[1 + k], ref.g[name]), name
+    for k, name in enumerate(sorted(ref.p)):
+        assert np.array_equal(got[1 + len(ref.g) + k], ref.p[name]), name
+
+
 def test_train_converges_at_reference_batch(torch_cuda, synth):
     """train_frame.py:188-192 shapes (batch 100 x 150 frames): the loss falls over a few steps"""
     from fpcodec_amd.train_frame import Trainer
