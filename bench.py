@@ -218,8 +218,41 @@ def e2e_config5(voc, torch, synth, parallel, rank, world, L=300):
         b.synchronize()
         return a.elapsed_time(b)
     x20 = nm_d[:, :, :20].contiguous()
-    enc_ms = ev_ms(lambda: model.encoder(cfg, x20, None, cfg["l1"], cfg["l2"], qtz=True, return_indices=True))
-    fwd_ms = ev_ms(lambda: model.forward(x20))
+    enc_call_ms = ev_ms(lambda: model.encoder(cfg, x20, None, cfg["l1"], cfg["l2"], qtz=True, return_indices=True))
+    # ... and around the raw C-ABI calls (no Python wrapper, no histogram download, no status synchronisation inside the events)
+    from fpcodec_amd import _lib
+    cbh = load_codebooks(cfg["cb_path"], cfg["scl_cb_path"], cfg["bl_cb_path"], cfg["bl_scl_cb_path"])
+    bufs = [torch.empty(B, L, n, device="cuda") for n in (20, 18, 18, 18, 1, 1)]
+    sym = torch.empty(B, L, 4, device="cuda", dtype=torch.int32)
+    hist = torch.zeros(cbh.hist_size, device="cuda", dtype=torch.int64)
+    s1, s2 = torch.zeros(B, 384, device="cuda"), torch.zeros(B, 128, device="cuda")
+    yb = torch.empty(B, L, 18, device="cuda")
+    hnd = model._handle()
+
+    def raw_encode():
+        _lib.check(_lib.lib().fpc_encode(hnd, cbh.handle, x20.data_ptr(), B, L, float(cfg["l1"]), float(cfg["l2"]), 1,
+                                         *[t.data_ptr() for t in bufs], sym.data_ptr(), hist.data_ptr(), None,
+                                         _lib.stream_ptr()), "fpc_encode")
+
+    def raw_forward():
+        _lib.check(_lib.lib().fpc_predictor_forward(hnd, x20.data_ptr(), B, L, s1.data_ptr(), s2.data_ptr(), yb.data_ptr(),
+                                                    _lib.stream_ptr()), "fpc_predictor_forward")
+    enc_ms = min(ev_ms(raw_encode) for _ in range(3))
+    fwd_ms = min(ev_ms(raw_forward) for _ in range(3))
+    model.check()
+    # ---- the training step at the reference's batch (train_frame.py:198-204: 100 x 150 frames), SURVEY 8(f) row 4 ----
+    from fpcodec_amd.train_frame import Trainer
+    tm = Wavernn(in_features=20, gru_units1=384, gru_units2=128, fc_units=18)
+    tm.load_state_dict(synth.predictor_state_dict())
+    tfeat = torch.from_numpy(synth.predictor_features(100, 150, utt0=6000)).cuda()
+    tr = Trainer(tm)
+    tr.step(tfeat)
+    torch.cuda.synchronize()
+    tt0 = time.perf_counter()
+    for _ in range(5):
+        tloss = tr.step(tfeat)
+    torch.cuda.synchronize()
+    train_ms = (time.perf_counter() - tt0) / 5 * 1e3
     coded = float(i2.sum())  # frames whose residual took the 2-stage search (the others: one stage of 512)
     enc_flop = B * L * PRED_FLOP_PER_FRAME + coded * VQ2_FLOP + (B * L - coded) * VQ1_FLOP
     sizes = load_codebooks(cfg["cb_path"], cfg["scl_cb_path"], cfg["bl_cb_path"], cfg["bl_scl_cb_path"]).sizes
@@ -241,7 +274,7 @@ def e2e_config5(voc, torch, synth, parallel, rank, world, L=300):
            "decode_features_ms": (t4 - t3) * 1e3,
            "predictor_roofline": {
                "bound": "mfma", "unit": "TFLOP/s", "peak": PEAK_F32_TFLOPS, "kernel": "k_encode_wsd",
-               "kernel_ms": enc_ms, "achieved": enc_flop / (enc_ms * 1e-3) / 1e12,
+               "kernel_ms": enc_ms, "call_ms": enc_call_ms, "achieved": enc_flop / (enc_ms * 1e-3) / 1e12,
                "frac": enc_flop / (enc_ms * 1e-3) / 1e12 / PEAK_F32_TFLOPS,
                "forward_kernel": "k_forward_ws", "forward_ms": fwd_ms,
                "forward_achieved": B * L * PRED_FLOP_PER_FRAME / (fwd_ms * 1e-3) / 1e12,
@@ -249,8 +282,14 @@ def e2e_config5(voc, torch, synth, parallel, rank, world, L=300):
                "algorithmic_flop": enc_flop,
                "note": "SURVEY 8(d): 1 328 640 FLOP per frame and utterance for the GRU rows and the output layer + the float64 "
                        "searches (2 x 51 flop per entry and target: 1 + 5 scans of 1 024 entries above the threshold, one of 512 "
-                       "below it), against the dense f32 MFMA peak; HIP events on the launch stream around one call "
-                       "(memset + kernel + histogram kernel)"}}
+                       "below it), against the dense f32 MFMA peak; kernel_ms / forward_ms: HIP events on the launch stream around "
+                       "one raw C-ABI call (granule memset + kernel + the empty fallback launch + histogram kernel), best of 3; "
+                       "call_ms: around Wavernn.encoder (adds the histogram download and the status synchronisation)"},
+           "train_step": {"batch": 100, "frames": 150, "step_ms": train_ms, "frames_per_s": 100 * 150 / (train_ms * 1e-3),
+                          "loss": float(tloss),
+                          "note": "fpc_trainer_step, 5 steps back to back (host clock): forward k_forward_ws<true>, loss, "
+                                  "backward k_train_bwd_ws, weight gradients on f32 MFMA, Adam (train_frame.py:53-120)"},
+           "gpu_time_s": (t2 - t0) + (t4 - t2) + (enc_call_ms + 6 * (enc_ms + fwd_ms)) * 1e-3 + 6 * train_ms * 1e-3}
     if rank == 0:  # framing figures on rank 0's share (the arithmetic coder is plain Python: a sample of it)
         idx_h = idx.cpu().numpy()
         fixed_bits = bitstream.bits_per_frame(idx_h, sizes)
@@ -444,6 +483,10 @@ def main():
                             "rtf_per_stream": samples_step / (msv / 1e3) / B / 16000.0}
         if e2e is not None:
             out["e2e"] = e2e
+        # how long the GPU worked inside this process (host clock around synchronised sections; the rest of the run is input
+        # synthesis and, at --gpus 1, the CPU baseline): timed steps + warm-up + the e2e legs + the two latency views
+        out["gpu_time_s"] = float(dt_local) + args.warmup * dec_s + (e2e["gpu_time_s"] if e2e is not None else 0.0) + \
+            2 * ms1 / 1e3 + 2 * msv / 1e3
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)

@@ -1267,12 +1267,12 @@ __global__ void k_colsum(const GradJobs J, int N) {
     if (r >= R) return;
     float s = 0.0f;
     int n = 0;
-    for (; n + 32 <= N; n += 32) {  // the adds stay in order; 32 loads in flight ahead of them
-        float v[32];
+    for (; n + 64 <= N; n += 64) {  // the adds stay in order; 64 loads in flight ahead of them (a wave's limit; latency-bound)
+        float v[64];
 #pragma unroll
-        for (int u = 0; u < 32; ++u) v[u] = D[(size_t)(n + u) * R + r];
+        for (int u = 0; u < 64; ++u) v[u] = D[(size_t)(n + u) * R + r];
 #pragma unroll
-        for (int u = 0; u < 32; ++u) s = s + v[u];
+        for (int u = 0; u < 64; ++u) s = s + v[u];
     }
     for (; n < N; ++n) s = s + D[(size_t)n * R + r];
     out[r] = s;
