@@ -79,7 +79,7 @@ struct WsArgs {
 };
 
 struct __attribute__((aligned(16))) WsLds : SearchLds {
-    float x[WIN * WG];        // input image [k][utterance, swizzled: ws_xi]; state images [k][utterance]
+    float x[WIN * WG];        // input image and state images [k][utterance]
     float h1[WH1 * WG];
     float h2[WH2 * WG];
     float pI[2][3][256];      // segment sums as the MFMA leaves them: [frame parity][gate][ws_tile(unit, utterance)]
@@ -449,11 +449,11 @@ __device__ __forceinline__ f32x4ws ws_mfma(float a, float b, f32x4ws c) { return
 // group (c = 0..7 of one q) hit 8 different bank quads (a plain 16-float pitch: two, a 4-way conflict on every store of every
 // product); a gate thread's 4-byte read covers two columns of different parity x 16 utterances = 32 different banks.
 __device__ __forceinline__ int ws_tile(int c, int u) { return c * 16 + (u ^ (((c >> 1) & 3) << 2)); }
-// The input image x: [k][16 utterances] with the utterance XOR-swizzled by the row pair (k < 20: ten different values).  As an
-// MFMA operand lane (utterance, k % 4) reads 2 rows of different parity x 16 utterances = 32 banks per half; the closed
-// loops WRITE it one utterance per half-wave, lane m = row m: 16 m + u puts the 18 rows into two banks (a 9-way conflict),
-// 16 m + (u ^ (m >> 1)) into 18 different ones.
-__device__ __forceinline__ int ws_xi(int k, int u) { return k * 16 + (u ^ ((k >> 1) & 15)); }
+// The input image x: [k][16 utterances], plain.  (The closed loops write it one utterance per half-wave, lane m = row m: a 9-way
+// bank conflict on 2 stores per frame; XOR-swizzling the utterance by the row pair removes it and was measured SLOWER -- the five
+// A-operand reads of I = W1i x, which sit on the frame's chain, need their addresses formed per k-step: encode 4.05 against
+// 4.01 ms, same box, profiles/r05_ablations.txt.)
+__device__ __forceinline__ int ws_xi(int k, int u) { return k * 16 + u; }
 __device__ __forceinline__ void ws_put(float* p, int lane, const f32x4ws& acc) {
     *reinterpret_cast<f32x4ws*>(&p[ws_tile(lane & 15, 4 * (lane >> 4))]) = acc;  // utterances 4 q .. 4 q + 3 of column c
 }
@@ -807,7 +807,8 @@ __device__ __forceinline__ bool ws_foreground(const WsCtx& X, WsLds& L, const Ws
     if (fw == 0) {  // GRU2 gates: 4 units x 16 utterances
         const int base = X.slice * WV2;
         const int v = lane;
-        const int vr = ws_tile(v >> 4, v & 15), vz = ws_tile(4 + (v >> 4), v & 15), vn = ws_tile(8 + (v >> 4), v & 15);  // columns gate * 4 + unit
+        // columns gate * 4 + unit: the swizzle of column 4 + unit is that of column unit with bit 3 flipped, of column 8 + unit the same
+        const int vr = ws_tile(v >> 4, v & 15), vz = (vr ^ 8) + 64, vn = vr + 128;
         const float gir = (L.pC[0][vr] + L.pC[1][vr]) + (L.pC[2][vr] + L.pC[3][vr]);
         const float giz = (L.pC[0][vz] + L.pC[1][vz]) + (L.pC[2][vz] + L.pC[3][vz]);
         const float gin = (L.pC[0][vn] + L.pC[1][vn]) + (L.pC[2][vn] + L.pC[3][vn]);

@@ -82,51 +82,64 @@ FPC_API int fpc_predictor_create(const fpc_predictor_weights* w, fpc_predictor**
 FPC_API void fpc_predictor_destroy(fpc_predictor* p);
 
 /* Kernel forms of the predictor.  All give the same bits (every row is evaluated in the canonical order of
- * oracle/fpc_oracle.c, matvec_seg); the tests compare them with each other and with the oracle.
+ * oracle/fpc_oracle.c, matvec_seg / matvec_t); the tests compare them with each other and with the oracle.
  *
- * (1) Weights-stationary (csrc/predictor_ws.h) -- what fpc_predictor_forward, fpc_encode and fpc_decode_features run for the
- *     reference's production shape (20 -> 384 -> 128 -> 18) on a whole MI355X (>= 256 CUs) unless a row split is pinned
- *     (below) or the codebooks exceed the limits of its search (more than 1 024 entries in a stage, more than 256 codes in
- *     a scalar book).  Utterances are taken in GROUPS of 16 (= the M dimension of one f32 MFMA tile); a group runs on 32
- *     workgroups, which the launch arranges to be the 32 CUs of one XCD (8 groups = 128 utterances fill the chip; more
- *     groups follow as workgroups retire; a partly filled last group costs what a full one does).  Each workgroup keeps
- *     1/32 of every weight matrix in LDS for the whole launch; the new state values go round as 16-byte granules
- *     {epoch, 3 values} in a block that belongs to the predictor handle and is cleared on the stream before each launch.
- *     fpc_trainer_step's forward is the same kernel (the activations the backward pass keeps are stored by the workgroups
- *     that evaluate them); the teacher-forced kernels take the output layer and the input product off the frame's chain.
- * (2) Row split (csrc/predictor.hip, predictor_df.h) -- every other shape, FPC_PRED_WS=0, a pinned split, and the training
- *     step's backward pass (and its forward under those switches): one utterance on 1, 2, 4 or 8 workgroups (one CU
- *     each) while the batch leaves CUs idle (B x n <= number of CUs), the slices of the recurrent state exchanged as tagged 8-byte words; weights streamed from L2 every frame.
- *     Two-role kernels (three waves walk a frame's latency chain, the others stream the recurrent products; LDS counters
- *     instead of workgroup barriers), or with FPC_PRED_DF=0 the phase-after-phase kernels (the tests' reference form); the
- *     training step's forward follows the same switch.
+ * (1) Weights-stationary (csrc/predictor_ws.h, predictor_wsd.h, predictor_bwd_ws.h) -- what fpc_predictor_forward,
+ *     fpc_encode, fpc_decode_features and fpc_trainer_step (forward AND backward pass) run for the reference's production
+ *     shape (20 -> 384 -> 128 -> 18) on a whole MI355X (>= 256 CUs) unless a row split is pinned (below) or the codebooks
+ *     exceed the limits of its search (more than 1 024 entries in a stage, more than 256 codes in a scalar book).
+ *     Utterances are taken in GROUPS of 16 (= the M dimension of one f32 MFMA tile); a group runs on 32 workgroups, which
+ *     the launch arranges to be the 32 CUs of one XCD (8 groups = 128 utterances fill the chip; more groups follow as
+ *     workgroups retire; a partly filled last group costs what a full one does).  Each workgroup keeps 1/32 of every
+ *     weight matrix on chip for the whole launch; the new state values (backward: the gate gradients) go round as 16-byte
+ *     granules {epoch, 3 values} in a block that belongs to the predictor handle and is cleared on the stream before each
+ *     launch, two granule sets per hop used by frame parity.
+ * (2) Row split (csrc/predictor.hip, predictor_df.h) -- the generic-shape family: every other shape, FPC_PRED_WS=0, a
+ *     pinned split, and the FALLBACK of (1): one utterance on 1, 2, 4 or 8 workgroups (one CU each) while the batch leaves
+ *     CUs idle (B x n <= number of CUs), the slices of the recurrent state exchanged as tagged 8-byte words; weights
+ *     streamed from L2 every frame.  Two-role kernels: three waves walk a frame's latency chain, the others stream the
+ *     recurrent products; LDS counters instead of workgroup barriers.
+ * Residency -- what (1) needs and what happens without it.  The frame loop of (1) needs all 32 workgroups of a group
+ *     RESIDENT at once (each spins for the others' granules; one workgroup per CU: ~150 kB of LDS), and nothing guarantees
+ *     that: another process, or this library's own vocoder launch on a side stream, may hold CUs for as long as it runs.
+ *     So every group DECIDES once, before anything is computed or written: each workgroup publishes a hello granule and
+ *     waits at most 10 ms for the other 31; the first to see them all proposes GO, the first to lose patience FALLBACK (one
+ *     compare-and-swap on a word of the granule block, the first proposal wins, every workgroup of the group -- also those
+ *     dispatched later -- adopts it).  GO: all 32 exist and stay resident; the launch runs as described.  FALLBACK: every
+ *     workgroup of the group returns at once, and the row-split launch (2) that every entry point queues BEHIND its
+ *     weights-stationary launch on the same stream -- one workgroup per utterance, no partner to wait for -- serves exactly
+ *     the groups that decided so (normally none: B workgroups that read one word and return, ~4 us).  Slower, never
+ *     wrong, never a timeout: fpc_encode beside a long fpc_lpcnet_synthesize on another stream returns the quiet run's
+ *     bits (tests).  fpc_predictor_fallback_groups() reports how many groups of the last launch took that route.
+ *     Row split with n > 1 (automatic only for shapes / switches that select (2) as the first choice) has no such
+ *     decision: it assumes the process owns the GPU; shared-GPU deployments of those pin one workgroup per utterance
+ *     with fpc_predictor_set_split(p, 1) (or FPC_PRED_SPLIT=0), as bench.py does when ranks share a device.
  * Common to (1) and (2):
- *  - ASSUMPTION: the process owns the GPU.  Both forms count on every workgroup of a group being dispatched at once; a
- *    co-tenant kernel that occupies CUs for longer than the bound below makes such a launch fail.  Shared-GPU
- *    deployments pin one workgroup per utterance with fpc_predictor_set_split(p, 1) (or FPC_PRED_SPLIT=0).
  *  - Placement is arranged for, checked, never assumed.  Blocks b and b + 8 are observed to land on one XCD (round-robin
  *    dealing), so the workgroups of a group get block indices 8 apart; each reads its XCD id from the hardware register
- *    (s_getreg_b32 HW_REG_XCC_ID), the ids go round once through the general path, and only if ALL agree the exchange uses
- *    plain stores, which stay in that XCD's L2 where the partners' L1-bypassing (sc1) loads find them (measured:
- *    tools/ubench/ub5.hip -- plain stores are seen by sc1 loads inside an XCD, never across XCDs).  Otherwise -- and always
- *    with FPC_FAST_HOP=0, which the tests use to run this path on a one-XCD placement -- every exchanged value is written
- *    through (sc1 stores).  A different dealing, or a wrong XCD id, therefore costs speed (1.35k against 2.0k cycles per
- *    hop), never correctness: the general path assumes nothing about where a workgroup runs.
- *  - A spin that does not see its partner within 1 s of wall clock gives up, never hangs: the launch stores NaN (floats)
- *    and -2 (symbols) for the utterance (row split: from that frame on; weights-stationary: for the whole group from that
- *    frame on), counts those frames in no histogram, the training step skips its Adam update,
- *    and the handle's sticky status word turns every later call on the handle -- and, at once, every call that
- *    synchronises anyway (fpc_decode_features, fpc_trainer_step with loss_host, fpc_trainer_export) -- into
- *    FPC_ERR_TIMEOUT with text in fpc_last_error(), until fpc_predictor_status() has reported and cleared it.
- *    The asynchronous entry points (fpc_predictor_forward, fpc_encode) therefore return FPC_OK for the failing launch
- *    itself: a caller that consumes their outputs without another call on the handle asks fpc_predictor_status() first.
+ *    (s_getreg_b32 HW_REG_XCC_ID), the ids go round with the hello granules through the general path, and only if ALL
+ *    agree the exchange uses plain stores, which stay in that XCD's L2 where the partners' L1-bypassing (sc1) loads find
+ *    them (measured: tools/ubench/ub5.hip -- plain stores are seen by sc1 loads inside an XCD, never across XCDs).
+ *    Otherwise -- and always with FPC_FAST_HOP=0, which the tests use to run this path on a one-XCD placement -- every
+ *    exchanged value is written through (sc1 stores).  A different dealing, or a wrong XCD id, therefore costs speed,
+ *    never correctness: the general path assumes nothing about where a workgroup runs.
+ *  - Once a group runs, a spin that does not see its partner within 1 s of wall clock gives up, never hangs (a partner
+ *    that WAS there and stopped answering: a real failure, not a placement question): the launch stores NaN (floats) and
+ *    -2 (symbols) for the utterance (row split: from that frame on; weights-stationary: for the whole group from the
+ *    frame before on), counts those frames in no histogram, the training step skips its Adam update, and the handle's
+ *    sticky status word turns every later call on the handle -- and, at once, every call that synchronises anyway
+ *    (fpc_decode_features, fpc_trainer_step with loss_host, fpc_trainer_export) -- into FPC_ERR_TIMEOUT with text in
+ *    fpc_last_error(), until fpc_predictor_status() has reported and cleared it.  The asynchronous entry points
+ *    (fpc_predictor_forward, fpc_encode) therefore return FPC_OK for the failing launch itself: a caller that consumes
+ *    their outputs without another call on the handle asks fpc_predictor_status() first.
  *  - Launches of ONE handle may be issued on different streams: a call on another stream first waits (on the device)
  *    for the handle's previous launch.  Creating and destroying handles is thread-safe; calls on one handle are not.
  * Environment: FPC_PRED_WS=0 never the weights-stationary kernels; FPC_PRED_SPLIT=0 one workgroup per utterance, 2|4|8
- * exactly that many (either selects the row-split kernels); FPC_PRED_DF=0 the phase kernels; FPC_FAST_HOP=0 the
- * write-through exchange everywhere; FPC_WS_TAIL=pair the encoder's search on an owner + helper workgroup per utterance
- * instead of distributed over the group (the tests' second form, same bits); FPC_SPIN_LIMIT_US / FPC_TEST_WITHHOLD_PUBLISH are test hooks (a shorter bound; the
- * last workgroup of utterance 0 / group 0 never publishes). */
+ * exactly that many (either selects the row-split kernels); FPC_TRAIN_BWD_ROWSPLIT=1 the training step's backward pass on
+ * the row-split kernel; FPC_FAST_HOP=0 the write-through exchange everywhere.  Test hooks: FPC_SPIN_LIMIT_US /
+ * FPC_HELLO_LIMIT_US (shorter bounds of the frame loop's wait / of the residency decision), FPC_TEST_WITHHOLD_PUBLISH=1
+ * (the last workgroup of utterance 0 / group 0 never publishes a frame's values: the give-up path) or =hello (not even its
+ * hello: stands for a workgroup that is not resident: the fallback path). */
 
 /* Synchronises the device and returns what the launches on the handle have reported: FPC_OK, FPC_ERR_TIMEOUT (a
  * row-split exchange gave up) or FPC_ERR_NONFINITE (a NaN / infinite residual reached a quantizer in fpc_encode: those
