@@ -1195,7 +1195,31 @@ struct GradJobs {  // the five weight matrices of the predictor in one launch (b
     int K[5], R[5];
 };
 constexpr int GSEG = 8;  // sample segments per gradient tile (oracle: ORC_GSEG)
+// bias gradient of column r of job `job`: plain sum over the samples in ascending order (grad_w of the oracle)
+__device__ __forceinline__ void colsum(const GradJobs& J, int N, int job, int r) {
+    const float* __restrict__ D = J.D[job];
+    float* __restrict__ out = J.bsum[job];
+    const int R = J.R[job];
+    if (r >= R) return;
+    float s = 0.0f;
+    int n = 0;
+    for (; n + 64 <= N; n += 64) {  // the adds stay in order; 64 loads in flight ahead of them (a wave's limit; latency-bound)
+        float v[64];
+#pragma unroll
+        for (int u = 0; u < 64; ++u) v[u] = D[(size_t)(n + u) * R + r];
+#pragma unroll
+        for (int u = 0; u < 64; ++u) s = s + v[u];
+    }
+    for (; n < N; ++n) s = s + D[(size_t)n * R + r];
+    out[r] = s;
+}
+// grid z: 5 GSEG slices of MFMA tiles, then 5 slices (one per job, blockIdx.y = 0 only) of bias sums: those are strictly
+// sequential adds, latency-bound on a few waves (0.18 ms as a launch of their own) -- beside the tiles they cost nothing
 __global__ __launch_bounds__(256) void k_grad_tn(const GradJobs J, int N, int seglen) {
+    if (blockIdx.z >= 5 * GSEG) {
+        if (blockIdx.y == 0) colsum(J, N, blockIdx.z - 5 * GSEG, blockIdx.x * 256 + threadIdx.x);
+        return;
+    }
     const int job = blockIdx.z / GSEG, sg = blockIdx.z % GSEG;
     const float* __restrict__ A = J.A[job];
     const float* __restrict__ D = J.D[job];
@@ -1247,8 +1271,16 @@ __global__ void k_transpose(const float* __restrict__ src, int K, int R, float* 
     dst[i] = src[(size_t)k * R + r];
 }
 
-// segment sums -> gradient, balanced tree
-__global__ void k_grad_reduce(const GradJobs J) {
+// segment sums -> gradient, balanced tree; one thread also latches the handle's status word for the Adam launches behind it:
+// the word lives in host memory (one PCIe round trip per reader), so it is copied into device memory once per step.
+// latch[0] = the status word, latch[1] = the number of steps whose update was applied (the host's step counter, and with it
+// Adam's bias corrections, follows this count after a failed step: fpc_trainer_step)
+__global__ void k_grad_reduce(const GradJobs J, const unsigned* status, unsigned* latch) {
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
+        const unsigned st = status_load(status);
+        latch[0] = st;
+        if (st == 0u) latch[1] += 1u;
+    }
     const int job = blockIdx.y;
     const size_t n = (size_t)J.K[job] * J.R[job];
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1257,37 +1289,7 @@ __global__ void k_grad_reduce(const GradJobs J) {
     J.C[job][i] = ((p[i] + p[n + i]) + (p[2 * n + i] + p[3 * n + i])) + ((p[4 * n + i] + p[5 * n + i]) + (p[6 * n + i] + p[7 * n + i]));
 }
 
-// bias gradient: plain sum over the samples in ascending order
-__global__ void k_colsum(const GradJobs J, int N) {
-    const int job = blockIdx.y;
-    const float* __restrict__ D = J.D[job];
-    float* __restrict__ out = J.bsum[job];
-    const int R = J.R[job];
-    const int r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= R) return;
-    float s = 0.0f;
-    int n = 0;
-    for (; n + 64 <= N; n += 64) {  // the adds stay in order; 64 loads in flight ahead of them (a wave's limit; latency-bound)
-        float v[64];
-#pragma unroll
-        for (int u = 0; u < 64; ++u) v[u] = D[(size_t)(n + u) * R + r];
-#pragma unroll
-        for (int u = 0; u < 64; ++u) s = s + v[u];
-    }
-    for (; n < N; ++n) s = s + D[(size_t)n * R + r];
-    out[r] = s;
-}
-
 // torch.optim.Adam, single-tensor path (betas 0.9 / 0.999, eps 1e-8, no weight decay)
-// the handle's status word lives in host memory (one PCIe round trip per reader): one thread copies it into device memory
-// once per step, and the ten Adam launches read the copy
-// latch[0] = the status word, latch[1] = the number of steps whose update was applied (the host's step counter, and with it
-// Adam's bias corrections, follows this count after a failed step: fpc_trainer_step)
-__global__ void k_latch_status(const unsigned* status, unsigned* latch) {
-    const unsigned st = status_load(status);
-    latch[0] = st;
-    if (st == 0u) latch[1] += 1u;
-}
 __global__ void k_adam(float* __restrict__ p, float* __restrict__ m, float* __restrict__ v, const float* __restrict__ g,
                        size_t n, float step_size, float bc2_sqrt, const unsigned* __restrict__ latch) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -2013,13 +2015,12 @@ extern "C" int fpc_trainer_step(fpc_trainer* t, const float* feat_dev, int B, in
         maxK = g.K > maxK ? g.K : maxK;
     }
     const int seglen = ((N + 4 * GSEG - 1) / (4 * GSEG)) * 4;
-    hipLaunchKernelGGL(k_grad_tn, dim3((maxR + 255) / 256, (maxK + 15) / 16, 5 * GSEG), dim3(256), 0, st, J, N, seglen);
-    hipLaunchKernelGGL(k_grad_reduce, dim3((unsigned)(((size_t)maxK * maxR + 255) / 256), 5), dim3(256), 0, st, J);
-    hipLaunchKernelGGL(k_colsum, dim3((maxR + 63) / 64, 5), dim3(64), 0, st, J, N);
+    hipLaunchKernelGGL(k_grad_tn, dim3((maxR + 255) / 256, (maxK + 15) / 16, 5 * GSEG + 5), dim3(256), 0, st, J, N, seglen);
+    hipLaunchKernelGGL(k_grad_reduce, dim3((unsigned)(((size_t)maxK * maxR + 255) / 256), 5), dim3(256), 0, st, J, p->status_dev,
+                       t->latch.as<unsigned>());
     t->step += 1;
     const double bc1 = 1.0 - pow(0.9, t->step), bc2 = 1.0 - pow(0.999, t->step);
     const float step_size = (float)(lr / bc1), bc2_sqrt = (float)sqrt(bc2);
-    hipLaunchKernelGGL(k_latch_status, dim3(1), dim3(1), 0, st, p->status_dev, t->latch.as<unsigned>());
     for (int k = 0; k < 10; ++k)
         hipLaunchKernelGGL(k_adam, dim3((unsigned)((t->sz[k] + 255) / 256)), dim3(256), 0, st, param_ptr(p, k),
                            t->m[k].as<float>(), t->v[k].as<float>(), t->grad[k].as<float>(), t->sz[k], step_size, bc2_sqrt,

@@ -448,7 +448,10 @@ __device__ __forceinline__ f32x4ws ws_mfma(float a, float b, f32x4ws c) { return
 // accumulator of lane (c, q) = utterances 4 q .. 4 q + 3 of column c goes out as ONE 16-byte store: the 8 lanes of a store
 // group (c = 0..7 of one q) hit 8 different bank quads (a plain 16-float pitch: two, a 4-way conflict on every store of every
 // product); a gate thread's 4-byte read covers two columns of different parity x 16 utterances = 32 different banks.
-__device__ __forceinline__ int ws_tile(int c, int u) { return c * 16 + (u ^ (((c >> 1) & 3) << 2)); }
+#ifndef FPC_WS_TILESWZ
+#define FPC_WS_TILESWZ 1
+#endif
+__device__ __forceinline__ int ws_tile(int c, int u) { return FPC_WS_TILESWZ ? c * 16 + (u ^ (((c >> 1) & 3) << 2)) : c * 16 + u; }
 // The input image x: [k][16 utterances], plain.  (The closed loops write it one utterance per half-wave, lane m = row m: a 9-way
 // bank conflict on 2 stores per frame; XOR-swizzling the utterance by the row pair removes it and was measured SLOWER -- the five
 // A-operand reads of I = W1i x, which sit on the frame's chain, need their addresses formed per k-step: encode 4.05 against
@@ -808,7 +811,7 @@ __device__ __forceinline__ bool ws_foreground(const WsCtx& X, WsLds& L, const Ws
         const int base = X.slice * WV2;
         const int v = lane;
         // columns gate * 4 + unit: the swizzle of column 4 + unit is that of column unit with bit 3 flipped, of column 8 + unit the same
-        const int vr = ws_tile(v >> 4, v & 15), vz = (vr ^ 8) + 64, vn = vr + 128;
+        const int vr = ws_tile(v >> 4, v & 15), vz = FPC_WS_TILESWZ ? (vr ^ 8) + 64 : vr + 64, vn = vr + 128;
         const float gir = (L.pC[0][vr] + L.pC[1][vr]) + (L.pC[2][vr] + L.pC[3][vr]);
         const float giz = (L.pC[0][vz] + L.pC[1][vz]) + (L.pC[2][vz] + L.pC[3][vz]);
         const float gin = (L.pC[0][vn] + L.pC[1][vn]) + (L.pC[2][vn] + L.pC[3][vn]);
