@@ -703,15 +703,17 @@ __device__ __forceinline__ bool ws_gather1(const WsCtx& X, WsLds& L, int p, unsi
 // h2(t) and whose frame is as long as its wave 0's path).  The owned utterance's values also go to L.h2own (ws_F_rows).
 template <int SHARE>
 __device__ __forceinline__ bool ws_gather2(const WsCtx& X, WsLds& L, int p, unsigned epoch) {
-    constexpr int NP = 64 * SHARE, NG = (WNS * WQ2 + NP - 1) / NP;
+    // thread p of NP: slice p / TPS, granules p % TPS + TPS k of it (shifts and masks: this runs on the frame's chain, and a
+    // division by 22 per granule was 2 % of the forward's frame)
+    constexpr int NP = 64 * SHARE, TPS = NP / WNS, NG = (WQ2 + TPS - 1) / TPS;
+    static_assert(NP % WNS == 0 && (TPS & (TPS - 1)) == 0, "threads per slice: a power of two");
     const int set = WOFF_H2 + (int)((epoch - 1u) & 1u) * WNS * WQ2;  // (epoch = frame + 1)
     int gi[NG], sl[NG], e[NG];
 #pragma unroll
     for (int j = 0; j < NG; ++j) {
-        const int i = p + NP * j;
-        sl[j] = i / WQ2;
-        e[j] = i - sl[j] * WQ2;
-        gi[j] = (i < WNS * WQ2 && sl[j] != X.slice) ? set + i : -1;
+        sl[j] = p / TPS;
+        e[j] = (p & (TPS - 1)) + TPS * j;
+        gi[j] = (e[j] < WQ2 && sl[j] != X.slice) ? set + sl[j] * WQ2 + e[j] : -1;
     }
     u32x4 v[NG];
     if (!ws_poll<NG>(X, L, gi, epoch, v)) return false;
