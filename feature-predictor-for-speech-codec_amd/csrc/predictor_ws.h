@@ -39,6 +39,9 @@ typedef float f32x4ws __attribute__((ext_vector_type(4)));
 #ifndef FPC_WS_A_SPLIT
 #define FPC_WS_A_SPLIT 0  // the teacher-forced forward's A(t+1): first unit's chain beside C(t), the rest behind it (ws_A)
 #endif
+#ifndef FPC_WS_HOIST
+#define FPC_WS_HOIST 1  // teacher-forced forward: lane-constant address arithmetic may leave the frame loop (the closed loops keep it inside: registers)
+#endif
 #ifndef FPC_WS_POLL_DELAY
 #define FPC_WS_POLL_DELAY 0  // x 64 cycles before the first poll of a hop
 #endif
@@ -744,7 +747,7 @@ __device__ __forceinline__ void wsd_F(WsLds& L, const WsRegs& R, int fw, int lan
 template <bool EARLY_I = false, bool FC_ALL = false, bool FC_LATE = false, bool SAVE = false>
 __device__ __forceinline__ bool ws_foreground(const WsCtx& X, WsLds& L, const WsRegs& R, int t, int ft0, int& fg_epoch,
                                               const WsSave* sv = nullptr) {
-    const int ft = ft0 + ws_opaque_zero();
+    const int ft = ft0 + (FPC_WS_HOIST && EARLY_I ? 0 : ws_opaque_zero());
     const int fw = ft0 >> 6, lane = ft & 63;
     const unsigned epoch = (unsigned)t + 1u;
     // (EARLY_I: the caller has waited for I(t) AND A(t) in one poll loop -- k_forward_ws at the top of its frame loop, before x(t + 1)
@@ -878,7 +881,7 @@ __device__ __forceinline__ bool ws_foreground(const WsCtx& X, WsLds& L, const Ws
 template <bool EARLY_I = false, bool FC_LATE = false, bool TANH_ONLY = false>
 __device__ __forceinline__ bool ws_background(const WsCtx& X, WsLds& L, const WsRegs& R, int t, bool last, int bt,
                                               float* y_late = nullptr) {
-    const int bw = bt >> 6, lane = (bt + ws_opaque_zero()) & 63;
+    const int bw = bt >> 6, lane = (bt + (FPC_WS_HOIST && EARLY_I ? 0 : ws_opaque_zero())) & 63;
     if (!df_wait(&L.sig[WSIG_P1], WFG * (t + 1), &L.dead)) return false;
     WBSTAMP(13)
     if (bw == 0) {  // the two waves of SIMD 0 run no matrix product beside the chain: B(t) under hop 1, then hop 2's gather
