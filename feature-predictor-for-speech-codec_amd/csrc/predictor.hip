@@ -1195,6 +1195,10 @@ struct GradJobs {  // the five weight matrices of the predictor in one launch (b
     int K[5], R[5];
 };
 constexpr int GSEG = 8;  // sample segments per gradient tile (oracle: ORC_GSEG)
+#ifndef FPC_GKT
+#define FPC_GKT 4
+#endif
+constexpr int GKT = FPC_GKT;  // 16-row k tiles per wave of k_grad_tn
 // bias gradient of column r of job `job`: plain sum over the samples in ascending order (grad_w of the oracle)
 __device__ __forceinline__ void colsum(const GradJobs& J, int N, int job, int r) {
     const float* __restrict__ D = J.D[job];
@@ -1226,23 +1230,33 @@ __global__ __launch_bounds__(256) void k_grad_tn(const GradJobs J, int N, int se
     const int K = J.K[job], R = J.R[job];
     float* __restrict__ C = J.part[job] + (size_t)sg * K * R;
     const int nbeg = sg * seglen, nend = (sg + 1) * seglen < N ? (sg + 1) * seglen : N;
-    if ((int)blockIdx.y * 16 >= K) return;
+    // one wave = GKT x 16 k-rows x 64 r-columns: GKT A fragments + 4 D fragments per 4 samples feed 4 GKT MFMAs (round 5: GKT = 4,
+    // 0.5 loads per MFMA; 16 k-rows per wave was 1.25 and L2-bound at 21 % of the f32 MFMA peak)
+    if ((int)blockIdx.y * 16 * GKT >= K) return;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int k0 = blockIdx.y * 16, r0 = (blockIdx.x * 4 + wave) * 64;
+    const int k0 = blockIdx.y * 16 * GKT, r0 = (blockIdx.x * 4 + wave) * 64;
     if (r0 >= R) return;
     const int fi = lane & 15, kq = lane >> 4;
-    const int ka = k0 + fi;
-    f32x4 acc[4];
+    f32x4 acc[GKT][4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    constexpr int UN = 8;  // groups of 4 samples fetched ahead of the MFMA chain (which stays in sample order)
+    for (int kt = 0; kt < GKT; ++kt)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[kt][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#ifndef FPC_GUN
+#define FPC_GUN 4
+#endif
+    constexpr int UN = FPC_GUN;  // groups of 4 samples fetched ahead of the MFMA chains (which stay in sample order)
     for (int n0 = nbeg; n0 < nend; n0 += 4 * UN) {
-        float a[UN], d[UN][4];
+        float a[UN][GKT], d[UN][4];
 #pragma unroll
         for (int u = 0; u < UN; ++u) {
             const int n = n0 + 4 * u + kq;
             const bool vn = n < nend;
-            a[u] = (vn && ka < K) ? A[(size_t)n * K + ka] : 0.0f;
+#pragma unroll
+            for (int kt = 0; kt < GKT; ++kt) {
+                const int ka = k0 + 16 * kt + fi;
+                a[u][kt] = (vn && ka < K) ? A[(size_t)n * K + ka] : 0.0f;
+            }
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int rc = r0 + 16 * j + fi;
@@ -1252,15 +1266,19 @@ __global__ __launch_bounds__(256) void k_grad_tn(const GradJobs J, int N, int se
 #pragma unroll
         for (int u = 0; u < UN; ++u)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u], d[u][j], acc[j], 0, 0, 0);
+            for (int kt = 0; kt < GKT; ++kt)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[kt][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][kt], d[u][j], acc[kt][j], 0, 0, 0);
     }
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
+    for (int kt = 0; kt < GKT; ++kt)
 #pragma unroll
-        for (int v = 0; v < 4; ++v) {  // C/D layout: col = lane & 15, row = (lane >> 4) * 4 + reg
-            const int kr = k0 + kq * 4 + v, rc = r0 + 16 * j + fi;
-            if (kr < K && rc < R) C[(size_t)kr * R + rc] = acc[j][v];
-        }
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {  // C/D layout: col = lane & 15, row = (lane >> 4) * 4 + reg
+                const int kr = k0 + 16 * kt + kq * 4 + v, rc = r0 + 16 * j + fi;
+                if (kr < K && rc < R) C[(size_t)kr * R + rc] = acc[kt][j][v];
+            }
 }
 
 // dst[r][k] = src[k][r]: refreshes the torch-layout copies after an Adam step
@@ -2015,7 +2033,7 @@ extern "C" int fpc_trainer_step(fpc_trainer* t, const float* feat_dev, int B, in
         maxK = g.K > maxK ? g.K : maxK;
     }
     const int seglen = ((N + 4 * GSEG - 1) / (4 * GSEG)) * 4;
-    hipLaunchKernelGGL(k_grad_tn, dim3((maxR + 255) / 256, (maxK + 15) / 16, 5 * GSEG + 5), dim3(256), 0, st, J, N, seglen);
+    hipLaunchKernelGGL(k_grad_tn, dim3((maxR + 255) / 256, (maxK + 16 * GKT - 1) / (16 * GKT), 5 * GSEG + 5), dim3(256), 0, st, J, N, seglen);
     hipLaunchKernelGGL(k_grad_reduce, dim3((unsigned)(((size_t)maxK * maxR + 255) / 256), 5), dim3(256), 0, st, J, p->status_dev,
                        t->latch.as<unsigned>());
     t->step += 1;
