@@ -54,6 +54,7 @@ constexpr int WQ1 = WV1 / 3, WQ2 = (WV2 + 2) / 3;  // 16-byte granules per workg
 constexpr int WQX = WFC / 3;                     // granules of an utterance's next input row (hop 3): 6
 constexpr int WFG = 4, WBG = 4;                  // waves per role
 constexpr int W1G = WIN * WU1 + 20;                // pitch of a gate's block of W1i in LDS
+constexpr int WXP = 17;                          // pitch of a row of the input image (ws_xi)
 constexpr int WPF = 20;                          // pitch of an utterance's 18 output rows in pFa (16-byte stores, 8 lanes: 8 bank quads)
 constexpr int WFGT = WFG * 64;
 // granule block of a group, in 16-byte units: hello | h1 | h2 | next input (the receiver's third hop)
@@ -82,7 +83,7 @@ struct WsArgs {
 };
 
 struct __attribute__((aligned(16))) WsLds : SearchLds {
-    float x[WIN * WG];        // input image and state images [k][utterance]
+    float x[WIN * WXP + 4];   // input image [k][utterance], rows WXP = 17 floats apart (ws_xi); 344 floats: the next member stays 16-byte aligned
     float h1[WH1 * WG];
     float h2[WH2 * WG];
     float pI[2][3][256];      // segment sums as the MFMA leaves them: [frame parity][gate][ws_tile(unit, utterance)]
@@ -455,11 +456,12 @@ __device__ __forceinline__ f32x4ws ws_mfma(float a, float b, f32x4ws c) { return
 #define FPC_WS_TILESWZ 1
 #endif
 __device__ __forceinline__ int ws_tile(int c, int u) { return FPC_WS_TILESWZ ? c * 16 + (u ^ (((c >> 1) & 3) << 2)) : c * 16 + u; }
-// The input image x: [k][16 utterances], plain.  (The closed loops write it one utterance per half-wave, lane m = row m: a 9-way
-// bank conflict on 2 stores per frame; XOR-swizzling the utterance by the row pair removes it and was measured SLOWER -- the five
-// A-operand reads of I = W1i x, which sit on the frame's chain, need their addresses formed per k-step: encode 4.05 against
-// 4.01 ms, same box, profiles/r05_ablations.txt.)
-__device__ __forceinline__ int ws_xi(int k, int u) { return k * 16 + u; }
+// The input image x: [k][utterance] with rows 17 floats apart.  The closed loops write it one utterance per half-wave, lane m =
+// row m, the forward 20 consecutive floats of an utterance per 20 lanes: at a 16-float pitch one utterance's rows live in two
+// banks (9- and 16-way conflicts), at 17 in 20 different ones; as an MFMA operand lane (utterance, k % 4) still reads at a
+// constant offset per k-step.  (An XOR swizzle of a 16-float pitch also removes the conflicts but needs the address of every
+// k-step formed separately, on the closed loops' chain: encode 4.05 against 4.01 ms, same box.)
+__device__ __forceinline__ int ws_xi(int k, int u) { return k * WXP + u; }
 __device__ __forceinline__ void ws_put(float* p, int lane, const f32x4ws& acc) {
     *reinterpret_cast<f32x4ws*>(&p[ws_tile(lane & 15, 4 * (lane >> 4))]) = acc;  // utterances 4 q .. 4 q + 3 of column c
 }
@@ -541,7 +543,7 @@ __device__ __forceinline__ void ws_I(WsLds& L, float bias, int g, int lane, int 
     f32x4ws acc = {bias, bias, bias, bias};
     const float* ws = L.w1i + g * W1G + q * WU1 + cc;
 #pragma unroll
-    for (int j = 0; j < WIN / 4; ++j) acc = ws_mfma(L.x[ws_xi(4 * j + q, c)], ws[4 * WU1 * j], acc);
+    for (int j = 0; j < WIN / 4; ++j) acc = ws_mfma(L.x[ws_xi(4 * j + q, c)], ws[4 * WU1 * j], acc);  // (ws_I: the forward only)
     ws_put(L.pI[buf][g], lane, acc);
 }
 // The closed loop's form of I (x(t) is the previous frame's result: I is on the chain): foreground wave fw evaluates the
@@ -706,17 +708,19 @@ __device__ __forceinline__ bool ws_gather1(const WsCtx& X, WsLds& L, int p, unsi
 // h2(t) and whose frame is as long as its wave 0's path).  The owned utterance's values also go to L.h2own (ws_F_rows).
 template <int SHARE>
 __device__ __forceinline__ bool ws_gather2(const WsCtx& X, WsLds& L, int p, unsigned epoch) {
-    // thread p of NP: slice p / TPS, granules p % TPS + TPS k of it (shifts and masks: this runs on the frame's chain, and a
-    // division by 22 per granule was 2 % of the forward's frame)
-    constexpr int NP = 64 * SHARE, TPS = NP / WNS, NG = (WQ2 + TPS - 1) / TPS;
-    static_assert(NP % WNS == 0 && (TPS & (TPS - 1)) == 0, "threads per slice: a power of two");
+    // granule i = p + NP j of the hop's WNS x WQ2: consecutive lanes take consecutive granules (their image writes are
+    // consecutive floats: conflict-free; a slice per group of four lanes -- slices are 64 floats apart -- was an 8-way conflict
+    // on every write); slice = i / 22 by a multiply and a shift, exact for i < 1 489 (22 x 2 979 = 65 538)
+    constexpr int NP = 64 * SHARE, NG = (WNS * WQ2 + NP - 1) / NP;
+    static_assert(WQ2 == 22 && WNS * WQ2 < 1489, "slice of a granule: (i * 2979) >> 16");
     const int set = WOFF_H2 + (int)((epoch - 1u) & 1u) * WNS * WQ2;  // (epoch = frame + 1)
     int gi[NG], sl[NG], e[NG];
 #pragma unroll
     for (int j = 0; j < NG; ++j) {
-        sl[j] = p / TPS;
-        e[j] = (p & (TPS - 1)) + TPS * j;
-        gi[j] = (e[j] < WQ2 && sl[j] != X.slice) ? set + sl[j] * WQ2 + e[j] : -1;
+        const int i = p + NP * j;
+        sl[j] = (i * 2979) >> 16;
+        e[j] = i - sl[j] * WQ2;
+        gi[j] = (i < WNS * WQ2 && sl[j] != X.slice) ? set + i : -1;
     }
     u32x4 v[NG];
     if (!ws_poll<NG>(X, L, gi, epoch, v)) return false;
@@ -1113,7 +1117,7 @@ __global__ __launch_bounds__(NT) void k_decode_feat_ws(const PredDev P, const Cb
     WsRegs R;
     for (int i = tid; i < WH1 * WG; i += NT) L.h1[i] = 0.0f;
     for (int i = tid; i < WH2 * WG; i += NT) L.h2[i] = 0.0f;
-    for (int i = tid; i < WIN * WG; i += NT) L.x[i] = 0.0f;
+    for (int i = tid; i < WIN * WXP + 4; i += NT) L.x[i] = 0.0f;
     __syncthreads();
     ws_prologue(P, X, L, R, S, tid);
     if (X.fallback) return;  // (workgroup- and group-uniform, nothing written yet) the row-split launch behind this one serves the group

@@ -409,7 +409,7 @@ __global__ __launch_bounds__(NT) void k_encode_wsd(const PredDev P, const CbDev 
     WsRegs R;
     for (int i = tid; i < WH1 * WG; i += NT) L.h1[i] = 0.0f;  // h = None -> zeros (wavernn.py:182)
     for (int i = tid; i < WH2 * WG; i += NT) L.h2[i] = 0.0f;
-    for (int i = tid; i < WIN * WG; i += NT) L.x[i] = 0.0f;   // c_in[:, 0, :] is all zero (wavernn.py:177-178)
+    for (int i = tid; i < WIN * WXP + 4; i += NT) L.x[i] = 0.0f;   // c_in[:, 0, :] is all zero (wavernn.py:177-178)
     for (int k = tid; k < C.n_hi; k += NT) L.sclc[k] = C.scl_hi[k];
     for (int k = tid; k < C.n_lo; k += NT) L.sclc[C.n_hi + k] = C.scl_lo[k];
     for (int i = tid; i < 3 * WNS * (NDIM + 1); i += NT) {  // this workgroup's entries 32 m + slice of the three books
