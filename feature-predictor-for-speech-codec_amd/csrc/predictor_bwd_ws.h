@@ -209,8 +209,11 @@ __global__ __launch_bounds__(NT) void k_train_bwd_ws(const PredDev P, const BwdW
             const bool want = g_is1 ? do1 : do2;
             bool ok = !ws_dead(L);
 #pragma unroll 1
-            for (int hf = 0; hf < 2 && ok; ++hf) {
-                constexpr int NH = BNG / 2;
+#ifndef FPC_BW_NH
+#define FPC_BW_NH (BNG / 2)
+#endif
+            for (int hf = 0; hf < BNG / FPC_BW_NH && ok; ++hf) {
+                constexpr int NH = FPC_BW_NH;
                 u32x4 v[NH];
                 const int g0 = set + (gs0 + 2 * NH * hf) * BQ + gitem;  // + 2 BQ per i
                 if (!__all(!want)) {
