@@ -2003,8 +2003,12 @@ extern "C" int fpc_trainer_step(fpc_trainer* t, const float* feat_dev, int B, in
         {
             (void)hipStreamSynchronize(st);
             volatile unsigned* w = (volatile unsigned*)p->status_host;
-            fprintf(stderr, "k_train_bwd_ws B=%d cycles/step (thread %d of workgroup 5, group 0): phase 1 %u poll %u image writes %u barriers %u "
-                    "prefetch issue %u products %u stage + barrier %u | before the loop %u kcycles, loop %u kcycles, kernel %u us\n", B, FPC_BW_STAMP_TID, w[44], w[45], w[46], w[47], 0u, w[48], w[49], w[50], w[51], w[52]);
+            fprintf(stderr, FPC_BW_STAMP_TID < 256
+                    ? "k_train_bwd_ws B=%d cycles/step (thread %d of workgroup 5, group 0; track A): hop %u image sync %u chain of 72 %u "
+                      "product sync %u wait for track B %u gates %u | before the loop %u kcycles, loop %u kcycles, kernel %u us\n"
+                    : "k_train_bwd_ws B=%d cycles/step (thread %d of workgroup 5, group 0; track B): gates %u poll %u image writes + sync %u "
+                      "stage + wait for track A %u chains of 24 %u product sync %u | before the loop %u kcycles, loop %u kcycles, kernel %u us\n",
+                    B, FPC_BW_STAMP_TID, w[44], w[45], w[46], w[47], w[48], w[49], w[50], w[51], w[52]);
             for (int k2 = 40; k2 < 56; ++k2) w[k2] = 0;
         }
 #endif

@@ -8,22 +8,30 @@
 //   GRU1 units 12 s .. 12 s + 11: their gate gradients, and the 12 COLUMNS of W1h^T / W2i^T that produce dh1 of those units,
 //   GRU2 units  4 s ..  4 s + 3 : their gate gradients, and the  4 columns of W2h^T that produce dh2 of those units,
 // as MFMA B operands in REGISTERS (wave w < 4: rows 288 w .. 288 w + 287 of W1h, 72 k-steps, the last 24 of them in LDS;
-// wave 4 + w: rows 96 w .. 96 w + 95 of W2i and of W2h, 24 + 24 k-steps).  The A operands are the gate-gradient vectors of ALL units of the 16 utterances, as images
-// in LDS ([row][utterance]: lane l of k-step j reads image[64 j + l]): they change hands once per step as 16-byte granules
-// {epoch, 3 values} -- one per (unit, utterance) -- through the group's granule block, two sets used by step parity (a
-// workgroup publishes step k + 1 once its gather of step k is complete, i.e. once every partner has published step k, which a
-// partner does only with step k - 1 whole in its LDS: the set of parity k + 1 is free).
+// wave 4 + w: rows 96 w .. 96 w + 95 of W2i and of W2h, 24 + 24 k-steps).  The A operands are the gate-gradient vectors of ALL
+// units of the 16 utterances, as images in LDS ([row][utterance]: lane l of k-step j reads image[64 j + l]): they change hands
+// as 16-byte granules {epoch, 3 values} -- one per (unit, utterance) -- through the group's granule block, two sets used by
+// step parity (a workgroup publishes step k + 1 of a recurrence once its gather of step k is complete, i.e. once every partner
+// has published step k, which a partner does only with step k - 1 whole in its LDS: the set of parity k + 1 is free).
 //
-// ONE hop per step, because the two recurrences are independent of each other going backward -- dh2(t) needs dpre(t) and
-// dh2n only, dh1(t) needs W2i^T g2i(t) and dh1n -- so step k works on GRU2 at frame t = L - 1 - k and on GRU1 at frame t + 1:
-//   phase 1 (gate threads, registers): dh2n(t) = fma(dh2(t+1), z2(t+1), tree(W2h^T g2h(t+1)));  dh2 = relu'(h2) * (fc_w^T dpre) + dh2n;
-//           gate gradients of GRU2 at t -> dgi2 / dgh2 (kept for the weight gradients), published;
-//           dh1n(t+1) = fma(dh1(t+2), z1(t+2), tree(W1h^T g1h(t+2)));  dh1 = tree(W2i^T g2i(t+1)) + dh1n;
-//           gate gradients of GRU1 at t + 1 -> dgi1 / dgh1, published;
-//   hop: every workgroup gathers the other 31 workgroups' granules into its images;
-//   phase 2 (all eight waves, MFMA): W2i^T g2i(t), W2h^T g2h(t), W1h^T g1h(t+1) for this workgroup's columns, in the row
-//           segments of oracle/fpc_oracle.c (matvec_t: 4 segments, each a row-ordered fmaf chain from 0 = what the f32 MFMA
-//           accumulates, the segment sums added as a balanced tree by the gate threads in the next phase 1).
+// TWO TRACKS, because the two recurrences are almost independent of each other going backward -- dh2(t) needs dpre(t) and
+// dh2n only; dh1(t) needs W2i^T g2i(t) and dh1n -- and each is a strictly serial loop of its own
+//   publish the gate gradients -> hop (one L2 round trip) -> transposed product on the matrix cores -> gate gradients:
+//   track B, waves 4-7, step k = 0 .. L-1, GRU2 at frame t = L-1-k:
+//     gates (wave 4): dh2n = fma(dh2(t+1), z2(t+1), tree(W2h^T g2h(t+1)));  dh2 = relu'(h2) * (fc_w^T dpre) + dh2n;
+//            gate gradients -> dgi2 / dgh2 (kept for the weight gradients), published;
+//     hop:   the other 31 workgroups' GRU2 granules into the image g2;
+//     MFMA:  W2i^T g2i(t) -> pa2[k & 1] (track A reads it one step later), W2h^T g2h(t) -> pb;
+//   track A, waves 0-3, step k = 1 .. L, GRU1 at frame t = L-k:
+//     hop:   the GRU1 granules of frame t + 1 (published at the end of step k - 1) into the image g1;
+//     MFMA:  W1h^T g1h(t+1) -> pa1, four chains of 72;
+//     gates (waves 0-2): dh1n = fma(dh1(t+1), z1(t+1), tree(pa1));  dh1 = tree(W2i^T g2i(t)) + dh1n;  -> dgi1 / dgh1, published.
+// The tracks meet in two LDS counters only (track A waits for the pa2 of its frame; track B does not overwrite a pa2 buffer
+// before track A has read it), the waves of a track in two more -- no workgroup barrier inside the loop, so the round trip of
+// one recurrence hides behind the products of the other.  (One track, one hop and one barrier pair per step -- the first form
+// of this kernel -- took 17.6 kcycles per step, 4 k of them waiting for granules and 2.4 k at the barrier:
+// profiles/r05_train_timing.txt.)  Products in the row segments of oracle/fpc_oracle.c (matvec_t: 4 segments, each a
+// row-ordered fmaf chain from 0 = what the f32 MFMA accumulates, the segment sums added as a balanced tree by the gate threads).
 // Every value is formed by the operations and in the order of k_train_bwd and of orc_train_step (gru_bwd): losses, gradients
 // and parameters are bit-identical to both (tests).  The saved activations a gate thread needs are fetched a step ahead.
 // Residency, give-up and fallback: as the forward kernels (ws_hello decides GO / FALLBACK per group before anything is
@@ -33,27 +41,114 @@
 #ifndef FPC_BW_STAMP_TID
 #define FPC_BW_STAMP_TID 0
 #endif
-constexpr int BQ1 = WV1;                     // granules per workgroup, GRU1 items (unit, utterance): {epoch, drpre, dzpre, dnpre * r}
-constexpr int BQ2 = WV2;                     // ... GRU2 items: {epoch, drpre, dzpre, dnpre} (the receiver multiplies by r itself)
-constexpr int BQ = BQ1 + BQ2;                // 256
+#ifndef FPC_BW_LATE_PREFETCH
+#define FPC_BW_LATE_PREFETCH 1
+#endif
+#ifndef FPC_BW_ACT_LATE
+#define FPC_BW_ACT_LATE 1
+#endif
+#ifndef FPC_BW_HINT
+#define FPC_BW_HINT 1
+#endif
+#ifndef FPC_BW_SENTINEL
+#define FPC_BW_SENTINEL 0
+#endif
+#ifndef FPC_BW_DELAY
+#define FPC_BW_DELAY 0
+#endif
+#ifndef FPC_BW_ROUNDS
+#define FPC_BW_ROUNDS 2  // rounds of the GRU1 gather: 2 x 12 granules per lane, or 1 x 24
+#endif
+constexpr int BQ1 = WV1;                       // granules per workgroup, GRU1 items (unit, utterance): {epoch, drpre, dzpre, dnpre * r}
+constexpr int BQ2 = WV2;                       // ... GRU2 items: {epoch, drpre, dzpre, dnpre} (the receiver multiplies by r itself)
+constexpr int BQ = BQ1 + BQ2;                  // 256
 constexpr int BGRANULES = WNS + 2 * WNS * BQ;  // hello | set 0 | set 1: 16 416 granules = 262 656 bytes per group
-constexpr int BNG = WNS * BQ / NT;           // granules a thread gathers per step: 16 (one per pair of source workgroups)
-static_assert(WNS * BQ % NT == 0 && NT == 2 * BQ, "gather assignment: thread p = item p % 256 of workgroups 2 i + p / 256");
+constexpr int BTN = NT / 2;                    // threads of a track
+static_assert(WNS * WG == 2 * BTN, "gather assignment: thread p of a track = utterance p % 16 of the source workgroups p / 16 and p / 16 + 16");
+enum { BSIG_A = 0, BSIG_BM, BSIG_B3, BSIG_AD, BSIG_AP, BSIG_BP, BSIG_N };
 
 struct __attribute__((aligned(16))) BwLds {
     float g1[3 * WH1 * WG];  // image of g1h(t+1): [gate * 384 + unit][utterance]
     float g2[4 * WH2 * WG];  // image of g2(t): rows gate * 128 + unit (gate < 3) = g2i; rows 384 + unit = dnpre * r (g2h's n rows)
     float pa1[4][256];       // W1h^T g1h: [row segment][ws_tile(column, utterance)]
-    float pa2[4][256];       // W2i^T g2i
+    float pa2[2][4][256];    // W2i^T g2i, by step parity
     float pb[4][256];        // W2h^T g2h (columns < 4)
     float w1[4][24 * 64];    // waves 0-3 keep k-steps 0 .. 47 of their 72 in registers; 48 .. 71 here: [wave][k-step - 48][lane]
-    float r2[WH2 * WG];      // r2 of every GRU2 unit at the step's frame [unit][utterance] (the gather forms dnpre * r)
-    float dp[WG][WIN];       // dpre of the step's frame [utterance][output]
+    float r2[WH2 * WG];      // r2 of every GRU2 unit at track B's frame [unit][utterance] (the gather forms dnpre * r)
+    float dp[WG * WIN];      // dpre of track B's frame [utterance][output]
     float fcw[WU2][WIN];     // rows 4 s .. 4 s + 3 of the output layer's weights ([H2][F] in the device layout)
+    int sig[BSIG_N];         // wave counters: the waves of a track among themselves (A, BM, B3), and the two tracks (B3, AD)
     int dead, dead_latch, hello, same_xcd;
 };
 
 __device__ __forceinline__ float bw_tree(const float (&p)[4][256], int v) { return (p[0][v] + p[1][v]) + (p[2][v] + p[3][v]); }
+
+// N granules per lane, granule i at g0 + (i / SPLIT) * 16 BQ + (i % SPLIT) * 16 (source workgroups s and s + 16, SPLIT items of
+// each), polled until every wanted tag of the WAVE shows `epoch`; `own`: the source (0 / 1) that is this workgroup itself (its
+// items are in the image already), -1: neither.  false: the wait was given up, or the workgroup is dead already.
+// "this wave has published": a hint for the waves of the track that have no gate items -- a wave that polls the granule block
+// before the partners can have published only re-issues its loads, and those loads queue in front of the publishing wave's
+// stores in the compute unit's one vector-memory pipeline (measured: six stores of the gate wave took 2.6 kcycles to issue
+// beside three polling waves).  Relaxed: it orders nothing (a release would wait for the store's acknowledgement).
+__device__ __forceinline__ void bw_hint(int* s) {
+    if ((threadIdx.x & 63) == 0) (void)__hip_atomic_fetch_add(s, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ void bw_await_hint(int* s, int target, int* dead) {
+    unsigned spins = 0;
+    while (__hip_atomic_load(s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < target) {
+        if ((++spins & 7u) == 0 && __hip_atomic_load(dead, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0) return;
+        __builtin_amdgcn_s_sleep(1);
+    }
+}
+template <int N, int SPLIT>
+__device__ __forceinline__ bool bw_poll(const WsCtx& X, BwLds& L, int g0, unsigned epoch, int own, u32x4 (&v)[N]) {
+    if (ws_dead(L)) return false;
+    unsigned spins = 0;
+    unsigned long long tm0 = 0, last = 0;
+#if FPC_BW_DELAY
+    __builtin_amdgcn_s_sleep(FPC_BW_DELAY);
+#endif
+#if FPC_BW_SENTINEL
+    bool sent = true;  // (first the LAST item of each source alone -- one load per source, not SPLIT: a round that comes too early is cheap)
+#else
+    constexpr bool sent = false;
+#endif
+    for (;;) {
+        bool all = true;
+        if (sent) {
+#pragma unroll
+            for (int i = SPLIT - 1; i < N; i += SPLIT) {
+                const u32x4 w = __builtin_amdgcn_raw_buffer_load_b128(X.rs, (g0 + (i / SPLIT) * 16 * BQ + (i % SPLIT) * 16) * 16, 0, 16);
+                all &= i / SPLIT == own || w.x == epoch;
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < N; ++i)
+                v[i] = __builtin_amdgcn_raw_buffer_load_b128(X.rs, (g0 + (i / SPLIT) * 16 * BQ + (i % SPLIT) * 16) * 16, 0, 16);
+#pragma unroll
+            for (int i = 0; i < N; ++i) all &= i / SPLIT == own || v[i].x == epoch;
+        }
+        if (__all(all)) {
+            if (!sent) return true;
+#if FPC_BW_SENTINEL
+            sent = false;
+            continue;
+#endif
+        }
+        if (ws_dead(L)) return false;
+        if ((++spins & 63u) == 0) {
+            const unsigned long long now = __builtin_amdgcn_s_memrealtime();
+            if (tm0 == 0 || now - last > spin_rearm_gap(X.limit)) tm0 = now;  // (this wave was descheduled: await_granule)
+            last = now;
+            if (now - tm0 > X.limit || (status_load(X.err) & FPC_ST_TIMEOUT) != 0u) {
+                ws_give_up(X, L);
+                return false;
+            }
+        }
+        __builtin_amdgcn_s_sleep(1);
+        asm volatile("" ::: "memory");  // (the loads are re-issued every round)
+    }
+}
 
 __global__ __launch_bounds__(NT) void k_train_bwd_ws(const PredDev P, const BwdW W, int Lf, const TrainBufs T, const WsArgs S) {
     __shared__ BwLds L;
@@ -66,6 +161,7 @@ __global__ __launch_bounds__(NT) void k_train_bwd_ws(const PredDev P, const BwdW
     if (!ws_role(S.ngroups, group, slice)) return;
     WsCtx X = ws_ctx(S, group, slice, BGRANULES);
     if (tid == 0) L.dead = (status_load(S.err) & FPC_ST_TIMEOUT) != 0u ? 1 : 0;  // (a failed handle waits for nobody)
+    if (tid < BSIG_N) L.sig[tid] = 0;
     // ---- this wave's B operands: rows of the torch-layout matrices (BwdW), this workgroup's columns ----
     float wB[48];
     if (wave < 4) {
@@ -85,17 +181,15 @@ __global__ __launch_bounds__(NT) void k_train_bwd_ws(const PredDev P, const BwdW
     __syncthreads();
     ws_hello(X, L, S, tid);
     if (X.fallback) return;  // (group-uniform, nothing written yet) k_train_bwd behind this launch serves the group
-    // ---- roles of phase 1: thread < 192: GRU1 item (unit 12 s + j, utterance u); 192 .. 255: GRU2 item (unit 4 s + j, u) ----
-    const bool is1 = tid < BQ1, is2 = tid >= BQ1 && tid < BQ;
-    const int it = is1 ? tid : tid - BQ1, ij = it >> 4, iu = it & 15;
-    const bool live = (is1 || is2) && iu < X.nu;                     // (a part-filled group: the missing utterances are zeros)
-    const int unit = is1 ? WU1 * slice + ij : WU2 * slice + ij, H = is1 ? WH1 : WH2;
+    // ---- the thread within its track: gate item (unit ij of the workgroup's, utterance iu); gather (sources gs / gs + 16, utterance gu) ----
+    const bool trackA = wave < 4;
+    const int p = tid & (BTN - 1);
+    const int ij = p >> 4, iu = p & 15, tv = ws_tile(ij, iu);
+    const bool gate = trackA ? p < BQ1 : p < BQ2;                    // (waves 0-2; wave 4)
+    const bool live = gate && iu < X.nu;                             // (a part-filled group: the missing utterances are zeros)
+    const int unit = trackA ? WU1 * slice + ij : WU2 * slice + ij, H = trackA ? WH1 : WH2;
     const size_t nrow = (size_t)(X.b0 + (iu < X.nu ? iu : 0)) * Lf;  // sample index of frame 0 of the thread's utterance
-    const int tv = ws_tile(ij, iu);
-    // ---- the gather's assignment: thread p takes item p % 256 of the source workgroups 2 i + p / 256, i < 16 ----
-    const int gitem = tid & (BQ - 1), gs0 = tid >> 8;
-    const bool g_is1 = gitem < BQ1;
-    const int gj = g_is1 ? gitem >> 4 : (gitem - BQ1) >> 4, gu = gitem & 15;
+    const int gs = p >> 4, gu = p & 15;
     // saved activations of the thread's item at frame t (0 outside the batch / the sequence)
     struct Act {
         float r, z, n, hn, hp, h;
@@ -104,7 +198,7 @@ __global__ __launch_bounds__(NT) void k_train_bwd_ws(const PredDev P, const BwdW
         Act a{0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         if (live && t >= 0 && t < Lf) {
             const size_t o = (nrow + t) * H + unit;
-            if (is1) {
+            if (trackA) {
                 a.r = T.r1[o], a.z = T.z1[o], a.n = T.n1[o], a.hn = T.hn1[o], a.hp = T.h1p[o];
             } else {
                 a.r = T.r2[o], a.z = T.z2[o], a.n = T.n2[o], a.hn = T.hn2[o], a.hp = T.h2p[o], a.h = T.h2[o];
@@ -112,175 +206,125 @@ __global__ __launch_bounds__(NT) void k_train_bwd_ws(const PredDev P, const BwdW
         }
         return a;
     };
-    // dpre and r2 of the step's frame go through LDS (one value / four values per thread, fetched a step ahead, stored behind the
-    // products: a gate thread would hold 18 registers of dpre, a gathering thread 16 of r2)
-    const int du = tid / WFC, dout = tid - du * WFC;  // thread < 288: dpre[utterance du][output dout]
-    auto load_dpv = [&](int t) { return (tid < WG * WFC && du < X.nu && t >= 0) ? T.dpre[((size_t)(X.b0 + du) * Lf + t) * WFC + dout] : 0.0f; };
-    f32x4ws r2v;
-    auto load_r2v = [&](int t) {  // thread p: units 4 (p / 16) .. + 3 ... of utterance p % 16: r2 image [unit][utterance]
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int un = 4 * (tid >> 4) + i, uu = tid & 15;
-            r2v[i] = (uu < X.nu && t >= 0) ? T.r2[((size_t)(X.b0 + uu) * Lf + t) * WH2 + un] : 0.0f;
-        }
-    };
-    auto stage = [&](float dpv) {
-        if (tid < WG * WFC) L.dp[du][dout] = dpv;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) L.r2[(4 * (tid >> 4) + i) * WG + (tid & 15)] = r2v[i];
-    };
-    Act an = load_act(is1 ? Lf : Lf - 1);  // (GRU1 has nothing to do in step 0)
-    float dpv = load_dpv(Lf - 1);
-    load_r2v(Lf - 1);
-    stage(dpv);
-    __syncthreads();
-    float dhp = 0.0f, zp = 0.0f;  // dh and z of the thread's item at the frame of the previous step
 #ifdef FPC_WS_PROF
     long long bprof[6] = {0, 0, 0, 0, 0, 0}, blast = __builtin_readcyclecounter();
     const long long t_loop = blast;
-#define BSTAMPW(i)                                             \
-    if (tid == FPC_BW_STAMP_TID) {                             \
-        const long long now_ = __builtin_readcyclecounter();   \
-        bprof[i] += now_ - blast;                              \
-        blast = now_;                                          \
+#define BSTAMPW(i)                                           \
+    if (tid == FPC_BW_STAMP_TID) {                           \
+        const long long now_ = __builtin_readcyclecounter(); \
+        bprof[i] += now_ - blast;                            \
+        blast = now_;                                        \
     }
 #else
 #define BSTAMPW(i)
 #endif
-    int k = 0;
-    for (; k <= Lf; ++k) {
-        const int t2 = Lf - 1 - k, t1 = t2 + 1;  // frames of GRU2 and of GRU1 in this step
-        const bool do2 = t2 >= 0, do1 = k >= 1;
-        const unsigned epoch = (unsigned)k + 1u;
-        const int set = WNS + (k & 1) * WNS * BQ;
-        // ---- phase 1 ----
-        const Act a = an;
-        if ((is1 && do1) || (is2 && do2)) {
-            const int t = is1 ? t1 : t2;
-            float dhn = 0.0f, dh;
-            if (is1) {
-                if (k >= 2) dhn = fmaf(dhp, zp, bw_tree(L.pa1, tv));  // dh1n(t1): gru_bwd's last line for frame t1 + 1
-                dh = bw_tree(L.pa2, tv) + dhn;                        // (k = 1: pa2 holds W2i^T g2i(L - 1))
-            } else {
-                if (k >= 1) dhn = fmaf(dhp, zp, bw_tree(L.pb, tv));
-                float dr = 0.0f;
-#pragma unroll
-                for (int o = 0; o < WFC; ++o) dr = fmaf(L.fcw[ij][o], L.dp[iu][o], dr);
-                dh = (a.h > 0.0f ? dr : 0.0f) + dhn;
-            }
-            const float dn_raw = dh * (1.0f - a.z);
-            const float dnpre = dn_raw * fmaf(-a.n, a.n, 1.0f);
-            const float dz_raw = dh * (a.hp - a.n);
-            const float dzpre = dz_raw * (a.z * (1.0f - a.z));
-            const float drpre = (dnpre * a.hn) * (a.r * (1.0f - a.r));
-            const float dnr = dnpre * a.r;
-            dhp = dh;
-            zp = a.z;
-            if (live) {  // kept for the weight gradients (k_grad_tn)
-                float* gi = is1 ? T.dgi1 : T.dgi2;
-                float* gh = is1 ? T.dgh1 : T.dgh2;
-                const size_t o = (nrow + t) * 3 * H + unit;
-                gi[o] = drpre, gi[o + H] = dzpre, gi[o + 2 * H] = dnpre;
-                gh[o] = drpre, gh[o + H] = dzpre, gh[o + 2 * H] = dnr;
-            }
-            if (k < Lf) {  // (the last step -- GRU1 at frame 0 -- feeds no product)
-                if (is1) {
-                    ws_store(X, set + slice * BQ + it, epoch, drpre, dzpre, dnr);
-                    L.g1[(0 * WH1 + unit) * WG + iu] = drpre;
-                    L.g1[(1 * WH1 + unit) * WG + iu] = dzpre;
-                    L.g1[(2 * WH1 + unit) * WG + iu] = dnr;
-                } else {
-                    ws_store(X, set + slice * BQ + BQ1 + it, epoch, drpre, dzpre, dnpre);
-                    L.g2[(0 * WH2 + unit) * WG + iu] = drpre;
-                    L.g2[(1 * WH2 + unit) * WG + iu] = dzpre;
-                    L.g2[(2 * WH2 + unit) * WG + iu] = dnpre;
-                    L.g2[(3 * WH2 + unit) * WG + iu] = dnr;
-                }
-            }
-        }
-        if (k == Lf) break;
-        BSTAMPW(0)
-        // ---- the hop: the other 31 workgroups' items of this step into the images ----
-        // (thread p polls item p % 256 of the source workgroups 2 i + p / 256 until every wanted tag of the WAVE shows the epoch;
-        //  the granule index is formed where it is used: an index array would be 16 more live registers)
-        // (in two halves of 8 granules: 16 at once keep 64 registers of payload live next to the wave's B operands, and the
-        //  allocator answers by leaving operands in scratch memory -- 63 registers, reloaded inside the MFMA chains every step)
-        {
-            const bool want = g_is1 ? do1 : do2;
-            bool ok = !ws_dead(L);
-#pragma unroll 1
-#ifndef FPC_BW_NH
-#define FPC_BW_NH (BNG / 2)
+#ifdef FPC_BW_PROF_A2  // (the stamps of track A inside its hop instead: hint wait | poll 1 | writes 1 | poll 2 | writes 2 | the rest)
+#define BSTAMPA(i)
+#define BSTAMPE(i) BSTAMPW(i)
+#else
+#define BSTAMPA(i) BSTAMPW(i)
+#define BSTAMPE(i)
 #endif
-            for (int hf = 0; hf < BNG / FPC_BW_NH && ok; ++hf) {
-                constexpr int NH = FPC_BW_NH;
-                u32x4 v[NH];
-                const int g0 = set + (gs0 + 2 * NH * hf) * BQ + gitem;  // + 2 BQ per i
-                if (!__all(!want)) {
-                    unsigned spins = 0;
-                    unsigned long long tm0 = 0, last = 0;
-                    for (;;) {
-                        bool all = true;
-#pragma unroll
-                        for (int i = 0; i < NH; ++i) v[i] = __builtin_amdgcn_raw_buffer_load_b128(X.rs, (g0 + 2 * BQ * i) * 16, 0, 16);
-#pragma unroll
-                        for (int i = 0; i < NH; ++i) all &= !want || 2 * (i + NH * hf) + gs0 == slice || v[i].x == epoch;
-                        if (__all(all)) break;
-                        if (ws_dead(L)) {
-                            ok = false;
-                            break;
-                        }
-                        if ((++spins & 63u) == 0) {
-                            const unsigned long long now = __builtin_amdgcn_s_memrealtime();
-                            if (tm0 == 0 || now - last > spin_rearm_gap(X.limit)) tm0 = now;  // (this wave was descheduled: await_granule)
-                            last = now;
-                            if (now - tm0 > X.limit || (status_load(X.err) & FPC_ST_TIMEOUT) != 0u) {
-                                ws_give_up(X, L);
-                                ok = false;
-                                break;
-                            }
-                        }
-                        __builtin_amdgcn_s_sleep(1);
-                        asm volatile("" ::: "memory");  // (the loads are re-issued every round)
-                    }
-                }
-                BSTAMPW(1)
-#pragma unroll
-                for (int i = 0; i < NH; ++i) {
-                    const int s = 2 * (i + NH * hf) + gs0;
-                    if (ok && want && s != slice) {
-                        const float v0 = __uint_as_float(v[i].y), v1 = __uint_as_float(v[i].z), v2 = __uint_as_float(v[i].w);
-                        if (g_is1) {
-                            const int u1 = WU1 * s + gj;
-                            L.g1[(0 * WH1 + u1) * WG + gu] = v0;
-                            L.g1[(1 * WH1 + u1) * WG + gu] = v1;
-                            L.g1[(2 * WH1 + u1) * WG + gu] = v2;
-                        } else {
-                            const int u2 = WU2 * s + gj;
-                            L.g2[(0 * WH2 + u2) * WG + gu] = v0;
-                            L.g2[(1 * WH2 + u2) * WG + gu] = v1;
-                            L.g2[(2 * WH2 + u2) * WG + gu] = v2;
-                            L.g2[(3 * WH2 + u2) * WG + gu] = v2 * L.r2[u2 * WG + gu];  // dgh[2 H + i] = dnpre * r[i] (gru_bwd)
-                        }
-                    }
-                }
-                BSTAMPW(2)
-            }
+#ifdef FPC_BW_PROF_B2  // (the stamps of track B inside its gates instead: pb tree | dot product | gate math + publication | kept stores | prefetch issue | the rest)
+#define BSTAMPB(i)
+#define BSTAMPD(i) BSTAMPW(i)
+#else
+#define BSTAMPB(i) BSTAMPW(i)
+#define BSTAMPD(i)
+#endif
+    // the gate gradients of one item from dh and its saved activations: {drpre, dzpre, dnpre, dnpre * r}
+    auto gate_grads = [&](const Act& a, float dh) {
+        const float dn_raw = dh * (1.0f - a.z);
+        const float dnpre = dn_raw * fmaf(-a.n, a.n, 1.0f);
+        const float dz_raw = dh * (a.hp - a.n);
+        const float dzpre = dz_raw * (a.z * (1.0f - a.z));
+        const float drpre = (dnpre * a.hn) * (a.r * (1.0f - a.r));
+        return f32x4ws{drpre, dzpre, dnpre, dnpre * a.r};
+    };
+    // ... kept for the weight gradients (k_grad_tn); behind the publication: one in-order memory queue per wave
+    auto keep = [&](const f32x4ws& g, int t) {
+        if (live) {
+            float* gi = trackA ? T.dgi1 : T.dgi2;
+            float* gh = trackA ? T.dgh1 : T.dgh2;
+            const size_t o = (nrow + t) * 3 * H + unit;
+            gi[o] = g[0], gi[o + H] = g[1], gi[o + 2 * H] = g[2];
+            gh[o] = g[0], gh[o + H] = g[1], gh[o + 2 * H] = g[3];
         }
-        // ONE barrier: the images are whole behind it, and it carries the give-up flag -- thread 0 copies the flag in front of it,
-        // everybody acts on the copy (a wait given up behind the copy shows a step later: every poll fails at once from then
-        // on, the status bit is set, the step's update is skipped either way)
-        if (tid == 0) L.dead_latch = __hip_atomic_load(&L.dead, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        lds_barrier();
-        if (L.dead_latch != 0) break;
-        BSTAMPW(3)
-        // ---- the next step's activations on their way (consumed in the next phase 1, behind the products) ----
-        an = load_act(is1 ? t1 - 1 : t2 - 1);
-        dpv = load_dpv(t2 - 1);
-        load_r2v(t2 - 1);
-        // ---- phase 2: this workgroup's columns of the three transposed products ----
-        if (wave < 4) {
-            if (do1) {  // W1h^T g1h(t1), rows 288 wave ..: one chain of 72 dependent MFMAs (the canonical order is a chain)
+    };
+    float dhp = 0.0f, zp = 0.0f;  // dh and z of the thread's item at the frame of the previous step
+    if (trackA) {
+        // =============================== track A: GRU1, frame t = L - k in step k = 1 .. L ===============================
+        int nsync = 0;
+        auto sync = [&]() {
+            ++nsync;
+            df_signal(&L.sig[BSIG_A]);
+            return df_wait(&L.sig[BSIG_A], 4 * nsync, &L.dead);
+        };
+        Act an = load_act(Lf - 1);
+        for (int k = 1; k <= Lf; ++k) {
+            const int t = Lf - k;
+            const Act a = an;
+#if !FPC_BW_ACT_LATE
+            an = load_act(t - 1);  // (consumed in the next step, behind the hop and the chain)
+#endif
+            if (k >= 2) {
+                // ---- the hop: GRU1 items of frame t + 1 (published in step k - 1: epoch k, set (k - 1) & 1), 12 per source ----
+                const int pset = WNS + ((k - 1) & 1) * WNS * BQ;
+                bool ok = true;
+#if FPC_BW_HINT
+                bw_await_hint(&L.sig[BSIG_AP], 3 * (k - 1), &L.dead);  // (this workgroup's gate waves have published step k - 1)
+#endif
+                BSTAMPE(0)
+#if FPC_BW_ROUNDS == 1
+                {  // both sources in one round: 24 granules (96 registers of payload) in flight per lane
+                    u32x4 v[2 * WU1];
+                    const int own = gs == slice ? 0 : gs + 16 == slice ? 1 : -1;
+                    ok = bw_poll<2 * WU1, WU1>(X, L, pset + gs * BQ + gu, (unsigned)k, own, v);
+                    if (ok) {
+#pragma unroll
+                        for (int j = 0; j < 2 * WU1; ++j)
+                            if (j / WU1 != own) {
+                                float* img = L.g1 + (WU1 * (gs + 16 * (j / WU1)) + j % WU1) * WG + gu;
+                                img[0 * WH1 * WG] = __uint_as_float(v[j].y);
+                                img[1 * WH1 * WG] = __uint_as_float(v[j].z);
+                                img[2 * WH1 * WG] = __uint_as_float(v[j].w);
+                            }
+                    }
+                }
+#else
+#pragma unroll 1
+                for (int hf = 0; hf < 2 && ok; ++hf) {
+                    const int s = gs + 16 * hf;
+                    u32x4 v[WU1];
+                    ok = bw_poll<WU1, WU1>(X, L, pset + s * BQ + gu, (unsigned)k, s == slice ? 0 : -1, v);
+                    if (hf == 0) {
+                        BSTAMPE(1)
+                    } else {
+                        BSTAMPE(3)
+                    }
+                    if (ok && s != slice) {
+                        float* img = L.g1 + (WU1 * s) * WG + gu;
+#pragma unroll
+                        for (int j = 0; j < WU1; ++j) {
+                            img[(0 * WH1 + j) * WG] = __uint_as_float(v[j].y);
+                            img[(1 * WH1 + j) * WG] = __uint_as_float(v[j].z);
+                            img[(2 * WH1 + j) * WG] = __uint_as_float(v[j].w);
+                        }
+                    }
+                    if (hf == 0) {
+                        BSTAMPE(2)
+                    } else {
+                        BSTAMPE(4)
+                    }
+                }
+#endif
+                BSTAMPA(0)
+                if (!ok || !sync()) break;  // the image whole
+                BSTAMPA(1)
+#if FPC_BW_ACT_LATE
+                an = load_act(t - 1);  // (consumed in the next step; issued here, where the vector-memory pipeline is idle)
+#endif
+                // ---- W1h^T g1h(t + 1), rows 288 wave ..: one chain of 72 dependent MFMAs (the canonical order is a chain) ----
                 f32x4ws acc = {0.f, 0.f, 0.f, 0.f};
                 const float* img = L.g1 + 288 * wave * WG + lane;
                 const float* wl = L.w1[wave] + lane;
@@ -301,30 +345,161 @@ __global__ __launch_bounds__(NT) void k_train_bwd_ws(const PredDev P, const BwdW
 #pragma unroll
                     for (int j = 0; j < 24; ++j) acc = ws_mfma(av[ch][j], ch < 2 ? wB[24 * ch + j] : bl[j], acc);
                 ws_put(L.pa1[wave], lane, acc);
+                BSTAMPA(2)
             }
-        } else if (do2) {  // W2i^T g2i(t2) and W2h^T g2h(t2), rows 96 sg ..: two chains of 24, interleaved
-            const int sg = wave - 4;
-            f32x4ws ai = {0.f, 0.f, 0.f, 0.f}, ah = {0.f, 0.f, 0.f, 0.f};
-            const float* img = L.g2 + 96 * sg * WG + lane;
-            float av[24], bv[24];
-#pragma unroll
-            for (int j = 0; j < 24; ++j) {
-                av[j] = img[64 * j];
-                // (g2h = g2i in the r and z rows; its n rows 256 .. 383 sit 128 rows further down the image)
-                bv[j] = img[64 * j + ((96 * sg + 4 * j >= 2 * WH2) ? WH2 * WG : 0)];
+#if FPC_BW_ACT_LATE
+            if (k < 2) an = load_act(t - 1);
+#endif
+            if (!sync()) break;  // pa1 whole (and nobody reads the image any more)
+            BSTAMPA(3)
+            // ---- the gates (waves 0-2): W2i^T g2i(t) is track B's product of its step k - 1 ----
+            if (wave < 3) {
+                if (!df_wait(&L.sig[BSIG_B3], 4 * k, &L.dead)) break;
+                BSTAMPA(4)
+                const float dhn = k >= 2 ? fmaf(dhp, zp, bw_tree(L.pa1, tv)) : 0.0f;  // dh1n(t): gru_bwd's last line for frame t + 1
+                const float dh = bw_tree(L.pa2[(k - 1) & 1], tv) + dhn;
+                df_signal(&L.sig[BSIG_AD]);  // (this wave has read the pa2 buffer: its lanes' values are in registers)
+                const f32x4ws g = gate_grads(a, dh);
+                dhp = dh;
+                zp = a.z;
+                if (k < Lf) {  // (the last step -- frame 0 -- feeds no product)
+                    ws_store(X, WNS + (k & 1) * WNS * BQ + slice * BQ + p, (unsigned)k + 1u, g[0], g[1], g[3]);
+#if FPC_BW_HINT
+                    bw_hint(&L.sig[BSIG_AP]);
+#endif
+                    L.g1[(0 * WH1 + unit) * WG + iu] = g[0];
+                    L.g1[(1 * WH1 + unit) * WG + iu] = g[1];
+                    L.g1[(2 * WH1 + unit) * WG + iu] = g[3];
+                }
+                keep(g, t);
+                BSTAMPA(5)
             }
-#pragma unroll
-            for (int j = 0; j < 24; ++j) {
-                ai = ws_mfma(av[j], wB[j], ai);
-                ah = ws_mfma(bv[j], wB[24 + j], ah);
-            }
-            ws_put(L.pa2[sg], lane, ai);
-            ws_put(L.pb[sg], lane, ah);
+            BSTAMPE(5)
         }
-        BSTAMPW(4)
-        stage(dpv);  // (the gather of this step has read r2, the gate threads dpre: the next step's values go in)
-        lds_barrier();
-        BSTAMPW(5)
+    } else {
+        // =============================== track B: GRU2, frame t = L - 1 - k in step k = 0 .. L - 1 ===============================
+        const int sg = wave - 4;
+        int nmid = 0;
+        // dpre and r2 of the step's frame go through LDS (fetched a step ahead, stored behind the gather):
+        // thread p: dpre values p and (p < 32) 256 + p of the 288; r2 of units 8 (p / 16) .. + 7 of utterance p % 16
+        float dpv[2];
+        f32x4ws r2v[2];
+        auto load_stage = [&](int t) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int e = p + 256 * i, du = e / WFC, dout = e - du * WFC;
+                dpv[i] = (e < WG * WFC && du < X.nu && t >= 0) ? T.dpre[((size_t)(X.b0 + du) * Lf + t) * WFC + dout] : 0.0f;
+            }
+            const f32x4ws zero = {0.f, 0.f, 0.f, 0.f};
+            const bool in = gu < X.nu && t >= 0;
+            const f32x4ws* src = reinterpret_cast<const f32x4ws*>(T.r2 + ((size_t)(X.b0 + (in ? gu : 0)) * Lf + (in ? t : 0)) * WH2 + 8 * gs);
+            r2v[0] = in ? src[0] : zero;
+            r2v[1] = in ? src[1] : zero;
+        };
+        auto stage = [&]() {
+            L.dp[p] = dpv[0];
+            if (p < WG * WFC - 256) L.dp[256 + p] = dpv[1];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) L.r2[(8 * gs + i) * WG + gu] = r2v[i >> 2][i & 3];
+        };
+        Act an = load_act(Lf - 1);
+        load_stage(Lf - 1);
+        stage();
+        df_signal(&L.sig[BSIG_BM]);
+        ++nmid;
+        (void)df_wait(&L.sig[BSIG_BM], 4 * nmid, &L.dead);
+        for (int k = 0; k < Lf; ++k) {
+            const int t = Lf - 1 - k;
+            const unsigned epoch = (unsigned)k + 1u;
+            const int set = WNS + (k & 1) * WNS * BQ;
+            const Act a = an;
+#if !FPC_BW_LATE_PREFETCH
+            an = load_act(t - 1);
+            load_stage(t - 1);
+#endif
+            // ---- the gates (wave 4) ----
+            if (sg == 0) {
+                const float dhn = k >= 1 ? fmaf(dhp, zp, bw_tree(L.pb, tv)) : 0.0f;
+                BSTAMPD(0)
+                float dr = 0.0f;
+#pragma unroll
+                for (int o = 0; o < WFC; ++o) dr = fmaf(L.fcw[ij][o], L.dp[iu * WFC + o], dr);
+                const float dh = (a.h > 0.0f ? dr : 0.0f) + dhn;
+                BSTAMPD(1)
+                const f32x4ws g = gate_grads(a, dh);
+                dhp = dh;
+                zp = a.z;
+                ws_store(X, set + slice * BQ + BQ1 + p, epoch, g[0], g[1], g[2]);
+#if FPC_BW_HINT
+                bw_hint(&L.sig[BSIG_BP]);
+#endif
+                L.g2[(0 * WH2 + unit) * WG + iu] = g[0];
+                L.g2[(1 * WH2 + unit) * WG + iu] = g[1];
+                L.g2[(2 * WH2 + unit) * WG + iu] = g[2];
+                L.g2[(3 * WH2 + unit) * WG + iu] = g[3];
+                BSTAMPD(2)
+                keep(g, t);
+                BSTAMPD(3)
+            }
+#if FPC_BW_LATE_PREFETCH
+            an = load_act(t - 1);  // (behind the publication; consumed a step later)
+            load_stage(t - 1);
+#endif
+            BSTAMPD(4)
+            BSTAMPB(0)
+            // ---- the hop: GRU2 items of this frame, 4 of each of the sources gs and gs + 16 ----
+            {
+                u32x4 v[2 * WU2];
+                const int own = gs == slice ? 0 : gs + 16 == slice ? 1 : -1;
+#if FPC_BW_HINT
+                bw_await_hint(&L.sig[BSIG_BP], k + 1, &L.dead);  // (this workgroup's gate wave has published this step)
+#endif
+                if (!bw_poll<2 * WU2, WU2>(X, L, set + gs * BQ + BQ1 + gu, epoch, own, v)) break;
+                BSTAMPB(1)
+#pragma unroll
+                for (int i = 0; i < 2 * WU2; ++i)
+                    if (i / WU2 != own) {
+                        const int u2 = WU2 * (gs + 16 * (i / WU2)) + i % WU2;
+                        const float v2 = __uint_as_float(v[i].w);
+                        L.g2[(0 * WH2 + u2) * WG + gu] = __uint_as_float(v[i].y);
+                        L.g2[(1 * WH2 + u2) * WG + gu] = __uint_as_float(v[i].z);
+                        L.g2[(2 * WH2 + u2) * WG + gu] = v2;
+                        L.g2[(3 * WH2 + u2) * WG + gu] = v2 * L.r2[u2 * WG + gu];  // dgh[2 H + i] = dnpre * r[i] (gru_bwd)
+                    }
+            }
+            ++nmid;
+            df_signal(&L.sig[BSIG_BM]);
+            if (!df_wait(&L.sig[BSIG_BM], 4 * nmid, &L.dead)) break;  // the image whole; dp and r2 of this frame read
+            BSTAMPB(2)
+            stage();
+            // (the pa2 buffer of this parity: read by track A in its step k - 1)
+            if (k >= 2 && !df_wait(&L.sig[BSIG_AD], 3 * (k - 1), &L.dead)) break;
+            BSTAMPB(3)
+            // ---- W2i^T g2i(t) and W2h^T g2h(t), rows 96 sg ..: two chains of 24, interleaved ----
+            {
+                f32x4ws ai = {0.f, 0.f, 0.f, 0.f}, ah = {0.f, 0.f, 0.f, 0.f};
+                const float* img = L.g2 + 96 * sg * WG + lane;
+                float av[24], bv[24];
+#pragma unroll
+                for (int j = 0; j < 24; ++j) {
+                    av[j] = img[64 * j];
+                    // (g2h = g2i in the r and z rows; its n rows 256 .. 383 sit 128 rows further down the image)
+                    bv[j] = img[64 * j + ((96 * sg + 4 * j >= 2 * WH2) ? WH2 * WG : 0)];
+                }
+#pragma unroll
+                for (int j = 0; j < 24; ++j) {
+                    ai = ws_mfma(av[j], wB[j], ai);
+                    ah = ws_mfma(bv[j], wB[24 + j], ah);
+                }
+                ws_put(L.pa2[k & 1][sg], lane, ai);
+                ws_put(L.pb[sg], lane, ah);
+            }
+            BSTAMPB(4)
+            df_signal(&L.sig[BSIG_B3]);
+            if (!df_wait(&L.sig[BSIG_B3], 4 * (k + 1), &L.dead)) break;  // pb, dp and r2 whole for the next step's gates and gather
+            BSTAMPB(5)
+            BSTAMPD(5)
+        }
     }
 #ifdef FPC_WS_PROF
     if (tid == FPC_BW_STAMP_TID && blockIdx.x == 8 * 5)

@@ -1,0 +1,8 @@
+set -e
+timeout -k 10 300 python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "train" 2>&1 | tail -2
+for v in f0 f1 f0 f1; do
+  export FPC_LIB_PATH=build_variants/lib_$v.so
+  echo -n "variant $v: "; timeout -k 10 200 python tools/time_train.py 2>&1 | grep "train step"
+done
+unset FPC_LIB_PATH
+TAG=r05bw bash tools/train_pmc.sh 2>&1 | grep -E "k_train_bwd_ws +(SQ_LDS|LDS|TCC_REQ|SQ_INSTS_VMEM)"
