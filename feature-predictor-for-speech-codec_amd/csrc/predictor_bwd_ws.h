@@ -41,24 +41,6 @@
 #ifndef FPC_BW_STAMP_TID
 #define FPC_BW_STAMP_TID 0
 #endif
-#ifndef FPC_BW_LATE_PREFETCH
-#define FPC_BW_LATE_PREFETCH 1
-#endif
-#ifndef FPC_BW_ACT_LATE
-#define FPC_BW_ACT_LATE 1
-#endif
-#ifndef FPC_BW_HINT
-#define FPC_BW_HINT 1
-#endif
-#ifndef FPC_BW_SENTINEL
-#define FPC_BW_SENTINEL 0
-#endif
-#ifndef FPC_BW_DELAY
-#define FPC_BW_DELAY 0
-#endif
-#ifndef FPC_BW_ROUNDS
-#define FPC_BW_ROUNDS 2  // rounds of the GRU1 gather: 2 x 12 granules per lane, or 1 x 24
-#endif
 constexpr int BQ1 = WV1;                       // granules per workgroup, GRU1 items (unit, utterance): {epoch, drpre, dzpre, dnpre * r}
 constexpr int BQ2 = WV2;                       // ... GRU2 items: {epoch, drpre, dzpre, dnpre} (the receiver multiplies by r itself)
 constexpr int BQ = BQ1 + BQ2;                  // 256
@@ -105,36 +87,14 @@ __device__ __forceinline__ bool bw_poll(const WsCtx& X, BwLds& L, int g0, unsign
     if (ws_dead(L)) return false;
     unsigned spins = 0;
     unsigned long long tm0 = 0, last = 0;
-#if FPC_BW_DELAY
-    __builtin_amdgcn_s_sleep(FPC_BW_DELAY);
-#endif
-#if FPC_BW_SENTINEL
-    bool sent = true;  // (first the LAST item of each source alone -- one load per source, not SPLIT: a round that comes too early is cheap)
-#else
-    constexpr bool sent = false;
-#endif
     for (;;) {
         bool all = true;
-        if (sent) {
 #pragma unroll
-            for (int i = SPLIT - 1; i < N; i += SPLIT) {
-                const u32x4 w = __builtin_amdgcn_raw_buffer_load_b128(X.rs, (g0 + (i / SPLIT) * 16 * BQ + (i % SPLIT) * 16) * 16, 0, 16);
-                all &= i / SPLIT == own || w.x == epoch;
-            }
-        } else {
+        for (int i = 0; i < N; ++i)
+            v[i] = __builtin_amdgcn_raw_buffer_load_b128(X.rs, (g0 + (i / SPLIT) * 16 * BQ + (i % SPLIT) * 16) * 16, 0, 16);
 #pragma unroll
-            for (int i = 0; i < N; ++i)
-                v[i] = __builtin_amdgcn_raw_buffer_load_b128(X.rs, (g0 + (i / SPLIT) * 16 * BQ + (i % SPLIT) * 16) * 16, 0, 16);
-#pragma unroll
-            for (int i = 0; i < N; ++i) all &= i / SPLIT == own || v[i].x == epoch;
-        }
-        if (__all(all)) {
-            if (!sent) return true;
-#if FPC_BW_SENTINEL
-            sent = false;
-            continue;
-#endif
-        }
+        for (int i = 0; i < N; ++i) all &= i / SPLIT == own || v[i].x == epoch;
+        if (__all(all)) return true;
         if (ws_dead(L)) return false;
         if ((++spins & 63u) == 0) {
             const unsigned long long now = __builtin_amdgcn_s_memrealtime();
@@ -264,34 +224,12 @@ __global__ __launch_bounds__(NT) void k_train_bwd_ws(const PredDev P, const BwdW
         for (int k = 1; k <= Lf; ++k) {
             const int t = Lf - k;
             const Act a = an;
-#if !FPC_BW_ACT_LATE
-            an = load_act(t - 1);  // (consumed in the next step, behind the hop and the chain)
-#endif
             if (k >= 2) {
                 // ---- the hop: GRU1 items of frame t + 1 (published in step k - 1: epoch k, set (k - 1) & 1), 12 per source ----
                 const int pset = WNS + ((k - 1) & 1) * WNS * BQ;
                 bool ok = true;
-#if FPC_BW_HINT
                 bw_await_hint(&L.sig[BSIG_AP], 3 * (k - 1), &L.dead);  // (this workgroup's gate waves have published step k - 1)
-#endif
                 BSTAMPE(0)
-#if FPC_BW_ROUNDS == 1
-                {  // both sources in one round: 24 granules (96 registers of payload) in flight per lane
-                    u32x4 v[2 * WU1];
-                    const int own = gs == slice ? 0 : gs + 16 == slice ? 1 : -1;
-                    ok = bw_poll<2 * WU1, WU1>(X, L, pset + gs * BQ + gu, (unsigned)k, own, v);
-                    if (ok) {
-#pragma unroll
-                        for (int j = 0; j < 2 * WU1; ++j)
-                            if (j / WU1 != own) {
-                                float* img = L.g1 + (WU1 * (gs + 16 * (j / WU1)) + j % WU1) * WG + gu;
-                                img[0 * WH1 * WG] = __uint_as_float(v[j].y);
-                                img[1 * WH1 * WG] = __uint_as_float(v[j].z);
-                                img[2 * WH1 * WG] = __uint_as_float(v[j].w);
-                            }
-                    }
-                }
-#else
 #pragma unroll 1
                 for (int hf = 0; hf < 2 && ok; ++hf) {
                     const int s = gs + 16 * hf;
@@ -317,13 +255,10 @@ __global__ __launch_bounds__(NT) void k_train_bwd_ws(const PredDev P, const BwdW
                         BSTAMPE(4)
                     }
                 }
-#endif
                 BSTAMPA(0)
                 if (!ok || !sync()) break;  // the image whole
                 BSTAMPA(1)
-#if FPC_BW_ACT_LATE
                 an = load_act(t - 1);  // (consumed in the next step; issued here, where the vector-memory pipeline is idle)
-#endif
                 // ---- W1h^T g1h(t + 1), rows 288 wave ..: one chain of 72 dependent MFMAs (the canonical order is a chain) ----
                 f32x4ws acc = {0.f, 0.f, 0.f, 0.f};
                 const float* img = L.g1 + 288 * wave * WG + lane;
@@ -347,9 +282,7 @@ __global__ __launch_bounds__(NT) void k_train_bwd_ws(const PredDev P, const BwdW
                 ws_put(L.pa1[wave], lane, acc);
                 BSTAMPA(2)
             }
-#if FPC_BW_ACT_LATE
             if (k < 2) an = load_act(t - 1);
-#endif
             if (!sync()) break;  // pa1 whole (and nobody reads the image any more)
             BSTAMPA(3)
             // ---- the gates (waves 0-2): W2i^T g2i(t) is track B's product of its step k - 1 ----
@@ -364,9 +297,7 @@ __global__ __launch_bounds__(NT) void k_train_bwd_ws(const PredDev P, const BwdW
                 zp = a.z;
                 if (k < Lf) {  // (the last step -- frame 0 -- feeds no product)
                     ws_store(X, WNS + (k & 1) * WNS * BQ + slice * BQ + p, (unsigned)k + 1u, g[0], g[1], g[3]);
-#if FPC_BW_HINT
                     bw_hint(&L.sig[BSIG_AP]);
-#endif
                     L.g1[(0 * WH1 + unit) * WG + iu] = g[0];
                     L.g1[(1 * WH1 + unit) * WG + iu] = g[1];
                     L.g1[(2 * WH1 + unit) * WG + iu] = g[3];
@@ -413,10 +344,6 @@ __global__ __launch_bounds__(NT) void k_train_bwd_ws(const PredDev P, const BwdW
             const unsigned epoch = (unsigned)k + 1u;
             const int set = WNS + (k & 1) * WNS * BQ;
             const Act a = an;
-#if !FPC_BW_LATE_PREFETCH
-            an = load_act(t - 1);
-            load_stage(t - 1);
-#endif
             // ---- the gates (wave 4) ----
             if (sg == 0) {
                 const float dhn = k >= 1 ? fmaf(dhp, zp, bw_tree(L.pb, tv)) : 0.0f;
@@ -430,9 +357,7 @@ __global__ __launch_bounds__(NT) void k_train_bwd_ws(const PredDev P, const BwdW
                 dhp = dh;
                 zp = a.z;
                 ws_store(X, set + slice * BQ + BQ1 + p, epoch, g[0], g[1], g[2]);
-#if FPC_BW_HINT
                 bw_hint(&L.sig[BSIG_BP]);
-#endif
                 L.g2[(0 * WH2 + unit) * WG + iu] = g[0];
                 L.g2[(1 * WH2 + unit) * WG + iu] = g[1];
                 L.g2[(2 * WH2 + unit) * WG + iu] = g[2];
@@ -441,19 +366,15 @@ __global__ __launch_bounds__(NT) void k_train_bwd_ws(const PredDev P, const BwdW
                 keep(g, t);
                 BSTAMPD(3)
             }
-#if FPC_BW_LATE_PREFETCH
             an = load_act(t - 1);  // (behind the publication; consumed a step later)
             load_stage(t - 1);
-#endif
             BSTAMPD(4)
             BSTAMPB(0)
             // ---- the hop: GRU2 items of this frame, 4 of each of the sources gs and gs + 16 ----
             {
                 u32x4 v[2 * WU2];
                 const int own = gs == slice ? 0 : gs + 16 == slice ? 1 : -1;
-#if FPC_BW_HINT
                 bw_await_hint(&L.sig[BSIG_BP], k + 1, &L.dead);  // (this workgroup's gate wave has published this step)
-#endif
                 if (!bw_poll<2 * WU2, WU2>(X, L, set + gs * BQ + BQ1 + gu, epoch, own, v)) break;
                 BSTAMPB(1)
 #pragma unroll

@@ -38,8 +38,11 @@ open(os.path.join(P, "r05_predictor_ws.txt"), "w").write(f"tree {head}; library:
 t = os.path.join(R, "gpurun_out", "r05", "train_prof", "kernel_stats.csv")
 if os.path.exists(t):
     shutil.copy(t, os.path.join(P, "r05_train_kernel_stats.csv"))
+tp = os.path.join(R, "gpurun_out", "r05", "train_pmc", "summary.txt")
+if os.path.exists(tp):
+    shutil.copy(tp, os.path.join(P, "r05_train_pmc_summary.txt"))
 open(os.path.join(P, "r05_train_timing.txt"), "w").write(
     f"tree {head}; tools/time_train.py at the reference's batch (100 x 150, train_frame.py:198-204), twice; then the backward pass on the "
-    "row-split kernel; then the stage profile of k_train_bwd_ws; the rocprofv3 kernel table of the step: r05_train_kernel_stats.csv\n" +
+    "row-split kernel; then the stage profiles of k_train_bwd_ws (one thread of each track); the rocprofv3 kernel table of the step: r05_train_kernel_stats.csv\n" +
     "".join(l for l in open(os.path.join(o, "train.txt")) if "amdgpu.ids" not in l))
 print("collected into profiles/r05_*")

@@ -1,5 +1,6 @@
 # round-5 measurement pass on the GPU box, every tracked record of the round from ONE tree in ONE call:
-#   bash tools/build_variant_pred.sh ws_prof -DFPC_WS_PROF -DFPC_WS_PROF_TAIL ; bash tools/build_variant_pred.sh bwprof0 -DFPC_WS_PROF   (here)
+#   bash tools/build_variant_pred.sh ws_prof -DFPC_WS_PROF -DFPC_WS_PROF_TAIL ; bash tools/build_variant_pred.sh bwprof0 -DFPC_WS_PROF ;
+#   bash tools/build_variant_pred.sh bwprof256 -DFPC_WS_PROF -DFPC_BW_STAMP_TID=256   (here)
 #   gpurun --timeout 1200 -- 'bash tools/measure_round5.sh'
 # then  python tools/collect_round5.py  copies the summaries into profiles/r05_*.
 set -e
@@ -22,6 +23,8 @@ for i in 1 2; do timeout -k 10 200 python tools/time_train.py 2>&1 | grep "train
 echo "FPC_TRAIN_BWD_ROWSPLIT=1 (back-propagation on the row-split kernel, one utterance per workgroups):" >> $o/train.txt
 FPC_TRAIN_BWD_ROWSPLIT=1 timeout -k 10 200 python tools/time_train.py 2>&1 | grep "train step" >> $o/train.txt
 echo "stage profile of k_train_bwd_ws (-DFPC_WS_PROF build: every launch followed by a host synchronisation):" >> $o/train.txt
-FPC_LIB_PATH=build_variants/lib_bwprof0.so timeout -k 10 200 python tools/time_train.py 2>&1 | grep "k_train_bwd_ws" | tail -2 >> $o/train.txt
+FPC_LIB_PATH=build_variants/lib_bwprof0.so timeout -k 10 200 python tools/time_train.py 2>&1 | grep "k_train_bwd_ws" | tail -1 >> $o/train.txt
+FPC_LIB_PATH=build_variants/lib_bwprof256.so timeout -k 10 200 python tools/time_train.py 2>&1 | grep "k_train_bwd_ws" | tail -1 >> $o/train.txt
+echo "== training step: counters"; TAG=r05 bash tools/train_pmc.sh > $o/train_pmc.log 2>&1; grep "k_train_bwd_ws" gpurun_out/r05/train_pmc/summary.txt | head -20
 cat $o/train.txt
 ls $o
