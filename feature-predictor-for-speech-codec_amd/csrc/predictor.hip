@@ -1998,6 +1998,7 @@ extern "C" int fpc_trainer_step(fpc_trainer* t, const float* feat_dev, int B, in
         WsArgs wb;
         const int rc = ws_args(p, B, st, &wb, BGRANULES);  // fresh granules (zeroed behind the forward launches on the stream)
         if (rc != FPC_OK) return rc;
+        if (const char* wh = getenv("FPC_TEST_WITHHOLD_PUBLISH")) wb.withhold = wh[0] == 'b' ? 1 : wb.withhold;  // test hook: this kernel alone
         hipLaunchKernelGGL(k_train_bwd_ws, dim3(ws_grid(wb)), dim3(NT), 0, st, P, bw, L, T, wb);
 #ifdef FPC_WS_PROF
         {

@@ -138,8 +138,9 @@ FPC_API void fpc_predictor_destroy(fpc_predictor* p);
  * exactly that many (either selects the row-split kernels); FPC_TRAIN_BWD_ROWSPLIT=1 the training step's backward pass on
  * the row-split kernel; FPC_FAST_HOP=0 the write-through exchange everywhere.  Test hooks: FPC_SPIN_LIMIT_US /
  * FPC_HELLO_LIMIT_US (shorter bounds of the frame loop's wait / of the residency decision), FPC_TEST_WITHHOLD_PUBLISH=1
- * (the last workgroup of utterance 0 / group 0 never publishes a frame's values: the give-up path) or =hello (not even its
- * hello: stands for a workgroup that is not resident: the fallback path). */
+ * (the last workgroup of utterance 0 / group 0 never publishes a frame's values: the give-up path), =backward (the same in
+ * the training step's backward kernel alone) or =hello (not even its hello: stands for a workgroup that is not resident: the
+ * fallback path). */
 
 /* Synchronises the device and returns what the launches on the handle have reported: FPC_OK, FPC_ERR_TIMEOUT (a
  * row-split exchange gave up) or FPC_ERR_NONFINITE (a NaN / infinite residual reached a quantizer in fpc_encode: those

@@ -1381,11 +1381,14 @@ def test_encode_beside_the_librarys_own_long_decode(torch_cuda, model, vocoder, 
         assert np.array_equal(a, b)
 
 
-def test_trainer_step_that_gives_up_updates_nothing_and_the_count_follows(torch_cuda, synth, monkeypatch):
+@pytest.mark.parametrize("hook", ["1", "backward"])
+def test_trainer_step_that_gives_up_updates_nothing_and_the_count_follows(torch_cuda, synth, monkeypatch, hook):
     """the training step whose forward (weights-stationary kernel: one workgroup of group 0 withholds, its partners time out
-    after 20 ms) gave up: the call fails with the timeout code, NO parameter moves (the Adam launches read the latched status
-    word), and after the error has been reported the next steps continue with Adam's bias corrections of the updates actually
-    applied -- parameters bit-identical to a trainer that never saw the failure (the step counter)"""
+    after 20 ms) gave up -- or, hook "backward", whose forward is whole and whose BACKWARD kernel alone gives up (its two
+    tracks leave their loops independently: the wave whose wait timed out sets the workgroup's flag, every LDS-counter wait
+    of either track reads it): the call fails with the timeout code, NO parameter moves (the Adam launches read the latched
+    status word), and after the error has been reported the next steps continue with Adam's bias corrections of the updates
+    actually applied -- parameters bit-identical to a trainer that never saw the failure (the step counter)"""
     from fpcodec_amd._lib import FpcError
     from fpcodec_amd.train_frame import Trainer
     from fpcodec_amd.wavernn import Wavernn
@@ -1405,7 +1408,7 @@ def test_trainer_step_that_gives_up_updates_nothing_and_the_count_follows(torch_
     l0 = t1.step(feat)
     t1.sync()
     before = {k: v.numpy().copy() for k, v in m1.state_dict().items()}
-    monkeypatch.setenv("FPC_TEST_WITHHOLD_PUBLISH", "1")
+    monkeypatch.setenv("FPC_TEST_WITHHOLD_PUBLISH", hook)
     monkeypatch.setenv("FPC_SPIN_LIMIT_US", "20000")
     with pytest.raises(FpcError, match="timed out"):
         t1.step(feat)
