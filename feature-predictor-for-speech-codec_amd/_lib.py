@@ -7,7 +7,7 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("FPC_LIB_PATH") or os.path.join(_HERE, "libfpcodec.so")  # override: kernel-variant experiments
 _lib = None
-ABI_VERSION = 2  # the FPC_ABI_VERSION of include/fpcodec.h this binding is written against
+ABI_VERSION = 3  # the FPC_ABI_VERSION of include/fpcodec.h this binding is written against
 
 SYMBOLS = [
     "fpc_last_error", "fpc_abi_version", "fpc_build_info", "fpc_device_count",
@@ -19,7 +19,7 @@ SYMBOLS = [
     "fpc_lpcnet_synthesize", "fpc_lpcnet_condition", "fpc_lpcnet_last_decode_ms",
     "fpc_lpcnet_kernel_variant", "fpc_lpcnet_set_chunk_frames",
     "fpc_trainer_create", "fpc_trainer_destroy", "fpc_trainer_step", "fpc_trainer_export",
-    "fpc_cb_workspace_bytes", "fpc_cb_find_nearest", "fpc_cb_update", "fpc_cb_mean0",
+    "fpc_cb_workspace_bytes", "fpc_cb_find_nearest", "fpc_cb_update", "fpc_cb_mean0", "fpc_kmeans1d",
 ]
 
 
@@ -95,6 +95,8 @@ def lib():
         L.fpc_cb_update.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
                                     C.c_void_p, C.c_void_p]
         L.fpc_cb_mean0.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+        L.fpc_kmeans1d.argtypes = [C.c_void_p, C.c_longlong, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_double, C.c_int,
+                                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.fpc_predictor_create.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
         L.fpc_predictor_destroy.argtypes = [C.c_void_p]
         L.fpc_predictor_status.argtypes = [C.c_void_p]

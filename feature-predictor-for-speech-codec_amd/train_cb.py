@@ -66,12 +66,61 @@ def save_codebook(path, codebook):
         np.save(path, arr, allow_pickle=True)
 
 
-def train_scalar_codebook(values, n_clusters):
+def kmeans_draws(n, k, n_init, seed=0):
+    """the random draws of scikit-learn's k-means++ seeding in its order, from numpy's RandomState(seed): one RandomState for
+    all runs (KMeans.fit), per run `choice(n, p = 1 / n)` for the first seed and `uniform(size = trials)` for every further
+    one (_kmeans_plusplus), trials = 2 + int(ln k).  The draws do not depend on the data: handing them to fpc_kmeans1d makes a
+    run pick the seeds sklearn's `KMeans(random_state=seed)` picks.  Returns (first_ids int64 (n_init,), uniforms float64
+    (n_init, k - 1, trials), trials)"""
+    rs = np.random.RandomState(seed)
+    trials = 2 + int(np.log(k))
+    w = np.ones(n)
+    p = w / w.sum()
+    first = np.empty(n_init, dtype=np.int64)
+    u = np.empty((n_init, max(k - 1, 0), trials), dtype=np.float64)
+    for r in range(n_init):
+        first[r] = rs.choice(n, p=p)
+        for c in range(k - 1):
+            u[r, c] = rs.uniform(size=trials)
+    return first, u, trials
+
+
+def train_scalar_codebook(values, n_clusters, n_init=10, backend="gpu", max_iter=300, details=None):
     """(n_clusters, 1) float64 centres of the scalar residuals: the reference's commented
-    `KMeans(n_clusters, random_state=0).fit(values[:, None]).cluster_centers_` (train_cb.py:219-226)"""
-    from sklearn.cluster import KMeans
-    v = np.asarray(values, dtype=np.float64).reshape(-1, 1)
-    return KMeans(n_clusters=int(n_clusters), random_state=0, n_init=10).fit(v).cluster_centers_.astype(np.float64)
+    `KMeans(n_clusters, random_state=0).fit(values[:, None]).cluster_centers_` (train_cb.py:219-226; n_init = 10 is the
+    default of the scikit-learn releases that call was written for).
+    backend "gpu": fpc_kmeans1d (csrc/kmeans1d.hip: seeding and Lloyd iterations on the device, the seeding's random draws
+    from numpy's RandomState(0) in sklearn's order) -- the same seeds as sklearn, centres equal to rounding (tests: 1e-9), and
+    reproducible run to run; fails loudly without the library or a GPU.  backend "sklearn": the reference's call itself, on
+    the host.  `details`: a dict that receives inertia, n_iter and the seeds' indices (gpu backend)"""
+    k = int(n_clusters)
+    v = np.asarray(values, dtype=np.float64).reshape(-1, 1).copy()
+    if backend == "sklearn":
+        from sklearn.cluster import KMeans
+        return KMeans(n_clusters=k, random_state=0, n_init=n_init, max_iter=max_iter).fit(v).cluster_centers_.astype(np.float64)
+    if backend != "gpu":
+        raise ValueError(f"backend {backend!r}: 'gpu' or 'sklearn'")
+    import ctypes as C
+    from . import _lib
+    _lib.require_gpu()
+    n = v.shape[0]
+    if k > n:
+        raise ValueError(f"n_samples={n} should be >= n_clusters={k}.")  # (sklearn's message)
+    tol = float(np.mean(np.var(v, axis=0)) * 1e-4)  # KMeans._tol: from the data as given
+    mean = v.mean(axis=0)                            # "subtract of mean of x for more accurate distance computations"
+    v -= mean
+    first, u, trials = kmeans_draws(n, k, n_init)
+    x = torch.from_numpy(v[:, 0].copy()).cuda()
+    centers = np.empty(k, dtype=np.float64)
+    inertia, n_iter = C.c_double(0.0), C.c_int(0)
+    seeds = np.empty((n_init, k), dtype=np.int32)
+    _lib.check(_lib.lib().fpc_kmeans1d(C.c_void_p(x.data_ptr()), n, k, n_init, trials, first.ctypes.data_as(C.c_void_p),
+                                       u.ctypes.data_as(C.c_void_p), tol, int(max_iter), centers.ctypes.data_as(C.c_void_p),
+                                       C.byref(inertia), C.byref(n_iter), seeds.ctypes.data_as(C.c_void_p),
+                                       C.c_void_p(torch.cuda.current_stream().cuda_stream)), "fpc_kmeans1d")
+    if details is not None:
+        details.update(inertia=inertia.value, n_iter=n_iter.value, seeds=seeds, tol=tol, centred=centers.copy())
+    return centers[:, None] + mean
 
 
 def train(model, cfg, batches, verbose=False):

@@ -28,7 +28,7 @@ extern "C" {
 /* 2: fpc_encode takes the input mask (mask_dev, NULL = thresholds); exports fpc_build_info, fpc_lpcnet_set_chunk_frames
  *    (fpc_lpcnet_workspace_bytes follows the handle's chunk setting).  A binding compares fpc_abi_version() with the
  *    FPC_ABI_VERSION it was written against BEFORE any other call: the symbol sets of versions differ. */
-#define FPC_ABI_VERSION 2
+#define FPC_ABI_VERSION 3
 #define FPC_API __attribute__((visibility("default")))
 
 typedef enum {
@@ -328,6 +328,25 @@ FPC_API int fpc_cb_update(const void* data_dev, int data_f64, int nv, int nd, co
 
 /* np.mean(data, 0) as vq_train takes it (cb_func.py:34): accumulated in the data's own precision */
 FPC_API int fpc_cb_mean0(const void* data_dev, int data_f64, int nv, int nd, double* out_dev, fpc_stream s);
+
+/* ---- scalar codebooks: k-means of one feature (src/train_cb.py:219-226, commented out in the reference) ----
+ * sklearn.cluster.KMeans(n_clusters = k, random_state = 0).fit(v[:, None]).cluster_centers_ as scikit-learn 1.x computes it:
+ * k-means++ seeding with `trials` = 2 + int(ln k) candidates per seed, Lloyd iterations with sklearn's stopping rules (the
+ * labels repeat, or the summed squared centre shift <= tol; the E-step once more in the second case), n_init runs, lowest
+ * inertia wins unless it is the same clustering (csrc/kmeans1d.hip restates the operations that decide an outcome).
+ *   x_dev: n float64 values on the device, CENTRED (sklearn subtracts the mean first: the caller adds it to the centres);
+ *   first_ids[n_init]: each run's first seed; uniforms[n_init][k - 1][trials]: the seeding's uniform draws -- the caller draws
+ *     both from numpy's RandomState(0) in sklearn's order (choice(n, p = 1 / n), then uniform(size = trials) per seed; they do
+ *     not depend on the data), which makes a run pick the seeds sklearn picks; both arrays on the HOST;
+ *   tol: sklearn's absolute tolerance (1e-4 * mean(var(v, axis = 0))); max_iter: 300 in sklearn;
+ *   centers_host[k]; inertia_host, n_iter_host, seeds_host[n_init][k] (the seeds' indices) may be NULL.
+ * Synchronous (the iteration count is data dependent: the stream is synchronised once per Lloyd iteration).
+ * k <= 2048, trials <= 16, n < 2^28.  Every float64 sum has one fixed association (8 points per thread in index order, a
+ * halving tree over 256 threads, block sums one after the other): results are reproducible run to run, which sklearn's OpenMP
+ * reductions are not; against sklearn itself the centres agree to rounding (tests: 1e-9). */
+FPC_API int fpc_kmeans1d(const double* x_dev, long long n, int k, int n_init, int trials, const long long* first_ids,
+                 const double* uniforms, double tol, int max_iter, double* centers_host, double* inertia_host,
+                 int* n_iter_host, int* seeds_host, fpc_stream s);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,215 @@
+"""CPU restatement (numpy) of the scalar codebooks' k-means -- TEST INFRASTRUCTURE, not the product: only tests/ may import it.
+
+What is restated: scikit-learn's `KMeans(n_clusters=k, random_state=0).fit(v[:, None])` for ONE feature, the call the reference
+keeps (commented out) at /root/reference/src/train_cb.py:219-226.  scikit-learn is a third-party dependency that is not part of
+the reference tree (installed here: 1.7.2); its published algorithm (sklearn/cluster/_kmeans.py: KMeans.fit, _kmeans_plusplus,
+_kmeans_single_lloyd; _k_means_lloyd.pyx: _update_chunk_dense; _k_means_common.pyx: _relocate_empty_clusters_dense,
+_average_centers, _center_shift, _inertia_dense; metrics/pairwise.py: _euclidean_distances) is followed operation by operation
+where an operation decides an outcome (seed distances, the E-step's argmin, centre = sum * (1 / count), the stopping rules).
+The long float64 sums have no specified order in sklearn (BLAS / OpenMP reductions); here they have the ONE fixed shape
+csrc/kmeans1d.hip uses -- 8 consecutive points per thread, a halving tree over 256 threads, block sums one after the other --
+so the HIP kernels are compared with this file bit for bit, and this file is pinned to sklearn itself in the CPU suite
+(tests/test_host_cpu.py: the same seeds index for index, centres to 1e-9)."""
+import numpy as np
+
+KT, PPT = 256, 8
+CH = KT * PPT
+
+
+def draws(n, k, n_init, seed=0):
+    """the random draws of sklearn's seeding, in its order, from RandomState(seed): they do not depend on the data
+    (KMeans.fit: one RandomState for all runs; _kmeans_plusplus: choice(n, p = weights / sum) then uniform(size = trials) per
+    further seed).  Returns first_ids (n_init,), uniforms (n_init, k - 1, trials), trials"""
+    rs = np.random.RandomState(seed)
+    trials = 2 + int(np.log(k))
+    p = np.ones(n) / np.ones(n).sum()
+    first = np.empty(n_init, dtype=np.int64)
+    u = np.empty((n_init, max(k - 1, 0), trials))
+    for r in range(n_init):
+        first[r] = rs.choice(n, p=p)
+        for c in range(k - 1):
+            u[r, c] = rs.uniform(size=trials)
+    return first, u, trials
+
+
+def _block_sums(v):
+    """per block of 2048 points: thread t adds its 8 consecutive points in index order, then the halving tree over 256 threads"""
+    n = len(v)
+    nblk = (n + CH - 1) // CH
+    a = np.zeros(nblk * CH)
+    a[:n] = v
+    a = a.reshape(nblk, KT, PPT)
+    acc = np.zeros((nblk, KT))
+    for j in range(PPT):
+        acc = acc + a[:, :, j]
+    h = KT // 2
+    while h >= 1:
+        acc[:, :h] = acc[:, :h] + acc[:, h:2 * h]
+        h //= 2
+    return acc[:, 0].copy()
+
+
+def _seq(v):
+    """v[0] + v[1] + ... one after the other"""
+    return float(np.cumsum(v)[-1])
+
+
+def _seed_dist(c, cc, x, xx):
+    d = ((-2.0 * (c * x)) + cc) + xx
+    return np.where(d > 0.0, d, 0.0)
+
+
+def kmeans_plusplus(x, xx, k, first_id, u):
+    n = len(x)
+    seeds = np.empty(k, dtype=np.int64)
+    seeds[0] = first_id
+    closest = _seed_dist(x[first_id], xx[first_id], x, xx)
+    part = _block_sums(closest)
+    nblk = len(part)
+    for c in range(1, k):
+        prefix = np.cumsum(part)
+        total = prefix[-1]
+        cand = []
+        for t in range(u.shape[1]):
+            rv = u[c - 1, t] * total
+            lo = int(np.searchsorted(prefix, rv, side="left"))
+            pick = n - 1
+            if lo < nblk:
+                # inside the block: thread j starts from Q[j] = the exclusive prefix + the sums of the threads before it (a
+                # thread's sum = its 8 points in index order; Q one thread after the other); the candidate is the first point
+                # whose running value (Q[j] + its thread's points up to it) reaches rv, the point behind the block if none
+                base = prefix[lo - 1] if lo > 0 else 0.0
+                i0, i1 = lo * CH, min((lo + 1) * CH, n)
+                blk = np.zeros(CH)
+                blk[:i1 - i0] = closest[i0:i1]
+                blk = blk.reshape(KT, PPT)
+                S = np.zeros(KT)
+                for j in range(PPT):
+                    S = S + blk[:, j]
+                Q = np.cumsum(np.concatenate([[base], S]))[:KT]
+                run = np.empty((KT, PPT))
+                acc = Q.copy()
+                for j in range(PPT):
+                    acc = acc + blk[:, j]
+                    run[:, j] = acc
+                ok = (run >= rv).reshape(-1)
+                ok[i1 - i0:] = False
+                hit = np.nonzero(ok)[0]
+                pick = min(i0 + int(hit[0]) if len(hit) else i1, n - 1)
+            cand.append(pick)
+        pots, mins = [], []
+        for p in cand:
+            d = _seed_dist(x[p], xx[p], x, xx)
+            m = np.where(closest < d, closest, d)
+            mins.append(m)
+            pots.append(_seq(_block_sums(m)))
+        best = int(np.argmin(np.array(pots)))
+        seeds[c] = cand[best]
+        closest = mins[best]
+        part = _block_sums(closest)
+    return seeds
+
+
+def _assign(x, centers):
+    c2 = centers * centers
+    d = c2[None, :] + (-2.0 * (x[:, None] * centers[None, :]))
+    return np.argmin(d, axis=1).astype(np.int32)
+
+
+def _sums(x, labels, k):
+    n = len(x)
+    rows = (n + KT - 1) // KT
+    xp = np.zeros(rows * KT)
+    xp[:n] = x
+    lp = np.full(rows * KT, -1, dtype=np.int64)
+    lp[:n] = labels
+    xp, lp = xp.reshape(rows, KT), lp.reshape(rows, KT)
+    acc = np.zeros((k, KT))
+    cnt = np.zeros((k, KT))
+    js = np.arange(k)[:, None]
+    for r in range(rows):
+        m = lp[r][None, :] == js
+        acc = acc + np.where(m, xp[r][None, :], 0.0)
+        cnt = cnt + m
+    h = KT // 2
+    while h >= 1:
+        acc[:, :h] = acc[:, :h] + acc[:, h:2 * h]
+        cnt[:, :h] = cnt[:, :h] + cnt[:, h:2 * h]
+        h //= 2
+    return acc[:, 0].copy(), cnt[:, 0].copy()
+
+
+def _relocate(x, labels, centers_old, s, cnt):
+    empty = np.nonzero(cnt == 0.0)[0]
+    if len(empty) == 0:
+        return
+    d = x - centers_old[labels]
+    dist = d * d
+    if dist.max() == 0:
+        return
+    # the farthest first, the lower index on equal distances (sklearn takes them from an argpartition: order unspecified)
+    order = np.lexsort((np.arange(len(x)), -dist))[:len(empty)]
+    for e, p in zip(empty, order):
+        old = labels[p]
+        s[old] = s[old] - x[p]
+        s[e] = x[p]
+        cnt[e] = 1.0
+        cnt[old] = cnt[old] - 1.0
+
+
+def _same_clustering(l1, l2, k):
+    mapping = np.full(k, -1, dtype=np.int64)
+    for a, b in zip(l1, l2):
+        if mapping[a] == -1:
+            mapping[a] = b
+        elif mapping[a] != b:
+            return False
+    return True
+
+
+def kmeans1d(x, k, first_ids, uniforms, tol, max_iter=300):
+    """x: centred float64 values.  Returns (centers (k,), inertia, n_iter, seeds (n_init, k)) of the winning run"""
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    xx = x * x
+    best = None
+    all_seeds = []
+    for r in range(len(first_ids)):
+        seeds = kmeans_plusplus(x, xx, k, int(first_ids[r]), uniforms[r])
+        all_seeds.append(seeds)
+        centers = x[seeds].copy()
+        labels_old = np.full(len(x), -1, dtype=np.int32)
+        strict = False
+        for it in range(max_iter):
+            labels = _assign(x, centers)
+            s, cnt = _sums(x, labels, k)
+            _relocate(x, labels, centers, s, cnt)
+            new = np.where(cnt > 0.0, s * (1.0 / np.where(cnt > 0.0, cnt, 1.0)), s)
+            d = centers - new
+            sh = np.sqrt(d * d)
+            shift = _seq(sh * sh)
+            centers = new
+            if np.array_equal(labels, labels_old):
+                strict = True
+                break
+            if shift <= tol:
+                break
+            labels_old = labels
+        if not strict:
+            labels = _assign(x, centers)
+        d = x - centers[labels]
+        inertia = _seq(_block_sums(d * d))
+        if best is None or (inertia < best[1] and not _same_clustering(labels, best[3], k)):
+            best = (centers, inertia, it + 1, labels)
+    return best[0], best[1], best[2], np.array(all_seeds)
+
+
+def fit(values, k, n_init=10, seed=0, max_iter=300):
+    """sklearn.cluster.KMeans(n_clusters=k, random_state=seed, n_init=n_init).fit(values[:, None]).cluster_centers_ restated:
+    the tolerance from the data as given (KMeans._tol, before the mean is subtracted), the mean subtracted, added back at the end"""
+    v = np.asarray(values, dtype=np.float64).reshape(-1, 1).copy()
+    tol = float(np.mean(np.var(v, axis=0)) * 1e-4)
+    mean = v.mean(axis=0)
+    v -= mean
+    first, u, _ = draws(len(v), k, n_init, seed)
+    centers, inertia, n_iter, seeds = kmeans1d(v[:, 0], k, first, u, tol, max_iter)
+    return (centers[:, None] + mean), inertia, n_iter, seeds

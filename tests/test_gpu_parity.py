@@ -1480,3 +1480,76 @@ def test_encoder_mask_mode_and_multi_stage_lo_vs_reference_golden(torch_cuda, mo
     from fpcodec_amd._lib import FpcError
     with pytest.raises(FpcError, match="mask of shape"):
         model.encoder(cfg, torch.from_numpy(feat), torch.zeros(3, 30), 0.09, 0.28)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,k", [(5000, 8), (12000, 32), (3000, 64), (2049, 5), (40000, 16)])
+def test_scalar_codebook_kmeans_equals_oracle_bitwise_and_sklearn(torch_cuda, n, k):
+    """fpc_kmeans1d (csrc/kmeans1d.hip) = the reference's commented KMeans call (train_cb.py:219-226): seeds, iteration count,
+    inertia and centres BIT-IDENTICAL to oracle/kmeans1d_oracle.py (which the CPU suite pins to scikit-learn), and against
+    scikit-learn itself: the same seeds as its kmeans_plusplus, centres to 1e-9 (its sums have no specified order), the same
+    result twice (sklearn's OpenMP reductions do not promise that)"""
+    from sklearn.cluster import KMeans
+    from fpcodec_amd import train_cb
+    from oracle import kmeans1d_oracle as KO
+    rs = np.random.RandomState(100 + k)
+    v = (rs.laplace(size=n) * 0.1).astype(np.float32).astype(np.float64)
+    d = {}
+    c = train_cb.train_scalar_codebook(v, k, n_init=3, details=d)
+    assert c.shape == (k, 1) and c.dtype == np.float64
+    oc, oinertia, oiter, oseeds = KO.fit(v, k, n_init=3)
+    assert np.array_equal(d["seeds"], oseeds)
+    assert d["n_iter"] == oiter and d["inertia"] == oinertia
+    assert np.array_equal(c, oc)
+    km = KMeans(n_clusters=k, random_state=0, n_init=3).fit(v[:, None])
+    assert np.abs(c - km.cluster_centers_).max() < 1e-9 and d["n_iter"] == km.n_iter_
+    d2 = {}
+    c2 = train_cb.train_scalar_codebook(v, k, n_init=3, details=d2)
+    assert np.array_equal(c, c2) and d2["inertia"] == d["inertia"]
+
+
+@pytest.mark.gpu
+def test_scalar_codebook_kmeans_edges(torch_cuda):
+    """k = 1 (no seeding draws), heavy duplicates (fewer distinct values than a block), an empty cluster relocated (two equal
+    values seeded: impossible through k-means++, which never draws a point at distance 0 -- reached through first_ids /
+    uniforms that force it), refusals"""
+    import ctypes as C
+    from fpcodec_amd import _lib, train_cb
+    from oracle import kmeans1d_oracle as KO
+    rs = np.random.RandomState(7)
+    v = rs.normal(size=3000)
+    c = train_cb.train_scalar_codebook(v, 1, n_init=2)
+    assert abs(c[0, 0] - v.mean()) < 1e-12
+    dup = np.round(rs.normal(size=6000) * 4) / 4  # ~30 distinct values
+    d = {}
+    c = train_cb.train_scalar_codebook(dup, 6, n_init=2, details=d)
+    oc, oin, oit, oseeds = KO.fit(dup, 6, n_init=2)
+    assert np.array_equal(c, oc) and np.array_equal(d["seeds"], oseeds) and d["inertia"] == oin
+    with pytest.raises(ValueError, match="should be >= n_clusters"):
+        train_cb.train_scalar_codebook(np.arange(3.0), 4)
+    L = _lib.lib()
+    # the relocation: all candidates of the second seed drawn at u = 0 (-> point 0) behind first seed 0: two equal centres, the
+    # second one wins no point in the first E-step and takes the point farthest from its centre (sklearn's rule, the oracle's)
+    xs = rs.laplace(size=5000) * 0.1
+    xs -= xs.mean()
+    k, trials = 5, 3
+    first = np.zeros(1, dtype=np.int64)
+    u = rs.uniform(size=(1, k - 1, trials))
+    u[0, 0] = 0.0
+    tol = float(np.var(xs) * 1e-4)
+    oc, oin, oit, oseeds = KO.kmeans1d(xs, k, first, u, tol)
+    assert oseeds[0][0] == oseeds[0][1] == 0
+    xd = torch_cuda.from_numpy(xs).cuda()
+    out, inertia, n_iter, seeds = np.zeros(k), C.c_double(), C.c_int(), np.zeros((1, k), dtype=np.int32)
+    _lib.check(L.fpc_kmeans1d(C.c_void_p(xd.data_ptr()), len(xs), k, 1, trials, first.ctypes.data_as(C.c_void_p),
+                              u.ctypes.data_as(C.c_void_p), tol, 300, out.ctypes.data_as(C.c_void_p), C.byref(inertia),
+                              C.byref(n_iter), seeds.ctypes.data_as(C.c_void_p), None), "fpc_kmeans1d")
+    assert np.array_equal(seeds, oseeds) and np.array_equal(out, oc) and inertia.value == oin and n_iter.value == oit
+    x = torch_cuda.zeros(10, dtype=torch_cuda.float64, device="cuda")
+    out = np.zeros(4)
+    rc = L.fpc_kmeans1d(C.c_void_p(x.data_ptr()), 10, 4, 1, 3, first.ctypes.data_as(C.c_void_p), None, 0.0, 300,
+                        out.ctypes.data_as(C.c_void_p), None, None, None, None)
+    assert rc == -1 and b"uniform draws" in L.fpc_last_error()
+    rc = L.fpc_kmeans1d(C.c_void_p(x.data_ptr()), 10, 4000, 1, 3, first.ctypes.data_as(C.c_void_p), None, 0.0, 300,
+                        out.ctypes.data_as(C.c_void_p), None, None, None, None)
+    assert rc == -1 and b"k = 4000" in L.fpc_last_error()

@@ -30,9 +30,9 @@ def test_abi_exports_every_declared_symbol(built):
     for s in declared:
         assert hasattr(L, s), s
     m = re.search(r"#define FPC_ABI_VERSION (\d+)", hdr)
-    assert m and L.fpc_abi_version() == int(m.group(1)) == built.ABI_VERSION == 2
+    assert m and L.fpc_abi_version() == int(m.group(1)) == built.ABI_VERSION == 3
     # the shipped library is built without -D tunables and says so (a variant build lists them: tools/build_variant.sh)
-    assert L.fpc_build_info() == b"fpcodec abi 2 gfx950"
+    assert L.fpc_build_info() == b"fpcodec abi 3 gfx950"
 
 
 def test_binding_names_a_library_of_another_abi_version(built, tmp_path, monkeypatch):
@@ -45,7 +45,7 @@ def test_binding_names_a_library_of_another_abi_version(built, tmp_path, monkeyp
     subprocess.check_call(["gcc", "-shared", "-fPIC", "-o", str(so), str(src)])
     monkeypatch.setattr(built, "LIB_PATH", str(so))
     monkeypatch.setattr(built, "_lib", None)
-    with pytest.raises(built.FpcError, match="ABI version 1, this binding needs 2"):
+    with pytest.raises(built.FpcError, match="ABI version 1, this binding needs 3"):
         built.lib()
 
 
@@ -403,7 +403,7 @@ def test_train_cb_file_formats_and_scalar_codebook(tmp_path):
     assert b.dtype == object and b[1].shape == (5, 17)
     assert [s.shape for s in _read_vq_file(str(tmp_path / "b.npy"))] == [(8, 17), (5, 17)]
     vals = np.concatenate([rng.normal(-1, .01, 200), rng.normal(0.5, .01, 300), rng.normal(2, .01, 100)])
-    c = train_cb.train_scalar_codebook(vals, 3)
+    c = train_cb.train_scalar_codebook(vals, 3, backend="sklearn")
     assert c.shape == (3, 1) and c.dtype == np.float64
     assert np.allclose(np.sort(c[:, 0]), [-1, .5, 2], atol=0.01)
 
@@ -485,3 +485,78 @@ def test_no_hand_placed_vector_loads_in_the_predictor_sources():
         text = open(os.path.join(src, f)).read()
         for stmt in re.findall(r'asm\s*(?:volatile)?\s*\((.*?)\);', text, re.S):
             assert "_load_" not in stmt, (f, stmt[:120])
+
+
+def _scalar_residuals(n, seed):
+    """float32-born scalar residuals (what train_cb.py:174-175 collects), Laplace-shaped like prediction residuals"""
+    rs = np.random.RandomState(seed)
+    return (rs.laplace(size=n) * 0.1).astype(np.float32).astype(np.float64)
+
+
+@pytest.mark.parametrize("n,k", [(5000, 8), (12000, 32), (3000, 64)])
+def test_kmeans_oracle_is_pinned_to_sklearn(n, k):
+    """oracle/kmeans1d_oracle.py (what csrc/kmeans1d.hip is bit-identical to) against scikit-learn itself, the reference's call
+    (train_cb.py:219-226): the seeding picks sklearn's seeds index for index (same RandomState stream, same candidates, same
+    winners), Lloyd stops in the same iteration, centres and inertia agree to rounding -- sklearn's long sums have no
+    specified order, the oracle's have one"""
+    from sklearn.cluster import KMeans, kmeans_plusplus
+    from sklearn.utils.extmath import row_norms
+    sys.path.insert(0, ROOT)
+    from oracle import kmeans1d_oracle as KO
+    from fpcodec_amd import train_cb
+    v = _scalar_residuals(n, 3 + k)
+    c, inertia, n_iter, seeds = KO.fit(v, k, n_init=3)
+    km = KMeans(n_clusters=k, random_state=0, n_init=3).fit(v[:, None])
+    assert np.abs(c - km.cluster_centers_).max() < 1e-12
+    assert abs(inertia - km.inertia_) <= 1e-12 * km.inertia_ and n_iter == km.n_iter_
+    X = v[:, None] - v[:, None].mean(axis=0)
+    _, idx = kmeans_plusplus(X, k, random_state=np.random.RandomState(0), x_squared_norms=row_norms(X, squared=True))
+    assert np.array_equal(idx, seeds[0])
+    # the product's host half draws the same stream
+    f0, u0, t0 = KO.draws(n, k, 3)
+    f1, u1, t1 = train_cb.kmeans_draws(n, k, 3)
+    assert t0 == t1 == 2 + int(np.log(k)) and np.array_equal(f0, f1) and np.array_equal(u0, u1)
+
+
+def test_kmeans_oracle_relocates_an_empty_cluster_like_sklearn():
+    """a cluster that loses every point (sklearn: _relocate_empty_clusters_dense -- the empty cluster takes the point farthest
+    from its centre, the labels stay): forced by handing the Lloyd loop two equal centres; against sklearn's own
+    _kmeans_single_lloyd from the same initial centres"""
+    from sklearn.cluster import _kmeans as SK
+    sys.path.insert(0, ROOT)
+    from oracle import kmeans1d_oracle as KO
+    v = _scalar_residuals(2000, 9)
+    x = v - v.mean()
+    init = np.array([x[5], x[5], x[700], x[1500]])  # the second of two equal centres wins no point (first minimum)
+    labels = KO._assign(x, init)
+    s, cnt = KO._sums(x, labels, 4)
+    assert cnt[1] == 0.0
+    KO._relocate(x, labels, init, s, cnt)
+    far = int(np.argmax((x - init[labels]) ** 2))
+    assert cnt[1] == 1.0 and s[1] == x[far]
+    sk_labels, sk_inertia, sk_centers, sk_iter = SK._kmeans_single_lloyd(
+        x[:, None].copy(), np.ones(len(x)), init[:, None].copy(), max_iter=300, tol=float(np.var(x) * 1e-4), n_threads=1)
+    # the oracle's loop from the same start
+    centers, labels_old = init.copy(), np.full(len(x), -1, dtype=np.int32)
+    for it in range(300):
+        labels = KO._assign(x, centers)
+        s, cnt = KO._sums(x, labels, 4)
+        KO._relocate(x, labels, centers, s, cnt)
+        new = np.where(cnt > 0.0, s * (1.0 / np.where(cnt > 0.0, cnt, 1.0)), s)
+        shift = float(np.cumsum((centers - new) ** 2)[-1])
+        centers = new
+        if np.array_equal(labels, labels_old) or shift <= float(np.var(x) * 1e-4):
+            break
+        labels_old = labels
+    assert it + 1 == sk_iter and np.abs(centers - sk_centers[:, 0]).max() < 1e-12
+
+
+def test_scalar_codebook_gpu_backend_needs_the_gpu(built):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from fpcodec_amd import train_cb
+    with pytest.raises(built.FpcError, match="no CPU fallback"):
+        train_cb.train_scalar_codebook(np.arange(100.0), 4)
+    with pytest.raises(ValueError):
+        train_cb.train_scalar_codebook(np.arange(100.0), 4, backend="numpy")
