@@ -45,4 +45,8 @@ open(os.path.join(P, "r05_train_timing.txt"), "w").write(
     f"tree {head}; tools/time_train.py at the reference's batch (100 x 150, train_frame.py:198-204), twice; then the backward pass on the "
     "row-split kernel; then the stage profiles of k_train_bwd_ws (one thread of each track); the rocprofv3 kernel table of the step: r05_train_kernel_stats.csv\n" +
     "".join(l for l in open(os.path.join(o, "train.txt")) if "amdgpu.ids" not in l))
+km = os.path.join(o, "kmeans.txt")
+if os.path.exists(km):
+    old = open(os.path.join(P, "r05_kmeans.txt")).read().split("\n\n")
+    open(os.path.join(P, "r05_kmeans.txt"), "w").write(old[0] + f"\n(tree {head})\n\n" + open(km).read() + "\n" + "\n\n".join(old[2:]))
 print("collected into profiles/r05_*")

@@ -27,4 +27,5 @@ FPC_LIB_PATH=build_variants/lib_bwprof0.so timeout -k 10 200 python tools/time_t
 FPC_LIB_PATH=build_variants/lib_bwprof256.so timeout -k 10 200 python tools/time_train.py 2>&1 | grep "k_train_bwd_ws" | tail -1 >> $o/train.txt
 echo "== training step: counters"; TAG=r05 bash tools/train_pmc.sh > $o/train_pmc.log 2>&1; grep "k_train_bwd_ws" gpurun_out/r05/train_pmc/summary.txt | head -20
 cat $o/train.txt
+echo "== scalar codebooks: k-means"; (timeout -k 10 300 python tools/time_kmeans.py; timeout -k 10 400 python tools/time_kmeans.py 2000000 256) 2>&1 | grep -v amdgpu > $o/kmeans.txt; cat $o/kmeans.txt
 ls $o
