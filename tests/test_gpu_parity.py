@@ -557,10 +557,11 @@ def test_train_step_vs_torch_golden_and_oracle(torch_cuda, synth, golden, oracle
 
 def test_train_backward_weights_stationary_equals_row_split_and_oracle(torch_cuda, synth, oracle, monkeypatch):
     """back-propagation on the weights-stationary kernel (csrc/predictor_bwd_ws.h: 16 utterances a group on the 32
-    workgroups of an XCD, the transposed slices resident, W^T d on f32 MFMA, one hop per step) against the row-split kernel
-    (FPC_TRAIN_BWD_ROWSPLIT=1: one utterance per workgroup) -- loss, every gradient, every parameter after two steps, bit for
-    bit -- for 2 full groups + a part-filled one, for the shortest sequence (2 frames) and on both hop paths; and against
-    the CPU oracle at 19 x 9 (a full and a part-filled group)"""
+    workgroups of an XCD, the transposed slices resident, W^T d on f32 MFMA, the two recurrences as two concurrent tracks of
+    four waves) against the row-split kernel (FPC_TRAIN_BWD_ROWSPLIT=1: one utterance per workgroup) -- loss, every gradient,
+    every parameter after two steps, bit for bit -- for 2 full groups + a part-filled one, for the shortest sequence (2
+    frames), for more groups than the chip has XCDs (130 utterances: 9 groups) and on both hop paths; and against the CPU
+    oracle at 19 x 9 (a full and a part-filled group).  (tools/stress_train_bwd.py: eight more shapes, repeated)"""
     from fpcodec_amd.train_frame import Trainer
     from fpcodec_amd.wavernn import Wavernn
 
@@ -574,7 +575,7 @@ def test_train_backward_weights_stationary_equals_row_split_and_oracle(torch_cud
         sd = m.state_dict()
         return [np.float32(losses)] + [g[k] for k in sorted(g)] + [sd[k].numpy() for k in sorted(sd)]
 
-    for B, L in ((37, 21), (16, 2), (3, 5)):
+    for B, L in ((37, 21), (16, 2), (3, 5), (130, 7)):
         feat = synth.predictor_features(B, L, utt0=4400)
         monkeypatch.setenv("FPC_TRAIN_BWD_ROWSPLIT", "1")
         ref = run(feat)
