@@ -15,6 +15,7 @@
 // evaluated as k-ordered fmaf chains from the bias (what a gfx950 f32 MFMA accumulates),
 // distances in float64 with numpy's pairwise association, so results match the CPU
 // oracle bit for bit and the reference's indices exactly.
+#include <algorithm>
 #include "fpc_common.h"
 #include <atomic>
 #include <string>
@@ -1217,14 +1218,27 @@ __device__ __forceinline__ void colsum(const GradJobs& J, int N, int job, int r)
     for (; n < N; ++n) s = s + D[(size_t)n * R + r];
     out[r] = s;
 }
-// grid z: 5 GSEG slices of MFMA tiles, then 5 slices (one per job, blockIdx.y = 0 only) of bias sums: those are strictly
-// sequential adds, latency-bound on a few waves (0.18 ms as a launch of their own) -- beside the tiles they cost nothing
-__global__ __launch_bounds__(256) void k_grad_tn(const GradJobs J, int N, int seglen) {
-    if (blockIdx.z >= 5 * GSEG) {
-        if (blockIdx.y == 0) colsum(J, N, blockIdx.z - 5 * GSEG, blockIdx.x * 256 + threadIdx.x);
+// Which tile a workgroup computes (k_grad_tn's 1-D grid).  The workgroups of a launch go to the XCDs round-robin by linear
+// index, and every XCD has its own L2: workgroup l takes sample segment l % 8 -- with 8 segments (ORC_GSEG) and 8 XCDs ALL tiles
+// of a segment, of every job, run on ONE XCD, where the rows of A and D they share are fetched into the L2 once.  (As a 3-D
+// grid, tiles sharing D sat on different XCDs: TCC_MISS 8.7 M of 9.0 M requests, 1.1 GB per launch from beyond the L2 for
+// 240 MB of operands.)  Slots = the (job, column block, row block) tiles of one segment, the largest job first; behind them
+// `ncol` workgroups of bias sums (strictly sequential adds, latency-bound on a few waves: beside the tiles they cost nothing).
+struct GradMap {
+    unsigned char job[128], bx[128], by[128];
+    unsigned char cjob[32], cbx[32];
+    int nslots, ncol;
+};
+static_assert(GSEG == 8, "k_grad_tn: one sample segment per XCD");
+__global__ __launch_bounds__(256) void k_grad_tn(const GradJobs J, int N, int seglen, const GradMap M) {
+    const int lin = blockIdx.x;
+    if (lin >= GSEG * M.nslots) {
+        const int c = lin - GSEG * M.nslots;
+        colsum(J, N, M.cjob[c], M.cbx[c] * 256 + threadIdx.x);
         return;
     }
-    const int job = blockIdx.z / GSEG, sg = blockIdx.z % GSEG;
+    const int sg = lin % GSEG, slot = lin / GSEG;
+    const int job = M.job[slot], bxi = M.bx[slot], byi = M.by[slot];
     const float* __restrict__ A = J.A[job];
     const float* __restrict__ D = J.D[job];
     const int K = J.K[job], R = J.R[job];
@@ -1232,9 +1246,8 @@ __global__ __launch_bounds__(256) void k_grad_tn(const GradJobs J, int N, int se
     const int nbeg = sg * seglen, nend = (sg + 1) * seglen < N ? (sg + 1) * seglen : N;
     // one wave = GKT x 16 k-rows x 64 r-columns: GKT A fragments + 4 D fragments per 4 samples feed 4 GKT MFMAs (round 5: GKT = 4,
     // 0.5 loads per MFMA; 16 k-rows per wave was 1.25 and L2-bound at 21 % of the f32 MFMA peak)
-    if ((int)blockIdx.y * 16 * GKT >= K) return;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int k0 = blockIdx.y * 16 * GKT, r0 = (blockIdx.x * 4 + wave) * 64;
+    const int k0 = byi * 16 * GKT, r0 = (bxi * 4 + wave) * 64;
     if (r0 >= R) return;
     const int fi = lane & 15, kq = lane >> 4;
     f32x4 acc[GKT][4];
@@ -1245,9 +1258,8 @@ __global__ __launch_bounds__(256) void k_grad_tn(const GradJobs J, int N, int se
 #ifndef FPC_GUN
 #define FPC_GUN 4
 #endif
-    constexpr int UN = FPC_GUN;  // groups of 4 samples fetched ahead of the MFMA chains (which stay in sample order)
-    for (int n0 = nbeg; n0 < nend; n0 += 4 * UN) {
-        float a[UN][GKT], d[UN][4];
+    constexpr int UN = FPC_GUN;  // groups of 4 samples per fetch (the MFMA chains stay in sample order)
+    auto fetch = [&](float (&a)[UN][GKT], float (&d)[UN][4], int n0) {
 #pragma unroll
         for (int u = 0; u < UN; ++u) {
             const int n = n0 + 4 * u + kq;
@@ -1263,12 +1275,21 @@ __global__ __launch_bounds__(256) void k_grad_tn(const GradJobs J, int N, int se
                 d[u][j] = (vn && rc < R) ? D[(size_t)n * R + rc] : 0.0f;
             }
         }
+    };
+    auto products = [&](const float (&a)[UN][GKT], const float (&d)[UN][4]) {
 #pragma unroll
         for (int u = 0; u < UN; ++u)
 #pragma unroll
             for (int kt = 0; kt < GKT; ++kt)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) acc[kt][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][kt], d[u][j], acc[kt][j], 0, 0, 0);
+    };
+    // (two register buffers -- the next samples on their way during the products -- measured equal without the XCD map and
+    //  slower with it, 2.05 against 2.00 ms per step: 240 VGPRs leave one wave per SIMD; profiles/r05_ablations.txt item 11)
+    for (int n0 = nbeg; n0 < nend; n0 += 4 * UN) {
+        float a[UN][GKT], d[UN][4];
+        fetch(a, d, n0);
+        products(a, d);
     }
 #pragma unroll
     for (int kt = 0; kt < GKT; ++kt)
@@ -2038,7 +2059,34 @@ extern "C" int fpc_trainer_step(fpc_trainer* t, const float* feat_dev, int B, in
         maxK = g.K > maxK ? g.K : maxK;
     }
     const int seglen = ((N + 4 * GSEG - 1) / (4 * GSEG)) * 4;
-    hipLaunchKernelGGL(k_grad_tn, dim3((maxR + 255) / 256, (maxK + 16 * GKT - 1) / (16 * GKT), 5 * GSEG + 5), dim3(256), 0, st, J, N, seglen);
+    GradMap M;
+    M.nslots = 0, M.ncol = 0;
+    {
+        int order[5] = {0, 1, 2, 3, 4};  // the jobs with the most tiles first (they are what a late start would leave running alone)
+        auto tiles = [&](int j) { return ((J.K[j] + 16 * GKT - 1) / (16 * GKT)) * ((J.R[j] + 255) / 256); };
+        std::sort(order, order + 5, [&](int a, int b) { return tiles(a) > tiles(b); });
+        for (int o = 0; o < 5; ++o) {
+            const int j = order[o];
+            for (int y = 0; y < (J.K[j] + 16 * GKT - 1) / (16 * GKT); ++y)
+                for (int x = 0; x < (J.R[j] + 255) / 256; ++x) {
+                    if (M.nslots >= 128) {
+                        fpc::set_error("fpc_trainer_step: more than 128 gradient tiles per sample segment");
+                        return FPC_ERR_CAPACITY;
+                    }
+                    M.job[M.nslots] = (unsigned char)j, M.bx[M.nslots] = (unsigned char)x, M.by[M.nslots] = (unsigned char)y;
+                    ++M.nslots;
+                }
+        }
+        for (int j = 0; j < 5; ++j)
+            for (int x = 0; x < (J.R[j] + 255) / 256; ++x) {
+                if (M.ncol >= 32) {
+                    fpc::set_error("fpc_trainer_step: more than 32 bias-sum workgroups");
+                    return FPC_ERR_CAPACITY;
+                }
+                M.cjob[M.ncol] = (unsigned char)j, M.cbx[M.ncol] = (unsigned char)x, ++M.ncol;
+            }
+    }
+    hipLaunchKernelGGL(k_grad_tn, dim3(GSEG * M.nslots + M.ncol), dim3(256), 0, st, J, N, seglen, M);
     hipLaunchKernelGGL(k_grad_reduce, dim3((unsigned)(((size_t)maxK * maxR + 255) / 256), 5), dim3(256), 0, st, J, p->status_dev,
                        t->latch.as<unsigned>());
     t->step += 1;
