@@ -763,6 +763,7 @@ __device__ __forceinline__ bool ws_foreground(const WsCtx& X, WsLds& L, const Ws
     }
     WSTAMP(1)
     // ---- GRU1 gates of this workgroup's 12 units x 16 utterances: 48 values per wave; torch.nn.GRU rows [r; z; n]
+    float sa[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     {
         const int base = X.slice * WV1 + 48 * fw;
         if (lane < 48) {
@@ -782,15 +783,7 @@ __device__ __forceinline__ bool ws_foreground(const WsCtx& X, WsLds& L, const Ws
             const float hp = L.h1[base + lane];
             const float hn = fmaf(z, hp - n, n);
             L.h1[base + lane] = hn;
-            if (SAVE && (lane & 15) < X.nu) {
-                const size_t o = ((size_t)(X.b0 + (lane & 15)) * X.Lf + t) * WH1 + WU1 * X.slice + 3 * fw + (lane >> 4);
-                sv->h1p[o] = hp;
-                sv->r1[o] = r;
-                sv->z1[o] = z;
-                sv->n1[o] = n;
-                sv->hn1[o] = ghn;
-                sv->h1[o] = hn;
-            }
+            if (SAVE) sa[0] = hp, sa[1] = r, sa[2] = z, sa[3] = n, sa[4] = ghn, sa[5] = hn;
         }
         // (the same wave reads what it has just written: one in-order LDS queue per wave)
         if (lane < 16) {
@@ -799,6 +792,17 @@ __device__ __forceinline__ bool ws_foreground(const WsCtx& X, WsLds& L, const Ws
         }
     }
     df_signal(&L.sig[WSIG_P1]);  // (the background starts polling now, not before)
+    // the training forward's saved activations: BEHIND the publication (a wave's vector-memory instructions leave in order:
+    // six stores in front of the granule are six stores' worth of issue time on the hop)
+    if (SAVE && lane < 48 && (lane & 15) < X.nu) {
+        const size_t o = ((size_t)(X.b0 + (lane & 15)) * X.Lf + t) * WH1 + WU1 * X.slice + 3 * fw + (lane >> 4);
+        sv->h1p[o] = sa[0];
+        sv->r1[o] = sa[1];
+        sv->z1[o] = sa[2];
+        sv->n1[o] = sa[3];
+        sv->hn1[o] = sa[4];
+        sv->h1[o] = sa[5];
+    }
     WSTAMP(2)
     if (fw != 0) {
         if (!ws_gather1(X, L, ft - 64, epoch, false, t)) return false;
@@ -834,7 +838,12 @@ __device__ __forceinline__ bool ws_foreground(const WsCtx& X, WsLds& L, const Ws
         const float hn = fmaf(z, hp - n, n);
         L.h2[base + v] = hn;
         if ((v & 15) == X.own) L.h2own[WU2 * X.slice + (v >> 4)] = hn;
-        if (SAVE && (v & 15) < X.nu) {
+        if (lane < WQ2) {
+            const int i0 = 3 * lane, i1 = i0 + 1 < WV2 ? i0 + 1 : WV2 - 1, i2 = i0 + 2 < WV2 ? i0 + 2 : WV2 - 1;
+            ws_store(X, WOFF_H2 + (t & 1) * WNS * WQ2 + X.slice * WQ2 + lane, epoch, L.h2[base + i0], L.h2[base + i1], L.h2[base + i2]);
+        }
+        df_signal(&L.sig[WSIG_P2]);
+        if (SAVE && (v & 15) < X.nu) {  // (behind the publication, as GRU1's)
             const size_t o = ((size_t)(X.b0 + (v & 15)) * X.Lf + t) * WH2 + WU2 * X.slice + (v >> 4);
             sv->h2p[o] = hp;
             sv->r2[o] = r;
@@ -844,11 +853,6 @@ __device__ __forceinline__ bool ws_foreground(const WsCtx& X, WsLds& L, const Ws
             sv->h2[o] = hn;
             sv->relu[o] = hn > 0.0f ? hn : 0.0f;
         }
-        if (lane < WQ2) {
-            const int i0 = 3 * lane, i1 = i0 + 1 < WV2 ? i0 + 1 : WV2 - 1, i2 = i0 + 2 < WV2 ? i0 + 2 : WV2 - 1;
-            ws_store(X, WOFF_H2 + (t & 1) * WNS * WQ2 + X.slice * WQ2 + lane, epoch, L.h2[base + i0], L.h2[base + i1], L.h2[base + i2]);
-        }
-        df_signal(&L.sig[WSIG_P2]);
     }
     WSTAMP(7)
     if (fw == 0) {
