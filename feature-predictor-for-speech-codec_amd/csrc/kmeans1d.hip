@@ -277,7 +277,8 @@ __global__ __launch_bounds__(KT) void k_km_sums(const double* __restrict__ x, co
 
 // _relocate_empty_clusters_dense: the m empty clusters, in index order, take the m points farthest from their centres, farthest
 // first (sklearn takes them from an argpartition, whose order among the m is not specified; lower index first on equal
-// distances); the labels stay as they are.  One block; nothing to do (the usual case) when no cluster is empty.
+// distances); the labels stay as they are; nothing is relocated when every point sits on its centre.  One block; nothing to do
+// (the usual case) when no cluster is empty.
 __global__ __launch_bounds__(1024) void k_km_relocate(const double* __restrict__ x, const int* __restrict__ labels, long long n,
                                                       const double* __restrict__ centers_old, int k, double* __restrict__ sum,
                                                       double* __restrict__ cnt, int* __restrict__ taken) {
@@ -322,6 +323,8 @@ __global__ __launch_bounds__(1024) void k_km_relocate(const double* __restrict__
             }
             __syncthreads();
         }
+        // "Happens when there are more clusters than non-duplicate samples. Relocating is pointless in this case." (sklearn)
+        if (r == 0 && !(bv[0] > 0.0)) return;  // (np.max(distances) == 0; block-uniform: every thread reads the same bv[0])
         if (threadIdx.x == 0 && bi[0] < n) {
             const long long p = bi[0];
             const int e = empty[r], old = labels[p];
@@ -335,15 +338,31 @@ __global__ __launch_bounds__(1024) void k_km_relocate(const double* __restrict__
     }
 }
 
-// _average_centers and _center_shift: new centre = sum * (1 / count); scal[0] = sum_j (sqrt((old - new)^2))^2, one after the other
+// _average_centers and _center_shift: new centre = sum * (1 / count); a cluster that is STILL empty (more clusters than
+// distinct values) goes where sklearn puts it: "at the location of the biggest cluster" = entry argmax(count) of the array it
+// is averaging in place, in index order -- the averaged centre if that cluster comes before it, its raw SUM if it comes after.
+// scal[0] = sum_j (sqrt((old - new)^2))^2, one after the other
 __global__ __launch_bounds__(KT) void k_km_average(const double* __restrict__ sum, const double* __restrict__ cnt,
                                                    const double* __restrict__ centers_old, int k, double* __restrict__ centers_new,
                                                    double* __restrict__ shift2, double* __restrict__ scal) {
+    __shared__ int am;
+    if (threadIdx.x == 0) {
+        int a = 0;
+        for (int j = 1; j < k; ++j)
+            if (cnt[j] > cnt[a]) a = j;  // np.argmax: the first maximum
+        am = a;
+    }
+    __syncthreads();
     for (int j = threadIdx.x; j < k; j += KT) {
-        double c = sum[j];
+        double c;
         if (cnt[j] > 0.0) {
             const double alpha = 1.0 / cnt[j];
-            c = c * alpha;
+            c = sum[j] * alpha;
+        } else if (j > am && cnt[am] > 0.0) {
+            const double alpha = 1.0 / cnt[am];
+            c = sum[am] * alpha;
+        } else {
+            c = sum[am];
         }
         centers_new[j] = c;
         const double d = centers_old[j] - c;

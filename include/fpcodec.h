@@ -343,7 +343,9 @@ FPC_API int fpc_cb_mean0(const void* data_dev, int data_f64, int nv, int nd, dou
  * Synchronous (the iteration count is data dependent: the stream is synchronised once per Lloyd iteration).
  * k <= 2048, trials <= 16, n < 2^28.  Every float64 sum has one fixed association (8 points per thread in index order, a
  * halving tree over 256 threads, block sums one after the other): results are reproducible run to run, which sklearn's OpenMP
- * reductions are not; against sklearn itself the centres agree to rounding (tests: 1e-9). */
+ * reductions are not; against sklearn itself the centres agree to rounding (tests: 1e-9).  With fewer distinct values than
+ * clusters the surplus centres are duplicates of existing ones (sklearn's "location of the biggest cluster" rule is followed);
+ * where sklearn's own rounding noise then decides a relocation, the duplicate may sit on a different existing centre. */
 FPC_API int fpc_kmeans1d(const double* x_dev, long long n, int k, int n_init, int trials, const long long* first_ids,
                  const double* uniforms, double tol, int max_iter, double* centers_host, double* inertia_host,
                  int* n_iter_host, int* seeds_host, fpc_stream s);

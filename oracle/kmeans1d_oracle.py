@@ -157,6 +157,20 @@ def _relocate(x, labels, centers_old, s, cnt):
         cnt[old] = cnt[old] - 1.0
 
 
+def _average(s, cnt):
+    """_average_centers: sum * (1 / count) in place, in index order; a cluster that is still empty (more clusters than distinct
+    values) is put "at the location of the biggest cluster" = entry argmax(count) of the array as it stands at that moment --
+    the averaged centre if that cluster has been passed, its raw sum if not"""
+    new = s.copy()
+    am = int(np.argmax(cnt))
+    for j in range(len(s)):
+        if cnt[j] > 0.0:
+            new[j] = new[j] * (1.0 / cnt[j])
+        else:
+            new[j] = new[am]
+    return new
+
+
 def _same_clustering(l1, l2, k):
     mapping = np.full(k, -1, dtype=np.int64)
     for a, b in zip(l1, l2):
@@ -183,7 +197,7 @@ def kmeans1d(x, k, first_ids, uniforms, tol, max_iter=300):
             labels = _assign(x, centers)
             s, cnt = _sums(x, labels, k)
             _relocate(x, labels, centers, s, cnt)
-            new = np.where(cnt > 0.0, s * (1.0 / np.where(cnt > 0.0, cnt, 1.0)), s)
+            new = _average(s, cnt)
             d = centers - new
             sh = np.sqrt(d * d)
             shift = _seq(sh * sh)

@@ -1526,6 +1526,14 @@ def test_scalar_codebook_kmeans_edges(torch_cuda):
     c = train_cb.train_scalar_codebook(dup, 6, n_init=2, details=d)
     oc, oin, oit, oseeds = KO.fit(dup, 6, n_init=2)
     assert np.array_equal(c, oc) and np.array_equal(d["seeds"], oseeds) and d["inertia"] == oin
+    # more clusters than distinct values: the surplus centres stay empty (every point sits on its centre: no relocation) and go
+    # "to the location of the biggest cluster" (sklearn's _average_centers); n = k; all values equal
+    for v, k in ((np.repeat([1.0, -2.0], 700), 3), (np.repeat([3.0, -1.0, 0.5], [50, 900, 20]), 5), (np.full(1000, 0.25), 4),
+                 (np.arange(5.0) ** 2, 5), (rs.randint(0, 6, size=5000).astype(np.float64), 6)):
+        d = {}
+        c = train_cb.train_scalar_codebook(v, k, n_init=2, details=d)
+        oc, oin, oit, oseeds = KO.fit(v, k, n_init=2)
+        assert np.array_equal(c, oc) and np.array_equal(d["seeds"], oseeds) and d["inertia"] == oin and d["n_iter"] == oit, (k, len(v))
     with pytest.raises(ValueError, match="should be >= n_clusters"):
         train_cb.train_scalar_codebook(np.arange(3.0), 4)
     L = _lib.lib()

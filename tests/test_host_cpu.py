@@ -542,13 +542,34 @@ def test_kmeans_oracle_relocates_an_empty_cluster_like_sklearn():
         labels = KO._assign(x, centers)
         s, cnt = KO._sums(x, labels, 4)
         KO._relocate(x, labels, centers, s, cnt)
-        new = np.where(cnt > 0.0, s * (1.0 / np.where(cnt > 0.0, cnt, 1.0)), s)
+        new = KO._average(s, cnt)
         shift = float(np.cumsum((centers - new) ** 2)[-1])
         centers = new
         if np.array_equal(labels, labels_old) or shift <= float(np.var(x) * 1e-4):
             break
         labels_old = labels
     assert it + 1 == sk_iter and np.abs(centers - sk_centers[:, 0]).max() < 1e-12
+
+
+@pytest.mark.parametrize("case", ["two values", "three values", "all equal", "n = k"])
+def test_kmeans_oracle_more_clusters_than_distinct_values_like_sklearn(case):
+    """clusters that stay empty (no relocation: every point sits on its centre): sklearn's _average_centers puts them "at the
+    location of the biggest cluster" while it averages in place -- the averaged centre if that cluster has a lower index, its raw
+    sum if not; restated in the oracle, compared with KMeans itself.  The cases are exact in binary (values, mean, sums): with
+    inexact sums sklearn's NEXT iteration relocates the surplus centres to whichever points its own rounding noise (1e-16) leaves
+    farthest from their centres -- positions no other summation order reproduces, and not worth reproducing (sklearn warns
+    "Number of distinct clusters found smaller than n_clusters")"""
+    import warnings
+    from sklearn.cluster import KMeans
+    sys.path.insert(0, ROOT)
+    from oracle import kmeans1d_oracle as KO
+    v, k = {"two values": (np.repeat([1.0, -2.0], 700), 3), "three values": (np.repeat([3.0, -1.0, 0.5], [128, 256, 128]), 5),
+            "all equal": (np.full(1000, 0.25), 4), "n = k": (np.arange(5.0) ** 2, 5)}[case]
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        km = KMeans(n_clusters=k, random_state=0, n_init=3).fit(v[:, None])
+    c, inertia, n_iter, _ = KO.fit(v, k, n_init=3)
+    assert np.abs(c - km.cluster_centers_).max() < 1e-12 and n_iter == km.n_iter_ and abs(inertia - km.inertia_) < 1e-12
 
 
 def test_scalar_codebook_gpu_backend_needs_the_gpu(built):
