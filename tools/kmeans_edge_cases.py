@@ -1,3 +1,4 @@
+"""k-means of the scalar codebooks: degenerate inputs on the device against the oracle (bit for bit) and scikit-learn (centres)."""
 import sys; sys.path.insert(0, '.')
 import numpy as np, warnings
 warnings.filterwarnings("ignore")
