@@ -30,7 +30,7 @@
 // before track A has read it), the waves of a track in two more -- no workgroup barrier inside the loop, so the round trip of
 // one recurrence hides behind the products of the other.  (One track, one hop and one barrier pair per step -- the first form
 // of this kernel -- took 17.6 kcycles per step, 4 k of them waiting for granules and 2.4 k at the barrier:
-// profiles/r05_train_timing.txt.)  Products in the row segments of oracle/fpc_oracle.c (matvec_t: 4 segments, each a
+// profiles/r05_ablations.txt item 10.)  Products in the row segments of oracle/fpc_oracle.c (matvec_t: 4 segments, each a
 // row-ordered fmaf chain from 0 = what the f32 MFMA accumulates, the segment sums added as a balanced tree by the gate threads).
 // Every value is formed by the operations and in the order of k_train_bwd and of orc_train_step (gru_bwd): losses, gradients
 // and parameters are bit-identical to both (tests).  The saved activations a gate thread needs are fetched a step ahead.
