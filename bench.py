@@ -198,6 +198,31 @@ def e2e_config5(voc, torch, synth, parallel, rank, world, L=300):
     voc.synthesize(feats, seeds, out=pcm)
     torch.cuda.synchronize()
     t2 = time.perf_counter()
+    # ---- the same share as a pipeline: the encoder of batch k + 1 on a side stream while the vocoder decodes batch k.  The
+    # decode holds half of every XCD for its 65 ms, so the encoder's groups cannot become resident: each decides for the
+    # row-split fallback (fpcodec.h "Kernel forms": a busy GPU costs speed, never a timeout) and still hides behind the decode.
+    pipe = None
+    try:
+        s_enc = torch.cuda.Stream()
+        keep, cur, fb, nb = [feats], feats, 0, 3
+        torch.cuda.synchronize()
+        tp0 = time.perf_counter()
+        for _ in range(nb):
+            voc.synthesize(cur, seeds, out=pcm)                      # asynchronous, on the current stream
+            with torch.cuda.stream(s_enc):
+                nxt = encode_features(model, cfg, nm_d)[0]
+                fb += model.fallback_groups()                        # (synchronises: the decode of this batch is through too)
+            torch.cuda.current_stream().wait_stream(s_enc)
+            keep.append(nxt)                                          # (allocated on the side stream: alive until the end)
+            cur = nxt
+        torch.cuda.synchronize()
+        pipe = {"batches": nb, "ms_per_batch": (time.perf_counter() - tp0) / nb * 1e3, "fallback_groups_per_batch": fb / nb,
+                "note": "decode of batch k and encode of batch k + 1 concurrently (two streams, one process); sequential: "
+                        "encode_ms + decode_ms"}
+        assert torch.equal(keep[-1], feats), "the pipelined encoder's features differ from the sequential run's"
+        del keep
+    except Exception as e:  # (a diagnostic leg: it must not take the line down)
+        pipe = {"error": repr(e)[:200]}
     # receiver side: the same utterances rebuilt from the symbols alone
     enc = model.encoder(cfg, nm_d[:, :, :20], None, cfg["l1"], cfg["l2"], qtz=True, return_indices=True)
     idx = enc[7]
@@ -271,7 +296,7 @@ def e2e_config5(voc, torch, synth, parallel, rank, world, L=300):
            "encode_ms": (t1 - t0) * 1e3, "decode_ms": (t2 - t1) * 1e3,
            "rtf_aggregate": rep["samples"] / rep["elapsed_s"] / 16000.0, "keep_rates": keep,
            "entropy_bits_per_symbol": ent, "bits_per_frame": bits_frame, "bitrate_bps": bits_frame * 100.0,
-           "decode_features_ms": (t4 - t3) * 1e3,
+           "decode_features_ms": (t4 - t3) * 1e3, "pipelined": pipe,
            "predictor_roofline": {
                "bound": "mfma", "unit": "TFLOP/s", "peak": PEAK_F32_TFLOPS, "kernel": "k_encode_wsd",
                "kernel_ms": enc_ms, "call_ms": enc_call_ms, "achieved": enc_flop / (enc_ms * 1e-3) / 1e12,
