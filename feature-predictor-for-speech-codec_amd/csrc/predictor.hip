@@ -1025,9 +1025,9 @@ __global__ __launch_bounds__(NT) void k_train_fwd_df(const PredDev P, const floa
 // dL/dpre of every frame and the utterance's share of the loss (float64, frames then outputs in order)
 __global__ __launch_bounds__(256) void k_train_loss(const float* __restrict__ feat, int in, int F, int Lf, float scale,
                                                     const TrainBufs T) {
-    extern __shared__ float sh[];  // diff[(Lf-1)*F]
+    // dpre = d loss / d (pre-activation of the output layer); the loss itself -- a strictly sequential float64 sum per utterance,
+    // 13 us on one thread -- is not needed by anything on the device: it rides beside the weight-gradient tiles (k_grad_tn)
     const int b = blockIdx.x, tid = threadIdx.x;
-    const int ne = (Lf - 1) * F;
     for (int e = tid; e < Lf * F; e += 256) {
         const int t = e / F, o = e - t * F;
         const size_t n = (size_t)b * Lf + t;
@@ -1036,18 +1036,36 @@ __global__ __launch_bounds__(256) void k_train_loss(const float* __restrict__ fe
             const float th = T.th[n * F + o];
             const float y = th + th;
             const float diff = y - feat[(n + 1) * in + o];
-            sh[e] = diff;
             const float g = diff * scale;
             dp = (g + g) * fmaf(-th, th, 1.0f);
         }
         T.dpre[n * F + o] = dp;
     }
-    __syncthreads();
-    if (tid == 0) {
-        double lb = 0.0;
-        for (int e = 0; e < ne; ++e) lb += (double)sh[e] * (double)sh[e];
-        T.lossb[b] = lb;
+}
+// the squared error of utterance b: sum over (frame, output) in order of (double) diff^2, one add after the other (orc_train_step);
+// one wave: 64 elements per round are fetched and squared side by side, the adds stay in sequence (every lane carries the sum)
+__device__ __forceinline__ void loss_sum(const float* __restrict__ feat, int in, int F, int Lf, const TrainBufs& T, int b) {
+    const int lane = threadIdx.x & 63, ne = (Lf - 1) * F;
+    double lb = 0.0;
+    for (int e0 = 0; e0 < ne; e0 += 64) {
+        const int e = e0 + lane;
+        double d2 = 0.0;
+        if (e < ne) {
+            const int t = e / F, o = e - t * F;
+            const size_t n = (size_t)b * Lf + t;
+            const float th = T.th[n * F + o];
+            const float y = th + th;
+            const float diff = y - feat[(n + 1) * in + o];
+            d2 = (double)diff * (double)diff;
+        }
+        const int cnt = ne - e0 < 64 ? ne - e0 : 64;
+#pragma unroll
+        for (int j = 0; j < 64; ++j) {
+            const double v = __shfl(d2, j);
+            if (j < cnt) lb += v;
+        }
     }
+    if (lane == 0) T.lossb[b] = lb;
 }
 
 struct BwdLds {
@@ -1223,18 +1241,24 @@ __device__ __forceinline__ void colsum(const GradJobs& J, int N, int job, int r)
 // of a segment, of every job, run on ONE XCD, where the rows of A and D they share are fetched into the L2 once.  (As a 3-D
 // grid, tiles sharing D sat on different XCDs: TCC_MISS 8.7 M of 9.0 M requests, 1.1 GB per launch from beyond the L2 for
 // 240 MB of operands.)  Slots = the (job, column block, row block) tiles of one segment, the largest job first; behind them
-// `ncol` workgroups of bias sums (strictly sequential adds, latency-bound on a few waves: beside the tiles they cost nothing).
+// `ncol` workgroups of bias sums and B / 4 of loss sums (strictly sequential adds, latency-bound on a few waves: beside the tiles
+// they cost nothing).
 struct GradMap {
     unsigned char job[128], bx[128], by[128];
     unsigned char cjob[32], cbx[32];
     int nslots, ncol;
 };
 static_assert(GSEG == 8, "k_grad_tn: one sample segment per XCD");
-__global__ __launch_bounds__(256) void k_grad_tn(const GradJobs J, int N, int seglen, const GradMap M) {
+__global__ __launch_bounds__(256) void k_grad_tn(const GradJobs J, int N, int seglen, const GradMap M, int Lf, const TrainBufs T) {
     const int lin = blockIdx.x;
     if (lin >= GSEG * M.nslots) {
         const int c = lin - GSEG * M.nslots;
-        colsum(J, N, M.cjob[c], M.cbx[c] * 256 + threadIdx.x);
+        if (c < M.ncol) {
+            colsum(J, N, M.cjob[c], M.cbx[c] * 256 + threadIdx.x);
+        } else {  // the utterances' losses, four per workgroup (one wave each): J.A[0] = the features, K[0] = their width, R[4] = fc
+            const int b = 4 * (c - M.ncol) + (threadIdx.x >> 6);
+            if (b < N / Lf) loss_sum(J.A[0], J.K[0], J.R[4], Lf, T, b);
+        }
         return;
     }
     const int sg = lin % GSEG, slot = lin / GSEG;
@@ -2031,7 +2055,7 @@ extern "C" int fpc_trainer_step(fpc_trainer* t, const float* feat_dev, int B, in
         hipLaunchKernelGGL(k_train_fwd_df, dim3(B * sp.n), dim3(NT), 0, st, P, feat_dev, L, T, sp);
     }
     const double cnt = (double)B * (L - 1) * F;
-    hipLaunchKernelGGL(k_train_loss, dim3(B), dim3(256), sizeof(float) * (size_t)L * F, st, feat_dev, in, F, L,
+    hipLaunchKernelGGL(k_train_loss, dim3(B), dim3(256), 0, st, feat_dev, in, F, L,
                        (float)(2.0 / cnt), T);
     const BwdW bw{t->wt[0].as<float>(), t->wt[1].as<float>(), t->wt[2].as<float>()};
     if (ws_wanted(p) && !getenv("FPC_TRAIN_BWD_ROWSPLIT")) {
@@ -2107,7 +2131,7 @@ extern "C" int fpc_trainer_step(fpc_trainer* t, const float* feat_dev, int B, in
                 M.cjob[M.ncol] = (unsigned char)j, M.cbx[M.ncol] = (unsigned char)x, ++M.ncol;
             }
     }
-    hipLaunchKernelGGL(k_grad_tn, dim3(GSEG * M.nslots + M.ncol), dim3(256), 0, st, J, N, seglen, M);
+    hipLaunchKernelGGL(k_grad_tn, dim3(GSEG * M.nslots + M.ncol + (B + 3) / 4), dim3(256), 0, st, J, N, seglen, M, L, T);
     hipLaunchKernelGGL(k_grad_reduce, dim3((unsigned)(((size_t)maxK * maxR + 255) / 256), 5), dim3(256), 0, st, J, p->status_dev,
                        t->latch.as<unsigned>());
     t->step += 1;
