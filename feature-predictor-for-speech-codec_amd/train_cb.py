@@ -76,12 +76,16 @@ def kmeans_draws(n, k, n_init, seed=0):
     trials = 2 + int(np.log(k))
     w = np.ones(n)
     p = w / w.sum()
+    # RandomState.choice(n, p=p) = searchsorted(normalised cumsum of p, one random_sample(), side="right"): the O(n) part is the
+    # same for every run, so it is formed once (tests: equal to calling choice itself)
+    cdf = p.cumsum()
+    cdf /= cdf[-1]
     first = np.empty(n_init, dtype=np.int64)
     u = np.empty((n_init, max(k - 1, 0), trials), dtype=np.float64)
     for r in range(n_init):
-        first[r] = rs.choice(n, p=p)
-        for c in range(k - 1):
-            u[r, c] = rs.uniform(size=trials)
+        first[r] = min(int(cdf.searchsorted(rs.random_sample(), side="right")), n - 1)
+        if k > 1:
+            u[r] = rs.uniform(size=(k - 1) * trials).reshape(k - 1, trials)  # (= k - 1 draws of `trials` each: one stream)
     return first, u, trials
 
 
