@@ -18,8 +18,8 @@
 // (choice for the first seed, uniform(size = trials) per further seed) and hands them over, so a run picks the seeds sklearn
 // picks.  What differs from sklearn is the ASSOCIATION of the long float64 sums (potentials, cluster sums, inertia): sklearn's
 // are BLAS / OpenMP reductions whose order is not specified (and not reproducible across thread counts); here every sum has
-// one fixed shape -- 8 consecutive points per thread in index order, a halving tree over the block's 256 threads, the block
-// sums one after the other -- restated in oracle/oracle.py (orc_kmeans1d), to which this file is bit-identical; the oracle is
+// one fixed shape -- per block of 2 048 points thread t adds the points t, t + 256, .. in index order, then a halving tree over
+// the 256 threads, the block sums one after the other; cluster sums: per block the members in index order, then the blocks in order -- restated in oracle/oracle.py (orc_kmeans1d), to which this file is bit-identical; the oracle is
 // pinned to sklearn itself (same seeds, centres to 1e-9) in the CPU suite.
 #include "fpc_common.h"
 
@@ -66,11 +66,11 @@ __global__ __launch_bounds__(KT) void k_kpp_apply(const double* __restrict__ x, 
     __shared__ double sh[KT];
     const int s = *seed;
     const double c = x[s], cc = xx[s];
-    const long long i0 = (long long)blockIdx.x * CH + (long long)threadIdx.x * PPT;
+    const long long i0 = (long long)blockIdx.x * CH + threadIdx.x;  // thread t: points t, t + 256, .. of the block (coalesced)
     double acc = 0.0;
 #pragma unroll
     for (int j = 0; j < PPT; ++j) {
-        const long long i = i0 + j;
+        const long long i = i0 + (long long)j * KT;
         if (i < n) {
             double d = seed_dist(c, cc, x[i], xx[i]);
             if (!first) {
@@ -98,21 +98,34 @@ __global__ __launch_bounds__(KT) void k_kpp_pick(const double* __restrict__ part
                                                  double* __restrict__ pot, int* __restrict__ cand) {
     __shared__ double total;
     __shared__ double S[KT], Q[KT];
-    __shared__ int hit[KT];
+    __shared__ int hit[KT], slo[MAXT];
+    __shared__ double chunk[512];
     const int t = threadIdx.x;
-    if (t == 0) {
+    {  // the prefix, 512 block sums at a time through LDS (thread 0 adds them one after the other)
         double acc = 0.0;
-        for (int b = 0; b < nblk; ++b) {
-            acc = acc + part[b];
-            prefix[b] = acc;
+        for (int b0 = 0; b0 < nblk; b0 += 512) {
+            const int m = nblk - b0 < 512 ? nblk - b0 : 512;
+            for (int b = t; b < m; b += KT) chunk[b] = part[b0 + b];
+            __syncthreads();
+            if (t == 0) {
+                for (int b = 0; b < m; ++b) {
+                    acc = acc + chunk[b];
+                    chunk[b] = acc;
+                }
+            }
+            __syncthreads();
+            for (int b = t; b < m; b += KT) prefix[b0 + b] = chunk[b];
+            __syncthreads();
         }
-        total = acc;
-        *pot = acc;
+        if (t == 0) {
+            total = acc;
+            *pot = acc;
+        }
     }
     __syncthreads();
-    for (int tr = 0; tr < trials; ++tr) {
-        const double rv = u[tr] * total;
-        int lo = 0, hi = nblk;  // first b with prefix[b] >= rv (every thread: the same search)
+    if (t < trials) {  // first b with prefix[b] >= rv, every trial's search side by side
+        const double rv = u[t] * total;
+        int lo = 0, hi = nblk;
         while (lo < hi) {
             const int mid = (lo + hi) >> 1;
             if (prefix[mid] >= rv)
@@ -120,6 +133,12 @@ __global__ __launch_bounds__(KT) void k_kpp_pick(const double* __restrict__ part
             else
                 lo = mid + 1;
         }
+        slo[t] = lo;
+    }
+    __syncthreads();
+    for (int tr = 0; tr < trials; ++tr) {
+        const double rv = u[tr] * total;
+        const int lo = slo[tr];
         if (lo >= nblk) {  // (block-uniform)
             if (t == 0) cand[tr] = (int)(n - 1);
             continue;
@@ -179,11 +198,11 @@ __global__ __launch_bounds__(KT) void k_kpp_eval(const double* __restrict__ x, c
         scc[threadIdx.x] = xx[cand[threadIdx.x]];
     }
     __syncthreads();
-    const long long i0 = (long long)blockIdx.x * CH + (long long)threadIdx.x * PPT;
+    const long long i0 = (long long)blockIdx.x * CH + threadIdx.x;
     double px[PPT], pxx[PPT], pc[PPT];
 #pragma unroll
     for (int j = 0; j < PPT; ++j) {
-        const long long i = i0 + j;
+        const long long i = i0 + (long long)j * KT;
         const bool in = i < n;
         px[j] = in ? x[i] : 0.0;
         pxx[j] = in ? xx[i] : 0.0;
@@ -194,7 +213,7 @@ __global__ __launch_bounds__(KT) void k_kpp_eval(const double* __restrict__ x, c
         double acc = 0.0;
 #pragma unroll
         for (int j = 0; j < PPT; ++j)
-            if (i0 + j < n) {
+            if (i0 + (long long)j * KT < n) {
                 const double d = seed_dist(c, cc, px[j], pxx[j]);
                 acc = acc + (pc[j] < d ? pc[j] : d);
             }
@@ -204,15 +223,26 @@ __global__ __launch_bounds__(KT) void k_kpp_eval(const double* __restrict__ x, c
 }
 
 // the best candidate (np.argmin of the potentials: block sums added one after the other) becomes seed number `c`
-__global__ __launch_bounds__(64) void k_kpp_best(const double* __restrict__ partT, int nblk, int trials, const int* __restrict__ cand,
+// (the block sums come into LDS 512 at a time, all trials side by side; thread t adds trial t's in order)
+constexpr int BCH = 512;
+__global__ __launch_bounds__(KT) void k_kpp_best(const double* __restrict__ partT, int nblk, int trials, const int* __restrict__ cand,
                                                  const double* __restrict__ x, int c, int* __restrict__ seeds, double* __restrict__ centers) {
+    __shared__ double buf[MAXT][BCH];
     __shared__ double pots[MAXT];
     const int t = threadIdx.x;
-    if (t < trials) {
-        double acc = 0.0;
-        for (int b = 0; b < nblk; ++b) acc = acc + partT[(size_t)t * nblk + b];
-        pots[t] = acc;
+    double acc = 0.0;
+    for (int b0 = 0; b0 < nblk; b0 += BCH) {
+        const int m = nblk - b0 < BCH ? nblk - b0 : BCH;
+        for (int q = t; q < trials * BCH; q += KT) {
+            const int tr = q / BCH, b = q - tr * BCH;
+            if (b < m) buf[tr][b] = partT[(size_t)tr * nblk + b0 + b];
+        }
+        __syncthreads();
+        if (t < trials)
+            for (int b = 0; b < m; ++b) acc = acc + buf[t][b];
+        __syncthreads();
     }
+    if (t < trials) pots[t] = acc;
     __syncthreads();
     if (t == 0) {
         int best = 0;
@@ -255,24 +285,43 @@ __global__ __launch_bounds__(KT) void k_km_assign(const double* __restrict__ x, 
     if (old_labels[i] != bj) *flag = 1;
 }
 
-// M-step, block j: sum and count of the points labelled j -- thread t takes the points t, t + 256, .. in index order, then the
-// halving tree
-__global__ __launch_bounds__(KT) void k_km_sums(const double* __restrict__ x, const int* __restrict__ labels, long long n,
-                                                double* __restrict__ sum, double* __restrict__ cnt) {
-    __shared__ double sh[KT];
-    const int j = blockIdx.x;
-    double s = 0.0, c = 0.0;
-    for (long long i = threadIdx.x; i < n; i += KT)
-        if (labels[i] == j) {
-            s = s + x[i];
-            c = c + 1.0;
-        }
-    const double ts = block_tree(s, sh);
-    const double tc = block_tree(c, sh);
-    if (threadIdx.x == 0) {
-        sum[j] = ts;
-        cnt[j] = tc;
+// M-step in two levels, every add in index order: (1) per chunk of 2 048 points and cluster, the members' values one after the
+// other (thread j walks the chunk's labels in LDS -- every lane reads the same element: a broadcast -- for the clusters j, j + 256,
+// ..); (2) per cluster, the chunks' partial sums one after the other.  (One workgroup per cluster scanning ALL labels -- the first
+// form -- read n k labels from the L2 per iteration: 1.85 ms at n = 2 M, k = 256.)
+__global__ __launch_bounds__(KT) void k_km_psums(const double* __restrict__ x, const int* __restrict__ labels, long long n, int k,
+                                                 double* __restrict__ psum, double* __restrict__ pcnt) {
+    __shared__ double xv[CH];
+    __shared__ int lab[CH];
+    const long long i0 = (long long)blockIdx.x * CH;
+    const int m = (int)(n - i0 < CH ? n - i0 : CH);
+    for (int i = threadIdx.x; i < m; i += KT) {
+        xv[i] = x[i0 + i];
+        lab[i] = labels[i0 + i];
     }
+    __syncthreads();
+    for (int j = threadIdx.x; j < k; j += KT) {
+        double s = 0.0, c = 0.0;
+        for (int i = 0; i < m; ++i)
+            if (lab[i] == j) {
+                s = s + xv[i];
+                c = c + 1.0;
+            }
+        psum[(size_t)blockIdx.x * k + j] = s;
+        pcnt[(size_t)blockIdx.x * k + j] = c;
+    }
+}
+__global__ __launch_bounds__(KT) void k_km_sums(const double* __restrict__ psum, const double* __restrict__ pcnt, int nblk, int k,
+                                                double* __restrict__ sum, double* __restrict__ cnt) {
+    const int j = blockIdx.x * KT + threadIdx.x;
+    if (j >= k) return;
+    double s = 0.0, c = 0.0;
+    for (int b = 0; b < nblk; ++b) {
+        s = s + psum[(size_t)b * k + j];
+        c = c + pcnt[(size_t)b * k + j];
+    }
+    sum[j] = s;
+    cnt[j] = c;
 }
 
 // _relocate_empty_clusters_dense: the m empty clusters, in index order, take the m points farthest from their centres, farthest
@@ -381,11 +430,11 @@ __global__ __launch_bounds__(KT) void k_km_average(const double* __restrict__ su
 __global__ __launch_bounds__(KT) void k_km_inertia(const double* __restrict__ x, const int* __restrict__ labels, long long n,
                                                    const double* __restrict__ centers, double* __restrict__ part) {
     __shared__ double sh[KT];
-    const long long i0 = (long long)blockIdx.x * CH + (long long)threadIdx.x * PPT;
+    const long long i0 = (long long)blockIdx.x * CH + threadIdx.x;
     double acc = 0.0;
 #pragma unroll
     for (int j = 0; j < PPT; ++j) {
-        const long long i = i0 + j;
+        const long long i = i0 + (long long)j * KT;
         if (i < n) {
             const double d = x[i] - centers[labels[i]];
             acc = acc + d * d;
@@ -433,7 +482,7 @@ extern "C" int fpc_kmeans1d(const double* x_dev, long long n, int k, int n_init,
     const int nblk = (int)((n + CH - 1) / CH), nthr = (int)((n + KT - 1) / KT);
     const size_t nu = (size_t)n_init * (size_t)(k > 1 ? k - 1 : 0) * trials;
     DevBuf xx, closest, part, partT, prefix, u, cand, seeds, centers[2], best_centers, labels[2], best_labels, sum, cnt, shift2,
-        scal, flags, map, taken;
+        scal, flags, map, taken, psum, pcnt;
     FPC_HIP(xx.alloc(sizeof(double) * n));
     FPC_HIP(closest.alloc(sizeof(double) * n));
     FPC_HIP(part.alloc(sizeof(double) * nblk));
@@ -448,6 +497,8 @@ extern "C" int fpc_kmeans1d(const double* x_dev, long long n, int k, int n_init,
     }
     FPC_HIP(best_centers.alloc(sizeof(double) * k));
     FPC_HIP(best_labels.alloc(sizeof(int) * n));
+    FPC_HIP(psum.alloc(sizeof(double) * (size_t)nblk * k));
+    FPC_HIP(pcnt.alloc(sizeof(double) * (size_t)nblk * k));
     FPC_HIP(sum.alloc(sizeof(double) * k));
     FPC_HIP(cnt.alloc(sizeof(double) * k));
     FPC_HIP(shift2.alloc(sizeof(double) * k));
@@ -471,7 +522,7 @@ extern "C" int fpc_kmeans1d(const double* x_dev, long long n, int k, int n_init,
                                prefix.as<double>(), scal.as<double>() + 1, cand.as<int>());
             hipLaunchKernelGGL(k_kpp_eval, dim3(nblk), dim3(KT), 0, st, x_dev, xx.as<double>(), n, closest.as<double>(), cand.as<int>(),
                                trials, nblk, partT.as<double>());
-            hipLaunchKernelGGL(k_kpp_best, dim3(1), dim3(64), 0, st, partT.as<double>(), nblk, trials, cand.as<int>(), x_dev, c,
+            hipLaunchKernelGGL(k_kpp_best, dim3(1), dim3(KT), 0, st, partT.as<double>(), nblk, trials, cand.as<int>(), x_dev, c,
                                seeds.as<int>(), centers[0].as<double>());
             hipLaunchKernelGGL(k_kpp_apply, dim3(nblk), dim3(KT), 0, st, x_dev, xx.as<double>(), n, seeds.as<int>() + c, 0,
                                closest.as<double>(), part.as<double>());
@@ -486,7 +537,10 @@ extern "C" int fpc_kmeans1d(const double* x_dev, long long n, int k, int n_init,
             FPC_HIP(hipMemsetAsync(flags.p, 0, sizeof(int) * 4, st));
             hipLaunchKernelGGL(k_km_assign, dim3(nthr), dim3(KT), 0, st, x_dev, n, centers[cur].as<double>(), k, labels[lab ^ 1].as<int>(),
                                labels[lab].as<int>(), flags.as<int>());
-            hipLaunchKernelGGL(k_km_sums, dim3(k), dim3(KT), 0, st, x_dev, labels[lab].as<int>(), n, sum.as<double>(), cnt.as<double>());
+            hipLaunchKernelGGL(k_km_psums, dim3(nblk), dim3(KT), 0, st, x_dev, labels[lab].as<int>(), n, k, psum.as<double>(),
+                               pcnt.as<double>());
+            hipLaunchKernelGGL(k_km_sums, dim3((k + KT - 1) / KT), dim3(KT), 0, st, psum.as<double>(), pcnt.as<double>(), nblk, k,
+                               sum.as<double>(), cnt.as<double>());
             hipLaunchKernelGGL(k_km_relocate, dim3(1), dim3(1024), 0, st, x_dev, labels[lab].as<int>(), n, centers[cur].as<double>(), k,
                                sum.as<double>(), cnt.as<double>(), taken.as<int>());
             hipLaunchKernelGGL(k_km_average, dim3(1), dim3(KT), 0, st, sum.as<double>(), cnt.as<double>(), centers[cur].as<double>(), k,

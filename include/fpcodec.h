@@ -341,8 +341,8 @@ FPC_API int fpc_cb_mean0(const void* data_dev, int data_f64, int nv, int nd, dou
  *   tol: sklearn's absolute tolerance (1e-4 * mean(var(v, axis = 0))); max_iter: 300 in sklearn;
  *   centers_host[k]; inertia_host, n_iter_host, seeds_host[n_init][k] (the seeds' indices) may be NULL.
  * Synchronous (the iteration count is data dependent: the stream is synchronised once per Lloyd iteration).
- * k <= 2048, trials <= 16, n < 2^28.  Every float64 sum has one fixed association (8 points per thread in index order, a
- * halving tree over 256 threads, block sums one after the other): results are reproducible run to run, which sklearn's OpenMP
+ * k <= 2048, trials <= 16, n < 2^28.  Every float64 sum has one fixed association (per block of 2 048 points: thread t adds the
+ * points t, t + 256, .., a halving tree over 256 threads; block sums one after the other): results are reproducible run to run, which sklearn's OpenMP
  * reductions are not; against sklearn itself the centres agree to rounding (tests: 1e-9).  With fewer distinct values than
  * clusters the surplus centres are duplicates of existing ones (sklearn's "location of the biggest cluster" rule is followed);
  * where sklearn's own rounding noise then decides a relocation, the duplicate may sit on a different existing centre. */

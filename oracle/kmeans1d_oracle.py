@@ -7,7 +7,8 @@ _kmeans_single_lloyd; _k_means_lloyd.pyx: _update_chunk_dense; _k_means_common.p
 _average_centers, _center_shift, _inertia_dense; metrics/pairwise.py: _euclidean_distances) is followed operation by operation
 where an operation decides an outcome (seed distances, the E-step's argmin, centre = sum * (1 / count), the stopping rules).
 The long float64 sums have no specified order in sklearn (BLAS / OpenMP reductions); here they have the ONE fixed shape
-csrc/kmeans1d.hip uses -- 8 consecutive points per thread, a halving tree over 256 threads, block sums one after the other --
+csrc/kmeans1d.hip uses -- per block of 2048 points thread t adds points t, t + 256, .., a halving tree over 256 threads, block sums
+one after the other; cluster sums per block in index order, then the blocks in order --
 so the HIP kernels are compared with this file bit for bit, and this file is pinned to sklearn itself in the CPU suite
 (tests/test_host_cpu.py: the same seeds index for index, centres to 1e-9)."""
 import numpy as np
@@ -33,15 +34,15 @@ def draws(n, k, n_init, seed=0):
 
 
 def _block_sums(v):
-    """per block of 2048 points: thread t adds its 8 consecutive points in index order, then the halving tree over 256 threads"""
+    """per block of 2048 points: thread t adds the points t, t + 256, .. in index order, then the halving tree over 256 threads"""
     n = len(v)
     nblk = (n + CH - 1) // CH
     a = np.zeros(nblk * CH)
     a[:n] = v
-    a = a.reshape(nblk, KT, PPT)
+    a = a.reshape(nblk, PPT, KT)
     acc = np.zeros((nblk, KT))
     for j in range(PPT):
-        acc = acc + a[:, :, j]
+        acc = acc + a[:, j, :]
     h = KT // 2
     while h >= 1:
         acc[:, :h] = acc[:, :h] + acc[:, h:2 * h]
@@ -117,26 +118,17 @@ def _assign(x, centers):
 
 
 def _sums(x, labels, k):
+    """cluster sums and counts: per block of 2048 points the members' values one after the other in index order, then the blocks'
+    partial sums one after the other"""
     n = len(x)
-    rows = (n + KT - 1) // KT
-    xp = np.zeros(rows * KT)
-    xp[:n] = x
-    lp = np.full(rows * KT, -1, dtype=np.int64)
-    lp[:n] = labels
-    xp, lp = xp.reshape(rows, KT), lp.reshape(rows, KT)
-    acc = np.zeros((k, KT))
-    cnt = np.zeros((k, KT))
-    js = np.arange(k)[:, None]
-    for r in range(rows):
-        m = lp[r][None, :] == js
-        acc = acc + np.where(m, xp[r][None, :], 0.0)
-        cnt = cnt + m
-    h = KT // 2
-    while h >= 1:
-        acc[:, :h] = acc[:, :h] + acc[:, h:2 * h]
-        cnt[:, :h] = cnt[:, :h] + cnt[:, h:2 * h]
-        h //= 2
-    return acc[:, 0].copy(), cnt[:, 0].copy()
+    tot, cnt = np.zeros(k), np.zeros(k)
+    for i0 in range(0, n, CH):
+        ps, pc = np.zeros(k), np.zeros(k)
+        np.add.at(ps, labels[i0:i0 + CH], x[i0:i0 + CH])  # unbuffered, in order: ps[l] = ps[l] + x
+        np.add.at(pc, labels[i0:i0 + CH], 1.0)
+        tot = tot + ps
+        cnt = cnt + pc
+    return tot, cnt
 
 
 def _relocate(x, labels, centers_old, s, cnt):
