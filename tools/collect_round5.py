@@ -48,5 +48,6 @@ open(os.path.join(P, "r05_train_timing.txt"), "w").write(
 km = os.path.join(o, "kmeans.txt")
 if os.path.exists(km):
     old = open(os.path.join(P, "r05_kmeans.txt")).read().split("\n\n")
-    open(os.path.join(P, "r05_kmeans.txt"), "w").write(old[0] + f"\n(tree {head})\n\n" + open(km).read() + "\n" + "\n\n".join(old[2:]))
+    hdr = "\n".join(l for l in old[0].splitlines() if not l.startswith("(tree "))
+    open(os.path.join(P, "r05_kmeans.txt"), "w").write(hdr + f"\n(tree {head})\n\n" + open(km).read() + "\n" + "\n\n".join(old[2:]))
 print("collected into profiles/r05_*")
