@@ -718,7 +718,7 @@ struct SplitArgs {
     const unsigned* only;     // the weights-stationary launch's fallback (predictor_ws.h, ws_hello): run only the utterances
                               // whose group of 16 decided WS_FALLBACK there ([groups] decision words), nullptr: all
 };
-constexpr unsigned WS_GO = 1u, WS_FALLBACK = 2u;
+constexpr unsigned WS_GO = 1u, WS_FALLBACK = 2u, WS_DEAD = 3u;  // (WS_DEAD: a workgroup of the group gave up -- k_forward_ws for k_out_layer)
 // (workgroup-uniform) is utterance b left to this launch?
 __device__ __forceinline__ bool split_wanted(const SplitArgs& S, int b) {
     return S.only == nullptr || __hip_atomic_load((gu32*)(S.only + b / 16), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == WS_FALLBACK;
@@ -1326,6 +1326,76 @@ __global__ __launch_bounds__(256) void k_grad_tn(const GradJobs J, int N, int se
             }
 }
 
+// The teacher-forced forward's output layer over ALL frames at once: y[n] = 2 tanh(fc(relu(h2[n]))) for the samples n = b L + t
+// of the groups the weights-stationary launch served.  Inside k_forward_ws the layer cost the workgroup that owns an utterance
+// 40 MFMAs per frame for ONE useful column of a 16-column tile, on the background waves that also gather hop 1: those
+// workgroups were the frame's pole (forward 1.33 -> 1.25 ms without it).  Here the tile's M dimension is 16 SAMPLES: the same
+// products in the same order -- per output row 8 input segments of 16, each a k-ordered fmaf chain (segment 0 from the bias)
+// = what the f32 MFMA accumulates, the segment sums as a balanced tree, rows 16 and 17 on a second tile -- for 1/16 of the
+// matrix work.  relu(h2) comes from the history k_forward_ws writes; one wave = 16 samples through an LDS tile.
+__global__ __launch_bounds__(256) void k_out_layer(const PredDev P, const float* __restrict__ relu, int N, int Lf,
+                                                   const unsigned* __restrict__ dec, float* __restrict__ y) {
+    constexpr int PT = WH2 + 4;  // row pitch of the sample tile (16-byte rows, two-way conflicts at most)
+    __shared__ __attribute__((aligned(16))) float tile[4][16 * PT];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, c = lane & 15, q = lane >> 4;
+    float w0[8][4], w1[8][4];  // B operands: fc weights [k][output], outputs 0 .. 15 and 16, 17 (zero beyond)
+#pragma unroll
+    for (int sg = 0; sg < 8; ++sg)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int k = 16 * sg + 4 * j + q;
+            w0[sg][j] = P.fcw[(size_t)k * WFC + c];
+            w1[sg][j] = 16 + c < WFC ? P.fcw[(size_t)k * WFC + 16 + c] : 0.0f;
+        }
+    const float b0 = P.fcb[c], b1 = 16 + c < WFC ? P.fcb[16 + c] : 0.0f;
+    float* tl = tile[wave];
+    for (int n0 = (blockIdx.x * 4 + wave) * 16; n0 < N; n0 += gridDim.x * 64) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {  // 16 rows x 128 floats = 512 float4: 8 per lane
+            const int e = lane + 64 * i, row = e >> 5, c4 = e & 31;
+            f32x4ws v = {0.f, 0.f, 0.f, 0.f};
+            if (n0 + row < N) v = *reinterpret_cast<const f32x4ws*>(relu + (size_t)(n0 + row) * WH2 + 4 * c4);
+            *reinterpret_cast<f32x4ws*>(tl + row * PT + 4 * c4) = v;
+        }
+        // (one wave writes and reads its own tile: one in-order LDS queue per wave)
+        f32x4ws a0[8], a1[8];
+#pragma unroll
+        for (int sg = 0; sg < 8; ++sg) {
+            const float i0 = sg == 0 ? b0 : 0.0f, i1 = sg == 0 ? b1 : 0.0f;
+            a0[sg] = f32x4ws{i0, i0, i0, i0};
+            a1[sg] = f32x4ws{i1, i1, i1, i1};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float h = tl[c * PT + 16 * sg + 4 * j + q];  // A[sample c][k]
+                a0[sg] = ws_mfma(h, w0[sg][j], a0[sg]);
+                a1[sg] = ws_mfma(h, w1[sg][j], a1[sg]);
+            }
+        }
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {  // C/D layout: column = lane & 15 (output), rows 4 q + v (samples)
+            const int n = n0 + 4 * q + v;
+            if (n >= N) continue;
+            const int b = n / Lf;
+            const unsigned gd = __hip_atomic_load((gu32*)(dec + b / 16), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (gd == WS_DEAD) {  // a workgroup of the group gave up: the group's outputs fail loudly (fpcodec.h), whole
+                const float qnan = __uint_as_float(0x7fc00000u);
+                y[(size_t)n * WFC + c] = qnan;
+                if (16 + c < WFC) y[(size_t)n * WFC + 16 + c] = qnan;
+                continue;
+            }
+            if (gd != WS_GO) continue;  // (WS_FALLBACK: the row-split launch has written this utterance's rows)
+            const float s0 = ((a0[0][v] + a0[1][v]) + (a0[2][v] + a0[3][v])) + ((a0[4][v] + a0[5][v]) + (a0[6][v] + a0[7][v]));
+            const float t0 = fpc_tanhf(s0);
+            y[(size_t)n * WFC + c] = t0 + t0;  // the "dual" FC is the same Linear summed twice (wavernn.py:89-92)
+            if (16 + c < WFC) {
+                const float s1 = ((a1[0][v] + a1[1][v]) + (a1[2][v] + a1[3][v])) + ((a1[4][v] + a1[5][v]) + (a1[6][v] + a1[7][v]));
+                const float t1 = fpc_tanhf(s1);
+                y[(size_t)n * WFC + 16 + c] = t1 + t1;
+            }
+        }
+    }
+}
+
 // dst[r][k] = src[k][r]: the torch-layout copies the backward pass reads, at the first step (k_adam keeps them current)
 __global__ void k_transpose(const float* __restrict__ src, int K, int R, float* __restrict__ dst) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1434,6 +1504,7 @@ struct fpc_predictor {
     fpc::DevBuf flag;  // one int: "a symbol lay outside its codebook" (fpc_decode_features), allocated once per handle
     fpc::DevBuf xg;    // row-split exchange granules [B][2][h1 + h2] x 8 bytes, grown on demand
     fpc::DevBuf wsg;   // weights-stationary form (predictor_ws.h): granule blocks [groups][WGRANULES] x 16 bytes
+    fpc::DevBuf h2hist; // ... relu(h2) of every sample of a forward call [B][L][128] (k_out_layer), grown on demand
     fpc::DevBuf wsidx; // ... and the symbols of an encode call whose caller passes no idx buffer (the histograms are counted from them)
     // status word: host-mapped pinned memory the kernels OR failure bits into (FPC_ST_*); sticky until
     // fpc_predictor_status() clears it; read by the host without a synchronisation at the start of every call
@@ -1713,10 +1784,24 @@ extern "C" int fpc_predictor_forward(fpc_predictor* p, const float* x_dev, int B
         WsArgs wa;
         const int rcw = ws_args(p, B, static_cast<hipStream_t>(s), &wa);
         if (rcw != FPC_OK) return rcw;
+        const size_t hbytes = sizeof(float) * (size_t)B * (size_t)(L > 0 ? L : 1) * WH2;  // relu(h2) of every sample, for k_out_layer
+        if (p->h2hist.bytes < hbytes) {
+            FPC_HIP(hipStreamSynchronize(static_cast<hipStream_t>(s)));  // (a launch in flight may still read the old block)
+            if (p->h2hist.p) (void)hipFree(p->h2hist.p);
+            p->h2hist.p = nullptr;
+            FPC_HIP(p->h2hist.alloc(hbytes));
+        }
+        WsSave hs{};
+        hs.relu = p->h2hist.as<float>();
         hipLaunchKernelGGL(k_forward_ws<false>, dim3(ws_grid(wa)), dim3(NT), 0, static_cast<hipStream_t>(s), p->d, x_dev, L, h1_dev,
-                           h2_dev, y_dev, wa, WsSave{});
+                           h2_dev, y_dev, wa, hs);
         hipLaunchKernelGGL(k_forward_df, dim3(B), dim3(NT), 0, static_cast<hipStream_t>(s), p->d, x_dev, L, h1_dev, h2_dev, y_dev,
                            ws_fallback_args(p, wa));
+        if (L > 0) {
+            const int N = B * L, groups16 = (N + 15) / 16;
+            hipLaunchKernelGGL(k_out_layer, dim3((unsigned)std::min(1024, (groups16 + 3) / 4)), dim3(256), 0, static_cast<hipStream_t>(s),
+                               p->d, p->h2hist.as<float>(), N, L, wa.dec, y_dev);
+        }
         FPC_HIP(hipGetLastError());
 #ifdef FPC_WS_PROF
         ws_prof_print(p, "k_forward_ws", B, static_cast<hipStream_t>(s));

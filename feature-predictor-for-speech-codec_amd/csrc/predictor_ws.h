@@ -843,6 +843,8 @@ __device__ __forceinline__ bool ws_foreground(const WsCtx& X, WsLds& L, const Ws
             ws_store(X, WOFF_H2 + (t & 1) * WNS * WQ2 + X.slice * WQ2 + lane, epoch, L.h2[base + i0], L.h2[base + i1], L.h2[base + i2]);
         }
         df_signal(&L.sig[WSIG_P2]);
+        if (!SAVE && sv != nullptr && sv->relu != nullptr && (v & 15) < X.nu)  // the plain forward: what k_out_layer reads
+            sv->relu[((size_t)(X.b0 + (v & 15)) * X.Lf + t) * WH2 + WU2 * X.slice + (v >> 4)] = hn > 0.0f ? hn : 0.0f;
         if (SAVE && (v & 15) < X.nu) {  // (behind the publication, as GRU1's)
             const size_t o = ((size_t)(X.b0 + (v & 15)) * X.Lf + t) * WH2 + WU2 * X.slice + (v >> 4);
             sv->h2p[o] = hp;
@@ -928,7 +930,7 @@ __device__ __forceinline__ bool ws_background(const WsCtx& X, WsLds& L, const Ws
     }
     df_signal(&L.sig[WSIG_A]);
     WBSTAMP(16)
-    if (FC_LATE && X.own >= 0) {
+    if (FC_LATE && X.own >= 0 && y_late != nullptr) {
         if (!df_wait(&L.sig[WSIG_H2], 2 * (t + 1), &L.dead)) return false;  // h2(t) whole in LDS
         ws_F_late(L, R, L.pFl[t & 1], bw - 1, lane, X.own);
         df_signal(&L.sig[WSIG_FB]);
@@ -1047,8 +1049,9 @@ __global__ __launch_bounds__(NT) void k_forward_ws(const PredDev P, const float*
         __builtin_amdgcn_s_setprio(0);
     } else {
         for (int tb = 0; tb < Lf; ++tb)
-            if (!ws_background<true, true, TRAIN>(X, L, R, tb, tb + 1 == Lf, tid - WFGT,  // (the row of the owned utterance, if any)
-                                                  owner ? (TRAIN ? sv.th : y) + ((size_t)(X.b0 + slice) * Lf + tb) * WFC : nullptr))
+            if (!ws_background<true, true, TRAIN>(X, L, R, tb, tb + 1 == Lf, tid - WFGT,  // (training: tanh row of the owned utterance;
+                                                  //  the plain forward's output layer is k_out_layer, over all frames at once)
+                                                  (owner && TRAIN) ? sv.th + ((size_t)(X.b0 + slice) * Lf + tb) * WFC : nullptr))
                 break;
     }
     WPROF_DUMP(Lf)
@@ -1057,8 +1060,8 @@ __global__ __launch_bounds__(NT) void k_forward_ws(const PredDev P, const float*
     // new states of this workgroup's units; a launch that gave up fails loudly: NaN outputs and states, FPC_ERR_TIMEOUT
     const bool dead = ws_dead(L);
     const float qnan = __uint_as_float(0x7fc00000u);
-    if (dead && owner)
-        for (size_t k = tid; k < (size_t)Lf * WFC; k += NT) y[(size_t)(X.b0 + slice) * Lf * WFC + k] = qnan;
+    // (y: k_out_layer, behind this launch, writes the predictions of the groups that ran -- NaN for a group marked dead)
+    if (dead && tid == 0) __hip_atomic_store((gu32*)X.dec, WS_DEAD, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     for (int v = tid; v < WV1; v += NT) {
         const int c = v >> 4, u = v & 15;
         if (u < X.nu) h1[(size_t)(X.b0 + u) * WH1 + WU1 * slice + c] = dead ? qnan : L.h1[slice * WV1 + v];
