@@ -51,25 +51,24 @@ constexpr int WIN = 20, WH1 = 384, WH2 = 128, WFC = 18;
 constexpr int WU1 = WH1 / WNS, WU2 = WH2 / WNS;  // units per workgroup: 12, 4
 constexpr int WV1 = WU1 * WG, WV2 = WU2 * WG;    // state values per workgroup and hop: 192, 64
 constexpr int WQ1 = WV1 / 3, WQ2 = (WV2 + 2) / 3;  // 16-byte granules per workgroup and hop: 64, 22
-constexpr int WQX = WFC / 3;                     // granules of an utterance's next input row (hop 3): 6
 constexpr int WFG = 4, WBG = 4;                  // waves per role
 constexpr int W1G = WIN * WU1 + 20;                // pitch of a gate's block of W1i in LDS
 constexpr int WXP = 17;                          // pitch of a row of the input image (ws_xi)
 constexpr int WPF = 20;                          // pitch of an utterance's 18 output rows in pFa (16-byte stores, 8 lanes: 8 bank quads)
 constexpr int WFGT = WFG * 64;
-// granule block of a group, in 16-byte units: hello | h1 | h2 | next input (the receiver's third hop)
+// granule block of a group, in 16-byte units: hello | h1 | h2
 // (the state hops have TWO granule sets each, used by frame parity: a workgroup publishes h1(t+1) once its gather of h1(t) is
 //  complete, i.e. once every partner has published h1(t) -- which a partner does only with h1(t-1) whole in its LDS: the set
 //  of parity t+1 is free.  Likewise h2(t+1) follows the own gather of h2(t), the partners' h2(t) their gather of h2(t-1).
 //  With ONE set the publish of a frame had to wait for the previous frame's OTHER hop to prove that, which put hop 2 on the
 //  teacher-forced forward's loop although nothing on that loop needs h2: profiles/r05_ablations.txt)
-constexpr int WOFF_HELLO = 0, WOFF_H1 = WNS, WOFF_H2 = WOFF_H1 + 2 * WNS * WQ1, WOFF_X = WOFF_H2 + 2 * WNS * WQ2,
+constexpr int WOFF_HELLO = 0, WOFF_H1 = WNS, WOFF_H2 = WOFF_H1 + 2 * WNS * WQ1,
               // | the distributed searches' results [utterance][workgroup][5], first and second stage (predictor_wsd.h)
-              WOFF_G1 = WOFF_X + WG * WQX, WOFF_G2 = WOFF_G1 + WG * WNS * SURV,
-              WGRANULES = WOFF_G2 + WG * WNS * SURV;  // 10 752 granules = 172 032 bytes
+              WOFF_G1 = WOFF_H2 + 2 * WNS * WQ2, WOFF_G2 = WOFF_G1 + WG * WNS * SURV,
+              WGRANULES = WOFF_G2 + WG * WNS * SURV;  // 10 656 granules = 170 496 bytes
 static_assert(NT == 512, "predictor_ws.h is written for 8 waves per workgroup");
 static_assert(WH1 / 4 == 96 && WH2 / 2 == 64 && WFC == NDIM + 1, "production shape");
-enum { WSIG_A = 0, WSIG_B, WSIG_H1, WSIG_H2, WSIG_P1, WSIG_P2, WSIG_C, WSIG_I, WSIG_X, WSIG_FG, WSIG_FB, WNSIG };
+enum { WSIG_A = 0, WSIG_B, WSIG_H1, WSIG_H2, WSIG_P1, WSIG_P2, WSIG_C, WSIG_I, WSIG_X, WSIG_FB, WNSIG };
 
 struct WsArgs {
     int B, ngroups;
@@ -90,10 +89,8 @@ struct __attribute__((aligned(16))) WsLds : SearchLds {
     float pA[4][3][256];      // [segment][gate][...]
     float pC[4][256];         // [segment][ws_tile(gate * 4 + unit, utterance)]
     float pB[2][256];
-    float pF[8][2][16];       // [segment][tile][row in tile]: the owned utterance only
-    float pFl[2][8][2][16];   // the same for the forward's off-chain output layer, by frame parity
+    float pFl[2][8][2][16];   // the training forward's off-chain output layer: [frame parity][segment][tile][row in tile], owned utterance
     float fo[WG][WIN];        // predictions [utterance][row < 18]
-    float xn[MAX_IN];         // the owner's next input row
     float w1i[3 * W1G];        // [gate][k][unit], gates 260 floats apart (240: gates 0 and 2 in the same banks for ws_I_own's lanes)
     float w2i[WH1 * 3 * WU2];  // [k / 16][k % 4][gate * 4 + unit][(k % 16) / 4]
     float w2h[WH2 * 3 * WU2];
@@ -107,12 +104,14 @@ struct __attribute__((aligned(16))) WsLds : SearchLds {
     int same_xcd;
     int hello;       // the group's decision as this workgroup adopted it (ws_hello)
     // the distributed tail (predictor_wsd.h): every workgroup of a group serves every utterance of the group
-    double cbs[3][WNS][NDIM + 1];  // this workgroup's entries 32 m + slice of the books hi stage 1, hi stage 2, lo (18 doubles
+    // (16-byte aligned: the tail reads coordinate PAIRS; at an 8-byte offset -- one counter fewer in `sig` did that -- the encoder
+    //  lost 5 %)
+    __attribute__((aligned(16))) double cbs[3][WNS][NDIM + 1];  // this workgroup's entries 32 m + slice of the books hi stage 1, hi stage 2, lo (18 doubles
                                    // apart: 16-byte reads of coordinate pairs, conflict-free; 17 apart was measured slower --
                                    // 17 eight-byte reads per distance instead of 9 reads: profiles/r05_ablations.txt)
     float pFa[8][WG * WPF];        // output-layer segment sums of all 16 utterances [segment][utterance * 20 + row]
     float rsa[WG][WIN];            // residuals [utterance][row]
-    double xs[WG][NDIM + 1];       // first-stage targets
+    __attribute__((aligned(16))) double xs[WG][NDIM + 1];       // first-stage targets
     double xq2[WG][SURV][NDIM + 1];  // second-stage targets
     double dl[WG][WNS];            // a half-wave's 32 distances (local ranking, heads of the gathered lists)
     unsigned dh[WG][WNS];          // ... and their high words
@@ -203,12 +202,6 @@ template <class LT>
 __device__ __forceinline__ void ws_give_up(const WsCtx& X, LT& L) {
     status_or(X.err, FPC_ST_TIMEOUT);
     __hip_atomic_store(&L.dead, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-}
-// barrier of the foreground waves only
-__device__ __forceinline__ void ws_fg_sync(WsLds& L, int& fg_epoch) {
-    ++fg_epoch;
-    df_signal(&L.sig[WSIG_FG]);
-    (void)df_wait(&L.sig[WSIG_FG], WFG * fg_epoch, &L.dead);
 }
 __device__ __forceinline__ void ws_store(const WsCtx& X, int granule, unsigned epoch, float v0, float v1, float v2) {
     if (X.withhold) return;
@@ -594,38 +587,6 @@ __device__ __forceinline__ void ws_F_rows(WsLds& L, const WsRegs& R, float (&pF)
         for (int k = 0; k < 4; ++k) a = fmaf(h[i][k] > 0.0f ? h[i][k] : 0.0f, w[i][k], a);
     if (lane < 16) pF[rsg][1][row] = a;
 }
-// output layer on relu(h2) for the owned utterance: rows 0-15 as one MFMA tile (foreground wave fw = input segments 2 fw,
-// 2 fw + 1 of 16 inputs; the other 15 utterances of the M tile come for free and are dropped), rows 16, 17 as fmaf chains
-// on 16 lanes of wave 0 (a second tile would double the MFMAs for two rows -- measured: the forward's background waves come
-// late to the next hop, profiles/r05_ablations.txt)
-__device__ __forceinline__ void ws_F(WsLds& L, const WsRegs& R, int fw, int lane, int own) {
-    const int c = lane & 15, q = lane >> 4;
-    float hv[2][4], wv[2][4];  // (all operands first: two chains of four dependent MFMAs, not eight LDS round trips)
-#pragma unroll
-    for (int s2 = 0; s2 < 2; ++s2) {
-        const int sg = 2 * fw + s2;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const float h = L.h2[(16 * sg + 4 * j) * WG + lane];
-            hv[s2][j] = h > 0.0f ? h : 0.0f;  // (the rectified state, formed in the chain)
-            wv[s2][j] = L.fcw[(16 * sg + 4 * j + q) * 16 + c];
-        }
-    }
-#pragma unroll
-    for (int s2 = 0; s2 < 2; ++s2) {
-        const int sg = 2 * fw + s2;
-        const float b0 = sg == 0 ? R.bF[0] : 0.0f;
-        f32x4ws a0 = {b0, b0, b0, b0};
-#pragma unroll
-        for (int j = 0; j < 4; ++j) a0 = ws_mfma(hv[s2][j], wv[s2][j], a0);
-        if (q == (own >> 2)) {  // (C/D layout: this lane holds utterances 4 q .. 4 q + 3 of row c)
-            const int r = own & 3;
-            L.pF[sg][0][c] = r == 0 ? a0[0] : (r == 1 ? a0[1] : (r == 2 ? a0[2] : a0[3]));
-        }
-    }
-    if (fw == 0) ws_F_rows(L, R, L.pF, lane);
-}
-
 // The teacher-forced forward's output layer, off the chain: nothing of frame t + 1 depends on the prediction of frame t, so
 // background waves 1-3 evaluate it behind A(t + 1), when hop 2 of frame t is over -- h2(t) stays whole in LDS until the GRU2
 // gates of frame t + 1, which come behind hop 1 of that frame, i.e. behind these waves' own gather -- while the foreground
@@ -745,12 +706,13 @@ __device__ __forceinline__ bool ws_gather2(const WsCtx& X, WsLds& L, int p, unsi
 // barrier first), states in L.h1 / L.h2; false: the launch is dead
 // EARLY_I (the teacher-forced forward): I(t) has been computed one frame ahead by background wave 0 (k_forward_ws)
 __device__ __forceinline__ void wsd_F(WsLds& L, const WsRegs& R, int fw, int lane, int ft);  // predictor_wsd.h
+__device__ __forceinline__ void wsd_receive_tail(const WsCtx& X, WsLds& L, const PredDev& P, const CbDev& C, const int* __restrict__ idx,
+                                                 float* __restrict__ c_out, int* bad, int Lf, int frame, float pv, int tid);  // predictor_wsd.h
 // FC_ALL (the distributed encoder tail): the output layer's segment sums of all 16 utterances, no prediction formed here
 // FC_LATE (the teacher-forced forward): no output layer here -- the background evaluates it off the chain (ws_background)
 // SAVE (the training forward): the gates' activations of every sample go to *sv
 template <bool EARLY_I = false, bool FC_ALL = false, bool FC_LATE = false, bool SAVE = false>
-__device__ __forceinline__ bool ws_foreground(const WsCtx& X, WsLds& L, const WsRegs& R, int t, int ft0, int& fg_epoch,
-                                              const WsSave* sv = nullptr) {
+__device__ __forceinline__ bool ws_foreground(const WsCtx& X, WsLds& L, const WsRegs& R, int t, int ft0, const WsSave* sv = nullptr) {
     const int ft = ft0 + (FPC_WS_HOIST && EARLY_I ? 0 : ws_opaque_zero());
     const int fw = ft0 >> 6, lane = ft & 63;
     const unsigned epoch = (unsigned)t + 1u;
@@ -868,20 +830,7 @@ __device__ __forceinline__ bool ws_foreground(const WsCtx& X, WsLds& L, const Ws
     if (FC_LATE) return true;  // (a launch that died shows at the next frame's first wait)
     if (!df_wait(&L.sig[WSIG_H2], 2 * (t + 1), &L.dead)) return false;
     WSTAMP(9)
-    if (FC_ALL) {
-        wsd_F(L, R, fw, lane, ft);
-    } else if (X.own >= 0) {  // the output layer: only the workgroup that owns an utterance needs its prediction
-        ws_F(L, R, fw, lane, X.own);
-        ws_fg_sync(L, fg_epoch);
-        WSTAMP(10)
-        if (ft < WFC) {
-            const int row = ft, tile = row >> 4, o = row & 15;
-            const float acc = ((L.pF[0][tile][o] + L.pF[1][tile][o]) + (L.pF[2][tile][o] + L.pF[3][tile][o])) +
-                              ((L.pF[4][tile][o] + L.pF[5][tile][o]) + (L.pF[6][tile][o] + L.pF[7][tile][o]));
-            const float tt = fpc_tanhf(acc);
-            L.fo[X.own][row] = tt + tt;  // the "dual" FC is the same Linear summed twice (wavernn.py:89-92)
-        }
-    }
+    if (FC_ALL) wsd_F(L, R, fw, lane, ft);  // (the closed loops: every workgroup evaluates the layer for all 16 utterances)
     WSTAMP(11)
     return !ws_dead(L);
 }
@@ -1032,7 +981,6 @@ __global__ __launch_bounds__(NT) void k_forward_ws(const PredDev P, const float*
     };
     if (tid < WFGT) {
         __builtin_amdgcn_s_setprio(FPC_FG_PRIO);
-        int fg_epoch = 0;
         float xa[2];
         x_row(1, xa);
         for (int t = 0; t < Lf; ++t) {
@@ -1043,7 +991,7 @@ __global__ __launch_bounds__(NT) void k_forward_ws(const PredDev P, const float*
                 if (xdst[j] >= 0) L.x[xdst[j]] = xa[j];
             df_signal(&L.sig[WSIG_X]);
             x_row(t + 2, xa);
-            if (!ws_foreground<true, false, true, TRAIN>(X, L, R, t, tid, fg_epoch, &sv)) break;
+            if (!ws_foreground<true, false, true, TRAIN>(X, L, R, t, tid, &sv)) break;
             WSTAMP(12)
         }
         __builtin_amdgcn_s_setprio(0);
@@ -1072,26 +1020,6 @@ __global__ __launch_bounds__(NT) void k_forward_ws(const PredDev P, const float*
     }
 }
 
-// hop 3: the owners' next input rows (18 values = 6 granules each) -> x image; threads p < 96 of waves 0, 1
-__device__ __forceinline__ bool ws_gather3(const WsCtx& X, WsLds& L, int p, unsigned epoch) {
-    const int u = p / WQX, e = p - u * WQX;
-    int gi[1] = {(p < WG * WQX && u < X.nu && u != X.slice) ? WOFF_X + p : -1};  // (an owner has its own row already)
-    u32x4 v[1];
-    if (!ws_poll<1>(X, L, gi, epoch, v)) return false;
-    if (gi[0] >= 0) {
-        L.x[ws_xi(3 * e + 0, u)] = __uint_as_float(v[0].y);
-        L.x[ws_xi(3 * e + 1, u)] = __uint_as_float(v[0].z);
-        L.x[ws_xi(3 * e + 2, u)] = __uint_as_float(v[0].w);
-    }
-    return true;
-}
-// the owner's next input row L.xn goes out and into its own column of the x image (threads of wave 0)
-__device__ __forceinline__ void ws_publish_x(const WsCtx& X, WsLds& L, int lane, unsigned epoch) {
-    if (lane < WQX) ws_store(X, WOFF_X + X.slice * WQX + lane, epoch, L.xn[3 * lane], L.xn[3 * lane + 1], L.xn[3 * lane + 2]);
-    if (lane < WIN) L.x[ws_xi(lane, X.slice)] = L.xn[lane];
-}
-
-
 // float64 squared distance in numpy's pairwise order (vq_func.py:18): target in LDS, entry in registers
 __device__ __forceinline__ double ws_dist(const double* x, const double (&c)[NDIM + 1]) {
     double r[8];
@@ -1116,11 +1044,17 @@ __device__ __forceinline__ double ws_dist(const double* x, const double (&c)[NDI
 __global__ __launch_bounds__(NT) void k_decode_feat_ws(const PredDev P, const CbDev C, const float* __restrict__ pitch,
                                                        const int* __restrict__ idx, int Lf, float* __restrict__ c_out,
                                                        int* bad, const WsArgs S) {
+    // The receiver in the encoder's distributed form (predictor_wsd.h): EVERY workgroup evaluates the output layer of all 16
+    // utterances (one MFMA tile gives all 16 columns for the price of one) and rebuilds every next input row itself from the
+    // symbols -- a lookup -- so the frame has two hops, not three, and no workgroup does more than another.  (The first form
+    // had the workgroup owning an utterance compute the tile for its one column, rebuild the row, publish it, and everybody
+    // gather it: 2.16 ms at 128 x 300 against 1.82 ms for the ENCODER without quantisation, which does strictly more.)
     __shared__ WsLds L;
     const int tid = threadIdx.x;
     int group, slice;
     if (!ws_role(S.ngroups, group, slice)) return;
     WsCtx X = ws_ctx(S, group, slice);
+    X.own = -1;  // (the output layer runs for all utterances on every workgroup: ws_foreground<false, true>)
     WsRegs R;
     for (int i = tid; i < WH1 * WG; i += NT) L.h1[i] = 0.0f;
     for (int i = tid; i < WH2 * WG; i += NT) L.h2[i] = 0.0f;
@@ -1128,38 +1062,29 @@ __global__ __launch_bounds__(NT) void k_decode_feat_ws(const PredDev P, const Cb
     __syncthreads();
     ws_prologue(P, X, L, R, S, tid);
     if (X.fallback) return;  // (workgroup- and group-uniform, nothing written yet) the row-split launch behind this one serves the group
-    const bool owner = slice < X.nu;
-    const int b = X.b0 + slice;
-    int fg_epoch = 0;
     int i = 0;
+    // thread (u, m) = column m of utterance u; the pitch columns (m = 18, 19) are side information of the receiver
+    const int u = tid >> 5, m = tid & 31;
+    const float* pvp = nullptr;
+    if (m >= WFC && m < WIN && u < X.nu) pvp = pitch + (size_t)(X.b0 + u) * Lf * (WIN - WFC) + (m - WFC);
     for (; i < Lf; ++i) {
-        const unsigned epoch = (unsigned)i + 1u;
-        float pv = 0.0f;  // the pitch columns are side information of the receiver
-        if (tid < (WIN - WFC) * WG) {
-            const int u = tid / (WIN - WFC), k = tid % (WIN - WFC);
-            if (u < X.nu) pv = pitch[((size_t)(X.b0 + u) * Lf + i) * (WIN - WFC) + k];
-        }
+        const float pv = pvp != nullptr ? pvp[(size_t)i * (WIN - WFC)] : 0.0f;  // fetched before the step
         if (tid < WFGT) {
             __builtin_amdgcn_s_setprio(FPC_FG_PRIO);
-            (void)ws_foreground(X, L, R, i, tid, fg_epoch);
+            (void)ws_foreground<false, true>(X, L, R, i, tid);
             __builtin_amdgcn_s_setprio(0);
         } else {
             (void)ws_background(X, L, R, i, i + 1 == Lf, tid - WFGT);
         }
-        lds_barrier();
-        if (owner && tid < 64) {  // the residual is a lookup: one wave rebuilds the owned utterance's next input row
-            decode_frame(L.fo[slice], L.xn, P, C, pitch, idx, c_out, bad, (size_t)b * Lf + i, true, tid);
-            ws_publish_x(X, L, tid, epoch);
-        }
-        if (tid < (WIN - WFC) * WG) {
-            const int u = tid / (WIN - WFC), k = WFC + tid % (WIN - WFC);
-            if (!(owner && u == slice)) L.x[ws_xi(k, u)] = pv;
-        }
-        if (tid >= 64 && tid < 192) (void)ws_gather3(X, L, tid - 64, epoch);
-        if (ws_frame_dead(L, tid)) break;
+        lds_barrier();  // both roles meet: the tail takes the whole workgroup
+        wsd_receive_tail(X, L, P, C, idx, c_out, bad, Lf, i, pv, tid);
+        if (tid == 0) L.dead_latch = __hip_atomic_load(&L.dead, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        lds_barrier();  // the next input rows are in LDS; the give-up flag as every thread acts on it
+        if (L.dead_latch != 0) break;
     }
-    if (i < Lf && owner) {  // fail loudly: NaN from this frame on; the host reports FPC_ERR_TIMEOUT
+    if (i < Lf && slice < X.nu) {  // fail loudly: NaN from this frame on (its rows came from a failed hop); FPC_ERR_TIMEOUT on the host
         const float qnan = __uint_as_float(0x7fc00000u);
+        const int b = X.b0 + slice;
         for (size_t k = (size_t)i * WIN + tid; k < (size_t)Lf * WIN; k += NT) c_out[(size_t)b * Lf * WIN + k] = qnan;
     }
 }

@@ -399,6 +399,61 @@ __device__ __forceinline__ void wsd_tail(const WsCtx& X, WsLds& L, const CbDev& 
     }
 }
 
+// The RECEIVER's frame tail (k_decode_feat_ws): thread (u, m) = row m of utterance u.  Prediction from the output layer's segment
+// sums (wsd_F), quantized residual looked up from the frame's four symbols exactly as decode_frame does (scalar code | first +
+// second stage of the upper books | the lower book; -1: none; a symbol outside its book raises `bad`, reported by the workgroup
+// that owns the utterance), next input row into the image; the owner stores the row.
+__device__ __forceinline__ void wsd_receive_tail(const WsCtx& X, WsLds& L, const PredDev& P, const CbDev& C, const int* __restrict__ idx,
+                                                 float* __restrict__ c_out, int* bad, int Lf, int frame, float pv, int tid) {
+    const int u = tid >> 5, m = tid & 31;
+    const bool uv = u < X.nu, owner = uv && X.slice == u;
+    const size_t fi = (size_t)(X.b0 + (uv ? u : 0)) * Lf + frame;
+    if (m < WFC) {
+        const int o = u * WPF + m;
+        const float acc = ((L.pFa[0][o] + L.pFa[1][o]) + (L.pFa[2][o] + L.pFa[3][o])) +
+                          ((L.pFa[4][o] + L.pFa[5][o]) + (L.pFa[6][o] + L.pFa[7][o]));
+        const float tt = fpc_tanhf(acc);
+        const float f = tt + tt;  // the "dual" FC is the same Linear summed twice (wavernn.py:89-92)
+        float rq = 0.0f;
+        if (uv) {
+            const int* ix = idx + fi * 4;
+            if (m == 0) {
+                const int k = ix[0];
+                if (k >= 0) {
+                    if (k < C.n_hi)
+                        rq = (float)C.scl_hi[k];
+                    else if (C.scl_lo && k - C.n_hi < C.n_lo)
+                        rq = (float)C.scl_lo[k - C.n_hi];
+                    else if (owner)
+                        atomicOr(bad, 1);
+                }
+            } else {
+                const int d = m - 1, k1 = ix[1], k2 = ix[2], k3 = ix[3];
+                if (k1 >= 0) {
+                    if (k1 >= C.N_hi0 || (C.S_hi == 2 && (k2 < 0 || k2 >= C.N_hi1))) {
+                        if (owner) atomicOr(bad, 1);
+                    } else {
+                        const double e0 = C.vq_hi0_r[(size_t)k1 * NDIM + d];
+                        rq = (float)(C.S_hi == 2 ? e0 + C.vq_hi1_r[(size_t)k2 * NDIM + d] : e0);
+                    }
+                } else if (k3 >= 0) {
+                    if (!C.vq_lo_r || k3 >= C.N_lo) {
+                        if (owner) atomicOr(bad, 1);
+                    } else {
+                        rq = (float)C.vq_lo_r[(size_t)k3 * NDIM + d];
+                    }
+                }
+            }
+        }
+        const float cn = f + rq;
+        L.x[ws_xi(m, u)] = uv ? cn : 0.0f;
+        if (owner) c_out[fi * WIN + m] = cn;
+    } else if (m < WIN) {
+        L.x[ws_xi(m, u)] = uv ? pv : 0.0f;
+        if (owner) c_out[fi * WIN + m] = pv;
+    }
+}
+
 __global__ __launch_bounds__(NT) void k_encode_wsd(const PredDev P, const CbDev C, const EncArgs A, const WsArgs S) {
     __shared__ WsLds L;
     const int tid = threadIdx.x;
@@ -421,7 +476,6 @@ __global__ __launch_bounds__(NT) void k_encode_wsd(const PredDev P, const CbDev 
     __syncthreads();
     ws_prologue(P, X, L, R, S, tid);
     if (X.fallback) return;  // (workgroup- and group-uniform, nothing written yet) the row-split launch behind this one serves the group
-    int fg_epoch = 0;
     int i = 0;
     // this thread's feature value of a frame: thread (u, m) = column m < 20 of utterance u -- rows 0-17 for the residuals, the
     // pitch columns pass through to the next input (wavernn.py:178) -- where it is in frame 0 (nullptr: none)
@@ -436,7 +490,7 @@ __global__ __launch_bounds__(NT) void k_encode_wsd(const PredDev P, const CbDev 
         const float2 mk = mkp != nullptr ? mkp[i] : make_float2(0.0f, 0.0f);
         if (tid < WFGT) {
             __builtin_amdgcn_s_setprio(FPC_FG_PRIO);
-            (void)ws_foreground<false, true>(X, L, R, i, tid, fg_epoch);
+            (void)ws_foreground<false, true>(X, L, R, i, tid);
             __builtin_amdgcn_s_setprio(0);
         } else {
             (void)ws_background(X, L, R, i, i + 1 == A.Lf, tid - WFGT);
