@@ -1952,8 +1952,9 @@ extern "C" int fpc_encode(fpc_predictor* p, const fpc_codebooks* cb, const float
         FPC_HIP(hipGetLastError());
         if (hist_dev && qtz) {
             const size_t frames = (size_t)B * L;
-            hipLaunchKernelGGL(k_hist_symbols, dim3((unsigned)((frames + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(s), cd,
-                               a.idx, frames, hist_dev);
+            const unsigned hblocks = (unsigned)std::min<size_t>(32, (frames + 2047) / 2048);
+            hipLaunchKernelGGL(k_hist_symbols, dim3(hblocks), dim3(256), sizeof(unsigned) * (size_t)cb->hist_size, static_cast<hipStream_t>(s),
+                               cd, a.idx, frames, cb->hist_size, hist_dev);
             FPC_HIP(hipGetLastError());
         }
 #ifdef FPC_WS_PROF
