@@ -155,7 +155,9 @@ FPC_API int fpc_predictor_set_split(fpc_predictor* p, int n);
 
 /* Wavernn.forward (wavernn.py:63-102): x [B,L,in] -> y [B,L,fc]; h1 [B,H1],
  * h2 [B,H2] are read as initial state and overwritten with the final state.
- * All pointers are device pointers. */
+ * All pointers are device pointers.  (Production shape: the recurrences run in k_forward_ws, which keeps relu(h2) of every
+ * frame in a scratch block of the handle -- B * L * H2 floats, grown on demand -- and the output layer runs over all frames
+ * at once behind it, k_out_layer: same values, same order, y bit-identical to the layer evaluated frame by frame.) */
 FPC_API int fpc_predictor_forward(fpc_predictor* p, const float* x_dev, int B, int L,
                           float* h1_dev, float* h2_dev, float* y_dev, fpc_stream s);
 
