@@ -1786,7 +1786,7 @@ extern "C" int fpc_predictor_forward(fpc_predictor* p, const float* x_dev, int B
         if (rcw != FPC_OK) return rcw;
         const size_t hbytes = sizeof(float) * (size_t)B * (size_t)(L > 0 ? L : 1) * WH2;  // relu(h2) of every sample, for k_out_layer
         if (p->h2hist.bytes < hbytes) {
-            FPC_HIP(hipStreamSynchronize(static_cast<hipStream_t>(s)));  // (a launch in flight may still read the old block)
+            FPC_HIP(hipDeviceSynchronize());  // (a launch in flight -- on this stream or another -- may still read the old block)
             if (p->h2hist.p) (void)hipFree(p->h2hist.p);
             p->h2hist.p = nullptr;
             FPC_HIP(p->h2hist.alloc(hbytes));
