@@ -7,7 +7,7 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("FPC_LIB_PATH") or os.path.join(_HERE, "libfpcodec.so")  # override: kernel-variant experiments
 _lib = None
-ABI_VERSION = 3  # the FPC_ABI_VERSION of include/fpcodec.h this binding is written against
+ABI_VERSION = 4  # the FPC_ABI_VERSION of include/fpcodec.h this binding is written against
 
 SYMBOLS = [
     "fpc_last_error", "fpc_abi_version", "fpc_build_info", "fpc_device_count",
@@ -17,7 +17,8 @@ SYMBOLS = [
     "fpc_encode", "fpc_decode_features", "fpc_vq_quantize", "fpc_scl_quantize", "fpc_ceps2lpc",
     "fpc_lpcnet_create", "fpc_lpcnet_destroy", "fpc_lpcnet_workspace_bytes",
     "fpc_lpcnet_synthesize", "fpc_lpcnet_condition", "fpc_lpcnet_last_decode_ms",
-    "fpc_lpcnet_kernel_variant", "fpc_lpcnet_set_chunk_frames",
+    "fpc_lpcnet_kernel_variant", "fpc_lpcnet_set_chunk_frames", "fpc_lpcnet_set_pairing",
+    "fpc_lpcnet_last_streams_per_workgroup",
     "fpc_trainer_create", "fpc_trainer_destroy", "fpc_trainer_step", "fpc_trainer_export",
     "fpc_cb_workspace_bytes", "fpc_cb_find_nearest", "fpc_cb_update", "fpc_cb_mean0", "fpc_kmeans1d",
 ]
@@ -83,6 +84,8 @@ def lib():
         L.fpc_lpcnet_last_decode_ms.argtypes = [C.c_void_p]
         L.fpc_lpcnet_kernel_variant.argtypes = [C.c_void_p]
         L.fpc_lpcnet_set_chunk_frames.argtypes = [C.c_void_p, C.c_int]
+        L.fpc_lpcnet_set_pairing.argtypes = [C.c_void_p, C.c_int]
+        L.fpc_lpcnet_last_streams_per_workgroup.argtypes = [C.c_void_p]
         L.fpc_trainer_create.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
         L.fpc_trainer_destroy.argtypes = [C.c_void_p]
         L.fpc_trainer_step.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_double, C.POINTER(C.c_float),

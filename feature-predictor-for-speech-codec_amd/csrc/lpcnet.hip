@@ -133,6 +133,7 @@ __global__ __launch_bounds__(256) void k_frame_mfma(const float* __restrict__ x,
 }
 
 #include "lpcnet_decode.h"
+#include "lpcnet_decode2.h"
 
 }  // namespace
 
@@ -166,6 +167,9 @@ struct fpc_lpcnet {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool timed = false;
     int chunk = 0;  // frames per chunk of fpc_lpcnet_synthesize (0: the whole utterance in one pass)
+    int pairing = 0;  // fpc_lpcnet_set_pairing: 0 two utterances per workgroup when B exceeds the CU count, 1 always, -1 never
+    int cus = 0;      // compute units of the device
+    int last_streams_per_wg = 0;  // what the last fpc_lpcnet_synthesize launched (fpc_lpcnet_last_streams_per_workgroup)
 };
 
 static size_t ws_floats_per_frame() { return 128 + 128 + 128 + GA + GB; }
@@ -186,6 +190,14 @@ extern "C" int fpc_lpcnet_set_chunk_frames(fpc_lpcnet* m, int frames) {
     return FPC_OK;
 }
 
+extern "C" int fpc_lpcnet_set_pairing(fpc_lpcnet* m, int mode) {
+    FPC_REQUIRE(m && mode >= -1 && mode <= 1, "fpc_lpcnet_set_pairing: bad argument");
+    m->pairing = mode;
+    return FPC_OK;
+}
+
+extern "C" int fpc_lpcnet_last_streams_per_workgroup(const fpc_lpcnet* m) { return m ? m->last_streams_per_wg : -1; }
+
 extern "C" void fpc_lpcnet_destroy(fpc_lpcnet* m);
 
 extern "C" int fpc_lpcnet_create(const fpc_lpcnet_weights* w, fpc_lpcnet** out) {
@@ -205,6 +217,8 @@ extern "C" int fpc_lpcnet_create(const fpc_lpcnet_weights* w, fpc_lpcnet** out) 
     fpc_lpcnet* m = own.get();
     FPC_HIP(hipGetDevice(&m->device));
     if (const char* e = getenv("FPC_LPCNET_CHUNK")) m->chunk = atoi(e) > 0 ? atoi(e) : 0;
+    if (const char* e = getenv("FPC_LPCNET_PAIRING")) m->pairing = atoi(e) > 0 ? 1 : atoi(e) < 0 ? -1 : 0;
+    FPC_HIP(hipDeviceGetAttribute(&m->cus, hipDeviceAttributeMultiprocessorCount, m->device));
 
     auto up = [&](fpc::DevBuf& d, const float* src, size_t n) -> hipError_t {
         hipError_t e = d.alloc(n * 4);
@@ -616,6 +630,17 @@ extern "C" int fpc_lpcnet_synthesize(fpc_lpcnet* m, const float* features_dev, i
         P.stamps = stamps.as<unsigned>();
     }
     const int variant = decode_variant(m);
+    // More utterances than compute units: k_decode2 walks two utterances through each workgroup (lpcnet_decode2.h; the
+    // packed partial-sum planes exist for the instances whose update / reset row groups are <= 4 lanes wide).  Same PCM.
+    const bool pair = variant != 1616 && B > 1 && (m->pairing > 0 || (m->pairing == 0 && B > m->cus));
+    m->last_streams_per_wg = pair ? 2 : 1;
+#define FPC_LAUNCH2(QZR)                                                                                      \
+    do {                                                                                                      \
+        if (stamp)                                                                                            \
+            hipLaunchKernelGGL((k_decode2<true, QZR>), dim3((B + 1) / 2), dim3(NTHREADS), 0, st, P, B);       \
+        else                                                                                                  \
+            hipLaunchKernelGGL((k_decode2<false, QZR>), dim3((B + 1) / 2), dim3(NTHREADS), 0, st, P, B);      \
+    } while (0)
 #define FPC_LAUNCH(QZR, QN)                                                                       \
     do {                                                                                          \
         if (stamp)                                                                                \
@@ -637,7 +662,11 @@ extern "C" int fpc_lpcnet_synthesize(fpc_lpcnet* m, const float* features_dev, i
         P.f0 = f0;
         P.f1 = f1;
         if (f0 == 0) FPC_HIP(hipEventRecord(m->ev0, st));  // (chunked: the span from the first sample loop to the last)
-        if (variant == 208)
+        if (pair && variant == 208)
+            FPC_LAUNCH2(2);
+        else if (pair)
+            FPC_LAUNCH2(4);
+        else if (variant == 208)
             FPC_LAUNCH(2, 8);
         else if (variant == 408)
             FPC_LAUNCH(4, 8);
@@ -645,6 +674,7 @@ extern "C" int fpc_lpcnet_synthesize(fpc_lpcnet* m, const float* features_dev, i
             FPC_LAUNCH(16, 16);
     }
 #undef FPC_LAUNCH
+#undef FPC_LAUNCH2
     FPC_HIP(hipEventRecord(m->ev1, st));
     FPC_HIP(hipGetLastError());
     if (stamp && (long long)T * FPC_FRAME_SIZE >= FPC_STAMP_T0 + FPC_STAMP_NS) {  // diagnostic path only: synchronises

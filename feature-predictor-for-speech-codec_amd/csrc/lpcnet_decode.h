@@ -615,5 +615,4 @@ __global__ __launch_bounds__(NTHREADS) void k_decode(const DecodeParams P) {
         }
     }
 }
-#undef FPC_BARRIER
-#undef FPC_STAMP
+// (FPC_BARRIER / FPC_STAMP stay defined for lpcnet_decode2.h, which undefines them)

@@ -1,0 +1,666 @@
+// lpcnet_decode2.h -- the sample loop for MORE UTTERANCES THAN COMPUTE UNITS: two utterances per workgroup
+// (included by lpcnet.hip behind lpcnet_decode.h, whose helpers it uses; gfx950).
+//
+// k_decode (one utterance per workgroup) is a latency chain: per sample its vector pipes are busy 61 % of the
+// time and the LDS pipe 42 % (profiles/r05_pmc_decode.txt).  With more utterances than CUs the chip runs the
+// grid in rounds; this kernel instead walks TWO utterances through one workgroup in lockstep -- the same four
+// barriers per sample (five if either utterance's frame is voiced), every phase carrying both utterances, so
+// that each wave has two independent dependency chains to issue from and every barrier, L2 round trip and LDS
+// hop is paid once per PAIR of samples:
+//   * the sparse GRU_A weights (128 registers per mat-vec lane), the GRU_B weights (72 per sampler lane), the
+//     activation table and the diagonal / bias rows are shared by both utterances;
+//   * the dual-FC weights (36 registers per sampler lane in k_decode) move to LDS -- one ds_read_b128 serves both
+//     utterances -- which is what frees the registers for the second set of accumulators;
+//   * the partial-sum planes are packed (planes 4..7 exist for the candidate gate only: the update / reset gates'
+//     row groups are <= 4 lanes wide in the instances this kernel has), 24.7 kB per utterance instead of 74 kB;
+//   * the draw of utterance 0 runs on wave 0, that of utterance 1 on wave 1, side by side.
+// Every value is produced by the same operations in the same order as in k_decode (and in
+// oracle/fpc_oracle.c::orc_lpcnet_synthesize): the PCM is bit-identical, whichever kernel decodes an utterance.
+// Launched by fpc_lpcnet_synthesize when B exceeds the device's CU count (fpc_lpcnet_set_pairing overrides).
+#pragma once
+
+constexpr int PN = RNN_A + 4;         // plane stride of planes 4..7 (candidate-gate rows only); +4 as PSTRIDE
+constexpr int PART_LO = 4 * PSTRIDE;  // planes 0..3: all 1152 gate rows
+constexpr int PART_HI = 4 * PN;       // planes 4..7
+#ifndef FPC2_DBG_NS
+#define FPC2_DBG_NS 2
+#endif
+#ifndef FPC2_ABL
+#define FPC2_ABL 0  // timing-only ablations (bit 0: no sparse-product FMAs, 1: no window work, 2: gates of utterance 0 only)
+#endif
+#ifndef FPC2_N1
+#define FPC2_N1 13  // column steps (of 32: 16 of utterance 0, then 16 of utterance 1) of the sparse product under GRU_B ...
+#endif
+#ifndef FPC2_N2
+#define FPC2_N2 8   // ... and under the dual FC; the rest under the draw
+#endif
+
+// Field order matters (as in DecodeLds): everything a lane addresses with a lane-constant register plus a constant sits in
+// the first 64 KB, where the constant folds into the DS instruction's 16-bit offset field -- both utterances' copies, so one
+// address register serves both; the activation table's base (indexed by a computed value) folds likewise.  Behind them
+// the arrays that are addressed through a base register anyway.
+struct __attribute__((aligned(16))) PairStream {
+    float s1[RNN_A];
+    float cfa[GA];
+    float s2[RNN_B];
+    float hist[16];
+    unsigned o_sig, o_pred, o_exc;
+    float pred;
+    float4 qq[128];
+    float4 cand[256];
+};
+struct __attribute__((aligned(16))) PairStreamFar {
+    float p[256];
+    float uframe[FPC_FRAME_SIZE];
+    float part[PART_LO + PART_HI];
+};
+struct __attribute__((aligned(16))) Decode2Lds {
+    PairStream S[2];
+    float diag[GA];
+    float brn_a[RNN_A];
+    float ulaw_thr[64];
+    float2 tt[FPC_TANH_TABLE_SIZE - 1];
+    PairStreamFar F[2];
+    float4 fcw[9 * NSAMP];  // dual-FC weights of node = lane: chunk c = (fcw[2c], fcw[2c+1]) of k_decode's register array
+};
+static_assert(offsetof(Decode2Lds, tt) < 65536, "the activation table's base must fold into a DS offset");
+static_assert(sizeof(Decode2Lds) <= 160 * 1024, "Decode2Lds exceeds the LDS of a CU");
+
+// six independent row butterflies interleaved (see row_bfly16x3): DPP reads come >= 5 instructions behind the write
+__device__ __forceinline__ void row_bfly16x6(float& a, float& b, float& c, float& d, float& e, float& f) {
+#define FPC_B6(CTRL)                                                              \
+    "v_add_f32_dpp %0, %0, %0 " CTRL " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t" \
+    "v_add_f32_dpp %1, %1, %1 " CTRL " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t" \
+    "v_add_f32_dpp %2, %2, %2 " CTRL " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t" \
+    "v_add_f32_dpp %3, %3, %3 " CTRL " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t" \
+    "v_add_f32_dpp %4, %4, %4 " CTRL " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t" \
+    "v_add_f32_dpp %5, %5, %5 " CTRL " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+    asm volatile("s_nop 1\n\t" FPC_B6("quad_perm:[1,0,3,2]") FPC_B6("quad_perm:[2,3,0,1]") FPC_B6("row_half_mirror")
+                     FPC_B6("row_mirror")
+                 : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f));
+#undef FPC_B6
+}
+
+// the lane's index in its wave, produced where it is needed (two VALU instructions; asm volatile: not hoisted, so no
+// register -- or scratch slot -- is held across the sample loop for it)
+__device__ __forceinline__ unsigned lane_index_here() {
+    unsigned x;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(x));
+    return x;
+}
+
+// N table activations at once: all indices, all ds_read_b64, then all interpolations -- one LDS round trip for the
+// batch (the compiler otherwise emits read / wait / use per activation); same operations per value as lut_scaled
+template <int N>
+__device__ __forceinline__ void lut_batch(const float2* T2, const float (&x)[N], const float scale, float (&y)[N]) {
+    float f[N];
+    float2 td[N];
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+        const float u = fminf(fabsf(x[k]) * scale, 4095.99976f);
+        f[k] = __builtin_amdgcn_fractf(u);
+        td[k] = T2[(uint32_t)u];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int k = 0; k < N; ++k) y[k] = copysignf(fmaf(f[k], td[k].y, td[k].x), x[k]);
+}
+
+// the draw of one utterance by one wave (k_decode's drawing wave): normaliser, tail cut, scan, search, control block
+__device__ __forceinline__ float pair_draw(PairStream& S, const float4 p4, const bool sharpened, const float uf,
+                                           const int lane, const int t) {
+    float thr = 0.002f;
+    if (sharpened) {
+        float rs = row_bfly16((p4.x + p4.y) + (p4.z + p4.w));
+        rs = add_bcast<DPP_BCAST15, 0xa>(rs);
+        rs = add_bcast<DPP_BCAST31, 0xc>(rs);
+        thr = 0.002f * lane_val(rs, 63);
+    }
+    const float c0 = __builtin_amdgcn_fmed3f(p4.x - thr, 0.0f, 1.0f);
+    const float c1 = __builtin_amdgcn_fmed3f(p4.y - thr, 0.0f, 1.0f);
+    const float c2 = __builtin_amdgcn_fmed3f(p4.z - thr, 0.0f, 1.0f);
+    const float c3 = __builtin_amdgcn_fmed3f(p4.w - thr, 0.0f, 1.0f);
+    const float P1 = c0 + c1, s23 = c2 + c3;
+    const float P2 = P1 + c2, P3 = P1 + s23;
+    float I = P3;
+    I = I + dpp_f<DPP_ROW_SHR + 1>(I);
+    I = I + dpp_f<DPP_ROW_SHR + 2>(I);
+    I = I + dpp_f<DPP_ROW_SHR + 4>(I);
+    I = I + dpp_f<DPP_ROW_SHR + 8>(I);
+    I = add_bcast<DPP_BCAST15, 0xa>(I);
+    I = add_bcast<DPP_BCAST31, 0xc>(I);
+    const float rthr = uf * lane_val(I, 63);
+    const float O = dpp_f<DPP_WAVE_SHR1>(I);
+    const unsigned long long m0 = __builtin_amdgcn_fcmpf(O + c0, rthr, 5 /* FCMP_OLE */);
+    const unsigned long long m1 = __builtin_amdgcn_fcmpf(O + P1, rthr, 5);
+    const unsigned long long m2 = __builtin_amdgcn_fcmpf(O + P2, rthr, 5);
+    const unsigned long long m3 = __builtin_amdgcn_fcmpf(I, rthr, 5);
+    int exc = (__popcll(m0) + __popcll(m1)) + (__popcll(m2) + __popcll(m3));
+    exc = exc > 255 ? 255 : exc;
+    float4 cd = S.cand[exc];
+    asm volatile("" : "+v"(cd.x), "+v"(cd.y), "+v"(cd.z), "+v"(cd.w));
+    if (lane == 0) {
+        *reinterpret_cast<float4*>(&S.o_sig) =
+            make_float4(cd.z, cd.w, __uint_as_float((512u + (unsigned)exc) * (unsigned)GA), cd.y);
+        S.hist[t & 15] = cd.x;
+    }
+    return cd.x;
+}
+
+template <bool STAMP, int QZR>
+__global__ __launch_bounds__(NTHREADS) void k_decode2(const DecodeParams P, const int B) {
+    __shared__ Decode2Lds L;
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;  // (wave: an SGPR)
+    const int T = P.T;
+    // utterances 2 * block and 2 * block + 1; an odd batch's last workgroup decodes its one utterance twice (both
+    // copies compute and store the same values)
+    const int bs[2] = {2 * (int)blockIdx.x, 2 * (int)blockIdx.x + 1 < B ? 2 * (int)blockIdx.x + 1 : 2 * (int)blockIdx.x};
+
+    // ---- LDS init (k_decode's, per utterance) ----
+    const bool resume = P.state != nullptr && P.f0 > 0;
+    float* rec[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) rec[s] = P.state != nullptr ? P.state + (size_t)bs[s] * STATE_FLOATS : nullptr;
+    for (int i = tid; i < RNN_A; i += NTHREADS) {
+#pragma unroll
+        for (int s = 0; s < 2; ++s) L.S[s].s1[i] = resume ? rec[s][i] : 0.0f;
+        L.brn_a[i] = P.brn_a[i];
+    }
+    for (int i = tid; i < GA; i += NTHREADS) L.diag[i] = P.diag[i];
+    for (int i = tid; i < PART_LO + PART_HI; i += NTHREADS) L.F[0].part[i] = L.F[1].part[i] = 0.0f;
+    if (tid < 64) L.ulaw_thr[tid] = k_ulaw_thr[tid];
+    for (int k = tid; k < FPC_TANH_TABLE_SIZE - 1; k += NTHREADS) {
+        const float t0 = fpc_tanh_table_entry(k), t1 = fpc_tanh_table_entry(k + 1);
+        L.tt[k] = make_float2(t0, t1 - t0);
+    }
+    for (int i = tid; i < 9 * NSAMP; i += NTHREADS) {
+        // chunk c of node sl: rows 2c, 2c+1 of k_decode's fcw[18] = (channel 0, channel 1) pairs of inputs 2c, 2c+1;
+        // chunk 8 = (bias pair, factor pair)
+        const int c = i / NSAMP, sl = i - c * NSAMP;
+        float4 v;
+        if (c < 8) {
+            v.x = P.lane_fc[(2 * c) * NSAMP + sl];
+            v.y = P.lane_fc[(16 + 2 * c) * NSAMP + sl];
+            v.z = P.lane_fc[(2 * c + 1) * NSAMP + sl];
+            v.w = P.lane_fc[(16 + 2 * c + 1) * NSAMP + sl];
+        } else {
+            v.x = P.lane_fc[32 * NSAMP + sl];
+            v.y = P.lane_fc[33 * NSAMP + sl];
+            v.z = P.lane_fc[34 * NSAMP + sl];
+            v.w = P.lane_fc[35 * NSAMP + sl];
+        }
+        L.fcw[i] = v;
+    }
+    if (tid < 2 * RNN_B) {
+        const int s = tid >> 4, k = tid & 15;
+        L.S[s].s2[k] = resume ? rec[s][RNN_A + k] : 0.0f;
+        L.S[s].hist[k] = resume ? rec[s][RNN_A + 16 + k] : 0.0f;
+    }
+    if (tid < 2) {
+        PairStream& S = L.S[tid];
+        if (resume) {
+            *reinterpret_cast<float4*>(&S.o_sig) = *reinterpret_cast<const float4*>(&rec[tid][RNN_A + 32]);
+        } else {
+            S.o_sig = 128u * GA;
+            S.o_pred = (256u + 128u) * GA;
+            S.o_exc = (512u + 128u) * GA;
+            S.pred = -0.0f;
+        }
+    }
+    int16_t* out[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        out[s] = P.pcm + (size_t)bs[s] * T * FPC_FRAME_SIZE;
+        if (tid < FPC_LPC_ORDER + 1 && P.f0 == 0) out[s][tid] = 0;
+    }
+    __syncthreads();
+
+    if (wave >= 4) {
+        // =========================== mat-vec role ===========================
+        const int ml_ = tid - NSAMP;
+        f2 w2[64];
+#pragma unroll
+        for (int j = 0; j < 64; ++j) {
+            const int bc = j >> 2, rp = j & 3;
+            const int bb = bc >> 2, c = bc & 3;
+            w2[j] = mk2(P.lane_w[(bb * 32 + (2 * rp) * 4 + c) * NMAT + ml_],
+                        P.lane_w[(bb * 32 + (2 * rp + 1) * 4 + c) * NMAT + ml_]);
+        }
+        const unsigned colp_ = (unsigned)P.lane_meta[ml_];
+        const unsigned metap_ = (unsigned)P.lane_meta[NMAT + ml_];
+        const bool gate_lane = ml_ < RNN_A;
+        const unsigned ml_wave0 = (unsigned)__builtin_amdgcn_readfirstlane(ml_ & ~63);  // first lane of this wave (SGPR)
+        typedef __attribute__((address_space(3))) float lds_float;
+        // where this lane's 8 partial row sums of utterance 0 go (utterance 1: + sizeof(PairStreamFar)); 0 = no group
+        unsigned paddr_ = 0u;
+        if ((metap_ >> 16) != 0) {
+            const int grp = (int)(metap_ >> 16) - 1;
+            const int gate = grp / (RNN_A / 8), rb = grp - gate * (RNN_A / 8);
+            const int q = (int)(metap_ & 0xff);
+            float* dst = q < 4 ? &L.F[0].part[q * PSTRIDE + gate * RNN_A + rb * 8]
+                               : &L.F[0].part[PART_LO + (q - 4) * PN + rb * 8];  // (q >= 4: candidate gate only)
+            paddr_ = (unsigned)(size_t)(lds_float*)dst;
+        }
+        paddr_ = opaque(paddr_);
+
+        // steps k = 0..31 of the pair's sparse products: utterance k >> 4, column k & 15.  One accumulator set: an
+        // utterance's sums are published as its last column is done
+#define FPC2_STEPS(FROM, TO)                                                                                      \
+    _Pragma("unroll") for (int k = (FROM); k < (TO); ++k) {                                                       \
+        const int s = k >> 4, bc = k & 15;                                                                        \
+        if (bc == 0) {                                                                                            \
+            _Pragma("unroll") for (int rp = 0; rp < 4; ++rp) acc[rp] = a[rp] = splat2(0.0f);                      \
+            const unsigned colp = opaque(colp_);                                                                  \
+            const float4 ha = *reinterpret_cast<const float4*>(&L.S[s].s1[(colp & 0xff) * 4]);                    \
+            const float4 hb = *reinterpret_cast<const float4*>(&L.S[s].s1[((colp >> 8) & 0xff) * 4]);             \
+            hv0[0] = ha.x, hv0[1] = ha.y, hv0[2] = ha.z, hv0[3] = ha.w;                                           \
+            hv0[4] = hb.x, hv0[5] = hb.y, hv0[6] = hb.z, hv0[7] = hb.w;                                           \
+        }                                                                                                         \
+        if (bc == 8) {                                                                                            \
+            const unsigned colp = opaque(colp_);                                                                  \
+            const float4 hc = *reinterpret_cast<const float4*>(&L.S[s].s1[((colp >> 16) & 0xff) * 4]);            \
+            const float4 hd = *reinterpret_cast<const float4*>(&L.S[s].s1[(colp >> 24) * 4]);                     \
+            hv1[0] = hc.x, hv1[1] = hc.y, hv1[2] = hc.z, hv1[3] = hc.w;                                           \
+            hv1[4] = hd.x, hv1[5] = hd.y, hv1[6] = hd.z, hv1[7] = hd.w;                                           \
+        }                                                                                                         \
+        _Pragma("unroll") for (int rp = 0; rp < (FPC2_ABL & 1 ? 0 : 4); ++rp) {                                   \
+            if (bc < 8)                                                                                           \
+                acc[rp] = fma2(w2[bc * 4 + rp], splat2(hv0[bc]), acc[rp]);                                        \
+            else                                                                                                  \
+                a[rp] = fma2(w2[bc * 4 + rp], splat2(hv1[bc - 8]), a[rp]);                                        \
+        }                                                                                                         \
+        if (bc == 15) {                                                                                           \
+            _Pragma("unroll") for (int rp = 0; rp < 4; ++rp) acc[rp] = acc[rp] + a[rp];                           \
+            if (paddr_ != 0u) {                                                                                   \
+                typedef float v4f __attribute__((ext_vector_type(4)));                                            \
+                typedef __attribute__((address_space(3))) v4f lds_v4f;                                            \
+                lds_v4f* pp = (lds_v4f*)(size_t)(paddr_ + (unsigned)(s * sizeof(PairStreamFar)));                    \
+                v4f lo, hi;                                                                                       \
+                lo.x = acc[0].x, lo.y = acc[0].y, lo.z = acc[1].x, lo.w = acc[1].y;                               \
+                hi.x = acc[2].x, hi.y = acc[2].y, hi.z = acc[3].x, hi.w = acc[3].y;                               \
+                pp[0] = lo;                                                                                       \
+                pp[1] = hi;                                                                                       \
+            }                                                                                                     \
+        }                                                                                                         \
+    }                                                                                                             \
+    _Pragma("unroll") for (int rp = 0; rp < 4; ++rp) {                                                            \
+        pin(acc[rp]);                                                                                             \
+        pin(a[rp]);                                                                                               \
+    }
+        if (P.state != nullptr) {
+            if (resume) {  // the sparse products of the states the chunk starts from
+                f2 acc[4], a[4];
+                float hv0[8], hv1[8];
+                FPC2_STEPS(0, 32)
+            }
+            __syncthreads();
+        }
+        for (int fr = P.f0; fr < P.f1; ++fr) {
+            const bool voiced =
+                fpc_shape_exponent(P.features[((size_t)bs[0] * T + fr) * FPC_NB_FEATURES + 19]) > 0.0f ||
+                fpc_shape_exponent(P.features[((size_t)bs[1] * T + fr) * FPC_NB_FEATURES + 19]) > 0.0f;
+            if (gate_lane) {
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    const float* cfa = P.cfa + ((size_t)bs[s] * P.cf_T + (fr - P.f0)) * GA;
+                    L.S[s].cfa[ml_] = cfa[ml_];
+                    L.S[s].cfa[RNN_A + ml_] = cfa[RNN_A + ml_];
+                    L.S[s].cfa[2 * RNN_A + ml_] = cfa[2 * RNN_A + ml_];
+                }
+            }
+            for (int i = (fr == 0 ? FPC_LPC_ORDER + 1 : 0); i < FPC_FRAME_SIZE; ++i) {
+                const int st_t = fr * FPC_FRAME_SIZE + i;
+                const bool stamp_on = STAMP && blockIdx.x == 0 && st_t >= FPC_STAMP_T0 && st_t < FPC_STAMP_T0 + FPC_STAMP_NS;
+                // ---- X..Y: both utterances' table rows gathered together, gates of both ----
+#if FPC_PRIO
+                __builtin_amdgcn_s_setprio(FPC_PRIO);
+#endif
+                if (gate_lane) {
+                    const unsigned ml = lane_index_here() + ml_wave0;
+                    struct F3 {
+                        float x, y, z;
+                    };
+                    const char* tabc = reinterpret_cast<const char*>(P.tab);
+                    F3 ta[2], tb[2], tc[2];
+#pragma unroll
+                    for (int s = 0; s < (FPC2_ABL & 4 ? 1 : 2); ++s) {
+                        const unsigned oa = L.S[s].o_sig, ob = L.S[s].o_pred, oc = L.S[s].o_exc;
+                        ta[s] = *reinterpret_cast<const F3*>(tabc + (size_t)((oa + 3u * ml) * 4u));
+                        tb[s] = *reinterpret_cast<const F3*>(tabc + (size_t)((ob + 3u * ml) * 4u));
+                        tc[s] = *reinterpret_cast<const F3*>(tabc + (size_t)((oc + 3u * ml) * 4u));
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    // while the six rows are in flight: recurrent terms of the unit's three rows, utterance by utterance,
+                    // eight plane reads per LDS round trip
+                    float unb[2], uz[2], ur[2];
+#pragma unroll
+                    for (int s = 0; s < (FPC2_ABL & 4 ? 1 : 2); ++s) {
+                        const float* pl = &L.F[s].part[ml];
+                        {
+                            const float p0 = pl[2 * RNN_A], p1 = pl[2 * RNN_A + PSTRIDE], p2 = pl[2 * RNN_A + 2 * PSTRIDE],
+                                        p3 = pl[2 * RNN_A + 3 * PSTRIDE];
+                            __builtin_amdgcn_sched_barrier(0);
+                            const float lo4 = (p0 + p1) + (p2 + p3);
+                            const float p4 = pl[PART_LO], p5 = pl[PART_LO + PN], p6 = pl[PART_LO + 2 * PN],
+                                        p7 = pl[PART_LO + 3 * PN];
+                            __builtin_amdgcn_sched_barrier(0);
+                            const float hi4 = (p4 + p5) + (p6 + p7);
+                            const float h_own = L.S[s].s1[ml], dn = L.diag[2 * RNN_A + ml], bn = L.brn_a[ml];
+                            __builtin_amdgcn_sched_barrier(0);
+                            unb[s] = fmaf(dn, h_own, lo4 + hi4) + bn;
+                        }
+                        {
+                            float tz, tr;
+                            const float h_own = L.S[s].s1[ml], dz = L.diag[ml], dr = L.diag[RNN_A + ml];
+                            if (QZR == 4) {
+                                const float z0 = pl[0], z1 = pl[PSTRIDE], z2 = pl[2 * PSTRIDE], z3 = pl[3 * PSTRIDE];
+                                __builtin_amdgcn_sched_barrier(0);
+                                tz = (z0 + z1) + (z2 + z3);
+                                const float r0 = pl[RNN_A], r1 = pl[RNN_A + PSTRIDE], r2 = pl[RNN_A + 2 * PSTRIDE],
+                                            r3 = pl[RNN_A + 3 * PSTRIDE];
+                                __builtin_amdgcn_sched_barrier(0);
+                                tr = (r0 + r1) + (r2 + r3);
+                            } else {
+                                const float z0 = pl[0], z1 = pl[PSTRIDE];
+                                const float r0 = pl[RNN_A], r1 = pl[RNN_A + PSTRIDE];
+                                __builtin_amdgcn_sched_barrier(0);
+                                tz = z0 + z1;
+                                tr = r0 + r1;
+                            }
+                            uz[s] = fmaf(dz, h_own, tz);
+                            ur[s] = fmaf(dr, h_own, tr);
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    float xs[4];
+#pragma unroll
+                    for (int s = 0; s < (FPC2_ABL & 4 ? 1 : 2); ++s) {
+                        const float cz = L.S[s].cfa[ml], cr = L.S[s].cfa[RNN_A + ml];
+                        xs[2 * s] = (((ta[s].x + tb[s].x) + tc[s].x) + cz) + uz[s];
+                        xs[2 * s + 1] = (((ta[s].y + tb[s].y) + tc[s].y) + cr) + ur[s];
+                    }
+                    float zr[4];
+                    lut_batch<4>(L.tt, xs, 256.0f, zr);
+                    float xn[2];
+#pragma unroll
+                    for (int s = 0; s < (FPC2_ABL & 4 ? 1 : 2); ++s) {
+                        const float gn = ((ta[s].z + tb[s].z) + tc[s].z) + L.S[s].cfa[2 * RNN_A + ml];
+                        xn[s] = fmaf(fmaf(0.5f, zr[2 * s + 1], 0.5f), unb[s], gn);
+                    }
+                    float nn[2];
+                    lut_batch<2>(L.tt, xn, 512.0f, nn);
+#pragma unroll
+                    for (int s = 0; s < (FPC2_ABL & 4 ? 1 : 2); ++s) {
+                        const float h_own = L.S[s].s1[ml];
+                        L.S[s].s1[ml] = fmaf(fmaf(0.5f, zr[2 * s], 0.5f), h_own - nn[s], nn[s]);
+                    }
+                }
+#if FPC_PRIO
+                __builtin_amdgcn_s_setprio(0);
+#endif
+                FPC_BARRIER(0)  // Y
+                f2 acc[4], a[4];
+                float hv0[8], hv1[8];
+                FPC2_STEPS(0, FPC2_N1)
+                FPC_BARRIER(1)  // Z1
+                FPC2_STEPS(FPC2_N1, FPC2_N1 + FPC2_N2)
+                FPC_BARRIER(2)  // Z2
+                if (voiced) {
+                    FPC_BARRIER(3)  // Z3
+                }
+                FPC2_STEPS(FPC2_N1 + FPC2_N2, 32)
+                FPC_BARRIER(4)  // X
+            }
+        }
+#undef FPC2_STEPS
+        if (gate_lane) {
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+                if (rec[s] != nullptr) rec[s][ml_] = L.S[s].s1[ml_];
+        }
+    } else {
+        // =========================== sampler role ===========================
+        __builtin_amdgcn_s_setprio(3);
+        const int sl = tid;
+        const int u = sl >> 4, kl = sl & 15;
+        const int dw = wave & 1;  // the utterance this wave draws (waves 0, 1) and whose de-emphasis state it tracks
+        f2 wB[3][6][2];
+#pragma unroll
+        for (int g = 0; g < 3; ++g)
+#pragma unroll
+            for (int m = 0; m < 6; ++m)
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+                    wB[g][m][h] = mk2(P.lane_wb[(g * 24 + 4 * m + 2 * h) * NSAMP + sl],
+                                      P.lane_wb[(g * 24 + 4 * m + 2 * h + 1) * NSAMP + sl]);
+        const float ub0 = P.lane_ub[sl], ub1 = P.lane_ub[NSAMP + sl], ub2 = P.lane_ub[2 * NSAMP + sl];
+        const float brnb = P.brn_b[u];
+        const float my_ulaw = P.ulaw_tab[sl];
+        float mem = resume ? rec[dw][RNN_A + 36] : 0.0f;
+        float pcm_new = 0.0f;
+        float s2_own[2];
+#pragma unroll
+        for (int s = 0; s < 2; ++s) s2_own[s] = resume ? rec[s][RNN_A + u] : 0.0f;
+        if (P.state != nullptr) __syncthreads();
+
+        for (int fr = P.f0; fr < P.f1; ++fr) {
+            float shape_e[2], cfb_z[2], cfb_r[2], cfb_n[2], a_cur[2], a_nxt[2], a0_cur[2], a0_nxt[2];
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const float* feat = P.features + ((size_t)bs[s] * T + fr) * FPC_NB_FEATURES;
+                shape_e[s] = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(fpc_shape_exponent(feat[19]))));
+                const float* cfb = P.cfb + ((size_t)bs[s] * P.cf_T + (fr - P.f0)) * GB;
+                cfb_z[s] = cfb[u], cfb_r[s] = cfb[RNN_B + u], cfb_n[s] = cfb[2 * RNN_B + u];
+                const float* fa = feat + (FPC_NB_FEATURES - FPC_LPC_ORDER);
+                const float* fan = fa + (fr + 1 < T ? FPC_NB_FEATURES : 0);
+                a_cur[s] = fa[kl], a_nxt[s] = fan[kl];
+                a0_cur[s] = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(fa[0])));
+                a0_nxt[s] = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(fan[0])));
+                if (sl < FPC_FRAME_SIZE)
+                    L.F[s].uframe[sl] = fpc_philox_uniform(P.seeds[bs[s]], (uint32_t)(fr * FPC_FRAME_SIZE + sl));
+            }
+            const bool voiced = shape_e[0] > 0.0f || shape_e[1] > 0.0f;
+
+            for (int i = (fr == 0 ? FPC_LPC_ORDER + 1 : 0); i < FPC_FRAME_SIZE; ++i) {
+                const int t = fr * FPC_FRAME_SIZE + i;
+                const int st_t = t;
+                const bool stamp_on = STAMP && blockIdx.x == 0 && st_t >= FPC_STAMP_T0 && st_t < FPC_STAMP_T0 + FPC_STAMP_NS;
+#if FPC_PRIO
+                __builtin_amdgcn_s_setprio(0);
+#endif
+                // ---- X..Y: GRU_B recurrent parts, LPC taps, leaf candidates of both utterances ----
+                float ub_z[2], ub_r[2], ub_n[2];
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    const float s2k = L.S[s].s2[kl];
+                    ub_z[s] = ub0 * s2k, ub_r[s] = ub1 * s2k, ub_n[s] = ub2 * s2k;
+                }
+                row_bfly16x6(ub_z[0], ub_r[0], ub_n[0], ub_z[1], ub_r[1], ub_n[1]);
+#pragma unroll
+                for (int s = 0; s < (FPC2_ABL & 2 ? 0 : 2); ++s) {
+                    const bool lastsmp = i == FPC_FRAME_SIZE - 1;
+                    const float am = lastsmp ? a_nxt[s] : a_cur[s];
+                    const float a0 = lastsmp ? a0_nxt[s] : a0_cur[s];
+                    const float hk = L.S[s].hist[(t - kl) & 15];
+                    const float part = row_bfly16(kl ? am * hk : 0.0f);
+                    const float cpcm = L.S[s].pred + my_ulaw;
+                    const float cpred = -fmaf(a0, cpcm, part);
+                    const unsigned es = (unsigned)fpc_lin2ulaw_tab(cpcm, L.ulaw_thr);
+                    const unsigned ep = 256u + (unsigned)fpc_lin2ulaw_tab(cpred, L.ulaw_thr);
+                    L.S[s].cand[sl] = make_float4(cpcm, cpred, __uint_as_float((es << 10) + (es << 7)),
+                                                  __uint_as_float((ep << 10) + (ep << 7)));
+                }
+#if FPC2_ABL & 2
+                L.S[0].cand[sl] = L.S[1].cand[sl] = make_float4(0.0f, 0.0f, __uint_as_float(128u * GA), __uint_as_float(384u * GA));
+#endif
+#if FPC_PRIO
+                __builtin_amdgcn_s_setprio(3);
+#endif
+                FPC_BARRIER(0)  // Y
+                // ---- Y..Z1: GRU_B of both utterances (one weight register feeds two chains) ----
+                {
+                    const unsigned klv = (unsigned)kl;
+                    f2 acc[2][3][2];
+#pragma unroll
+                    for (int s = 0; s < 2; ++s)
+#pragma unroll
+                        for (int g = 0; g < 3; ++g) acc[s][g][0] = acc[s][g][1] = splat2(0.0f);
+#pragma unroll
+                    for (int m = 0; m < 6; ++m) {
+#pragma unroll
+                        for (int s = 0; s < 2; ++s) {
+                            const float4 h4 = *reinterpret_cast<const float4*>(&L.S[s].s1[24 * klv + 4 * m]);
+#pragma unroll
+                            for (int g = 0; g < 3; ++g) {
+                                acc[s][g][0] = fma2(wB[g][m][0], mk2(h4.x, h4.y), acc[s][g][0]);
+                                acc[s][g][1] = fma2(wB[g][m][1], mk2(h4.z, h4.w), acc[s][g][1]);
+                            }
+                        }
+                    }
+                    float a3[2][3];
+#pragma unroll
+                    for (int s = 0; s < 2; ++s)
+#pragma unroll
+                        for (int g = 0; g < 3; ++g) {
+                            const f2 pr = acc[s][g][0] + acc[s][g][1];
+                            a3[s][g] = pr.x + pr.y;
+                        }
+                    row_bfly16x6(a3[0][0], a3[0][1], a3[0][2], a3[1][0], a3[1][1], a3[1][2]);
+                    {
+                        // gates of both utterances: the four sigmoids in one LDS round trip, the two tanh in a second
+                        const float xs[4] = {(a3[0][0] + cfb_z[0]) + ub_z[0], (a3[0][1] + cfb_r[0]) + ub_r[0],
+                                             (a3[1][0] + cfb_z[1]) + ub_z[1], (a3[1][1] + cfb_r[1]) + ub_r[1]};
+                        float zr[4];
+                        lut_batch<4>(L.tt, xs, 256.0f, zr);
+                        const float xn[2] = {fmaf(fmaf(0.5f, zr[1], 0.5f), ub_n[0] + brnb, a3[0][2] + cfb_n[0]),
+                                             fmaf(fmaf(0.5f, zr[3], 0.5f), ub_n[1] + brnb, a3[1][2] + cfb_n[1])};
+                        float nn[2];
+                        lut_batch<2>(L.tt, xn, 512.0f, nn);
+#pragma unroll
+                        for (int s = 0; s < 2; ++s) {
+                            const float z = fmaf(0.5f, zr[2 * s], 0.5f);
+                            s2_own[s] = fmaf(z, s2_own[s] - nn[s], nn[s]);
+                        }
+                        if (kl == 0) {
+                            L.S[0].s2[u] = s2_own[0];
+                            L.S[1].s2[u] = s2_own[1];
+                        }
+                    }
+                }
+                FPC_BARRIER(1)  // Z1
+                // ---- Z1..Z2: dual FC of tree node `sl`, both utterances; weights from LDS, read once, a stage
+                //      (two weight chunks + four state values per utterance) ahead of the products ----
+                {
+                    const unsigned slv = opaque((unsigned)sl);
+                    float4 wa[2], wb[2], sv[2][2];
+#define FPC2_FC_LOAD(k4)                                                                 \
+    wa[(k4) & 1] = L.fcw[(2 * (k4)) * NSAMP + slv];                                      \
+    wb[(k4) & 1] = L.fcw[(2 * (k4) + 1) * NSAMP + slv];                                  \
+    sv[(k4) & 1][0] = *reinterpret_cast<const float4*>(&L.S[0].s2[4 * (k4)]);            \
+    sv[(k4) & 1][1] = *reinterpret_cast<const float4*>(&L.S[1].s2[4 * (k4)]);
+                    const float4 bf = L.fcw[8 * NSAMP + slv];  // (bias pair, factor pair)
+                    FPC2_FC_LOAD(0)
+                    f2 a01[2], b01[2];
+#pragma unroll
+                    for (int s = 0; s < 2; ++s) a01[s] = mk2(bf.x, bf.y), b01[s] = splat2(0.0f);
+#pragma unroll
+                    for (int k4 = 0; k4 < 4; ++k4) {
+                        if (k4 < 3) {
+                            FPC2_FC_LOAD(k4 + 1)
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                        const float4 w0 = wa[k4 & 1], w1 = wb[k4 & 1];
+#pragma unroll
+                        for (int s = 0; s < 2; ++s) {
+                            const float4 v = sv[k4 & 1][s];
+                            a01[s] = fma2(mk2(w0.x, w0.y), splat2(v.x), a01[s]);
+                            b01[s] = fma2(mk2(w0.z, w0.w), splat2(v.y), b01[s]);
+                            a01[s] = fma2(mk2(w1.x, w1.y), splat2(v.z), a01[s]);
+                            b01[s] = fma2(mk2(w1.z, w1.w), splat2(v.w), b01[s]);
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+#undef FPC2_FC_LOAD
+                    {
+                        const f2 c0 = a01[0] + b01[0], c1 = a01[1] + b01[1];
+                        const float xt[4] = {c0.x, c0.y, c1.x, c1.y};
+                        float t4[4];
+                        lut_batch<4>(L.tt, xt, 512.0f, t4);
+                        const float xv[2] = {fmaf(bf.w, t4[1], bf.z * t4[0]), fmaf(bf.w, t4[3], bf.z * t4[2])};
+                        float qs[2];
+                        lut_batch<2>(L.tt, xv, 256.0f, qs);
+#pragma unroll
+                        for (int s = 0; s < 2; ++s) {
+                            const float qv = fmaf(0.5f, qs[s], 0.5f);
+                            reinterpret_cast<float2*>(L.S[s].qq)[slv] = make_float2(1.0f - qv, qv);
+                        }
+                    }
+                }
+                const float uf = L.F[dw].uframe[i];
+                FPC_BARRIER(2)  // Z2
+                // ---- voiced frames: leaf probability + sharpening on all 256 lanes, per voiced utterance ----
+                if (voiced) {
+#pragma unroll
+                    for (int s = 0; s < 2; ++s) {
+                        if (shape_e[s] > 0.0f) {
+                            const float* qf = reinterpret_cast<const float*>(L.S[s].qq);
+                            const unsigned slv = opaque((unsigned)sl);
+                            float f[8];
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) f[j] = qf[(2u << j) + (slv >> (7 - j))];
+                            const float p = ((((f[0] * f[1]) * (f[2] * f[3])) * (f[4] * f[5])) * f[6]) * f[7];
+                            L.F[s].p[slv] = fpc_shape_pow(p, shape_e[s]);
+                        }
+                    }
+                    FPC_BARRIER(3)  // Z3
+                }
+                // ---- waves 0 / 1: the draw of utterance 0 / 1 ----
+                auto draw_phase = [&](PairStream& S, const float* pp, const float she) {
+                    const bool sharp = she > 0.0f;
+                    float4 p4;
+                    if (sharp) {
+                        p4 = *reinterpret_cast<const float4*>(&pp[4 * lane]);
+                    } else {
+                        const float* qf = reinterpret_cast<const float*>(S.qq);
+                        const unsigned lv = (unsigned)lane;
+                        float f[6];
+#pragma unroll
+                        for (int j = 0; j < 6; ++j) f[j] = qf[(2u << j) + (lv >> (5 - j))];
+                        const float2 q6 = *reinterpret_cast<const float2*>(&qf[128u + 2u * lv]);
+                        const float4 q7 = *reinterpret_cast<const float4*>(&qf[256u + 4u * lv]);
+                        const float pre = ((f[0] * f[1]) * (f[2] * f[3])) * (f[4] * f[5]);
+                        const float lo = pre * q6.x, hi = pre * q6.y;
+                        p4.x = lo * q7.x;
+                        p4.y = lo * q7.y;
+                        p4.z = hi * q7.z;
+                        p4.w = hi * q7.w;
+                    }
+                    pcm_new = pair_draw(S, p4, sharp, uf, lane, t);
+                };
+                if (wave == 0)
+                    draw_phase(L.S[0], L.F[0].p, shape_e[0]);
+                else if (wave == 1)
+                    draw_phase(L.S[1], L.F[1].p, shape_e[1]);
+                FPC_BARRIER(4)  // X
+                if (wave < 2) {
+                    mem = fmaf(FPC_PREEMPH, mem, pcm_new);
+                    if (lane == 0) out[dw][t] = fpc_pcm16(mem);
+                }
+            }
+        }
+        if (sl < 2 * RNN_B) {
+            const int s = sl >> 4, k = sl & 15;
+            if (rec[s] != nullptr) {
+                rec[s][RNN_A + k] = L.S[s].s2[k];
+                rec[s][RNN_A + 16 + k] = L.S[s].hist[k];
+            }
+        }
+        if (wave < 2 && lane == 0 && rec[dw] != nullptr) {
+            *reinterpret_cast<float4*>(&rec[dw][RNN_A + 32]) = *reinterpret_cast<const float4*>(&L.S[dw].o_sig);
+            rec[dw][RNN_A + 36] = mem;
+        }
+    }
+}
+#undef FPC_BARRIER
+#undef FPC_STAMP

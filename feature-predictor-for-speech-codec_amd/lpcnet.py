@@ -81,6 +81,14 @@ class LPCNet:
         not grow with T and gives the same samples (fpc_lpcnet_set_chunk_frames)"""
         _lib.check(_lib.lib().fpc_lpcnet_set_chunk_frames(self.handle, int(frames)), "fpc_lpcnet_set_chunk_frames")
 
+    def set_pairing(self, mode):
+        """utterances per workgroup of synthesize: 0 two when B exceeds the device's compute units (default), 1 always
+        two, -1 never (fpc_lpcnet_set_pairing); the PCM does not depend on it"""
+        _lib.check(_lib.lib().fpc_lpcnet_set_pairing(self.handle, int(mode)), "fpc_lpcnet_set_pairing")
+
+    def last_streams_per_workgroup(self):
+        return int(_lib.lib().fpc_lpcnet_last_streams_per_workgroup(self.handle))
+
     def workspace_bytes(self, B, T):
         return int(_lib.lib().fpc_lpcnet_workspace_bytes(self.handle, B, T))
 

@@ -27,8 +27,12 @@ extern "C" {
 
 /* 2: fpc_encode takes the input mask (mask_dev, NULL = thresholds); exports fpc_build_info, fpc_lpcnet_set_chunk_frames
  *    (fpc_lpcnet_workspace_bytes follows the handle's chunk setting).  A binding compares fpc_abi_version() with the
- *    FPC_ABI_VERSION it was written against BEFORE any other call: the symbol sets of versions differ. */
-#define FPC_ABI_VERSION 3
+ *    FPC_ABI_VERSION it was written against BEFORE any other call: the symbol sets of versions differ.
+ * 3: exports fpc_kmeans1d (scalar-codebook k-means) and fpc_predictor_fallback_groups; fpc_predictor_forward keeps a scratch
+ *    block in the handle (relu(h2) of all frames for the batched output layer).
+ * 4: exports fpc_lpcnet_set_pairing and fpc_lpcnet_last_streams_per_workgroup (fpc_lpcnet_synthesize decodes two utterances
+ *    per workgroup when the batch exceeds the device's compute units). */
+#define FPC_ABI_VERSION 4
 #define FPC_API __attribute__((visibility("default")))
 
 typedef enum {
@@ -271,6 +275,18 @@ FPC_API long long fpc_lpcnet_workspace_bytes(const fpc_lpcnet* m, int B, int T);
  * 2 kB record per utterance -- so the workspace does not grow with T.  Same samples bit for bit (tests); each chunk ends
  * when its slowest utterance does, which costs time: the default stays one pass. */
 FPC_API int fpc_lpcnet_set_chunk_frames(fpc_lpcnet* m, int frames);
+
+/* How fpc_lpcnet_synthesize maps utterances onto workgroups.  mode 0 (default; the environment variable
+ * FPC_LPCNET_PAIRING sets the default of new handles): one utterance per workgroup (k_decode) while B <= the device's
+ * compute units, two per workgroup (k_decode2: both utterances walk the sample loop in lockstep and share the weights in
+ * registers / LDS, every barrier and every L2 round trip) when B is larger -- the grid of B workgroups would otherwise run in
+ * rounds.  mode 1: always two per workgroup (B >= 2); mode -1: never.  The PCM of an utterance does not depend on the
+ * mapping (same operations in the same order; tests).  Models whose update / reset row groups are wider than 4 lanes
+ * (fpc_lpcnet_kernel_variant 1616) always take one utterance per workgroup. */
+FPC_API int fpc_lpcnet_set_pairing(fpc_lpcnet* m, int mode);
+/* utterances per workgroup of the last fpc_lpcnet_synthesize on this handle: 1 or 2 (0 before the first call, <0 on a
+ * null handle) */
+FPC_API int fpc_lpcnet_last_streams_per_workgroup(const fpc_lpcnet* m);
 
 /* test_lpcnet.py loop.  Device pointers.
  *   features [B,T,36] float32 (un-normalised: cepstrum, pitch, corr, 16 LPC)

@@ -30,9 +30,9 @@ def test_abi_exports_every_declared_symbol(built):
     for s in declared:
         assert hasattr(L, s), s
     m = re.search(r"#define FPC_ABI_VERSION (\d+)", hdr)
-    assert m and L.fpc_abi_version() == int(m.group(1)) == built.ABI_VERSION == 3
+    assert m and L.fpc_abi_version() == int(m.group(1)) == built.ABI_VERSION == 4
     # the shipped library is built without -D tunables and says so (a variant build lists them: tools/build_variant.sh)
-    assert L.fpc_build_info() == b"fpcodec abi 3 gfx950"
+    assert L.fpc_build_info() == b"fpcodec abi 4 gfx950"
 
 
 def test_binding_names_a_library_of_another_abi_version(built, tmp_path, monkeypatch):
