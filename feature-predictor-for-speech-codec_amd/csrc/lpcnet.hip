@@ -161,6 +161,9 @@ struct fpc_lpcnet {
     fpc::DevBuf embed_pitch, conv1_k, conv1_b, conv2_k, conv2_b, d1_k, d1_b, d2_k, d2_b;
     fpc::DevBuf ga_k, gb_k, bias_a, bias_b, tab;
     fpc::DevBuf lane_w, lane_meta, lane_wb, lane_ub, lane_fc, diag, brn_a, brn_b, ulaw_tab;
+    fpc::DevBuf lane_w2, lane_meta2;  // k_decode2's placement (row groups padded to an even number of lanes)
+    bool pair_ok = false;             // k_decode2 can serve this model
+    int lds_read_cycles2 = 0;
     int gate_qp[3];
     int nblocks = 0, nleaves = 0;
     int lds_read_cycles_greedy = 0, lds_read_cycles = 0;  // LDS cycles of the mat-vec state reads per sample (diagnostic)
@@ -188,6 +191,14 @@ extern "C" int fpc_lpcnet_set_chunk_frames(fpc_lpcnet* m, int frames) {
     FPC_REQUIRE(m && frames >= 0, "fpc_lpcnet_set_chunk_frames: bad argument");
     m->chunk = frames;
     return FPC_OK;
+}
+
+// kernel instance by the widest row group: (update/reset gates, candidate gate) partial-sum planes
+static int decode_variant_of(const int (&gate_qp)[3]) {
+    const int qzr = gate_qp[0] > gate_qp[1] ? gate_qp[0] : gate_qp[1], qn = gate_qp[2];
+    if (qzr <= 2 && qn <= 8) return 208;
+    if (qzr <= 4 && qn <= 8) return 408;
+    return 1616;
 }
 
 extern "C" int fpc_lpcnet_set_pairing(fpc_lpcnet* m, int mode) {
@@ -277,186 +288,207 @@ extern "C" int fpc_lpcnet_create(const fpc_lpcnet_weights* w, fpc_lpcnet** out) 
         }
         m->nblocks += (int)grps[g].cols.size();
     }
-    // canonical leaf = 2 consecutive blocks; a mat-vec lane owns 2 consecutive leaves (4 blocks);
-    // the lanes of one row group are consecutive lanes of ONE 16-lane DPP row
-    constexpr int NROWS16 = NMAT / 16;
-    std::vector<int> order(NROWGRP);
-    for (int g = 0; g < NROWGRP; ++g) order[g] = g;
-    auto lanes_of = [&](int g) {  // an empty row group still owns one (all-zero) lane
-        const int n = ((int)grps[g].cols.size() + 3) / 4;
-        return n > 0 ? n : 1;
-    };
-    std::sort(order.begin(), order.end(), [&](int a, int b) {
-        const int la = lanes_of(a), lb = lanes_of(b);
-        return la != lb ? la > lb : a < b;
-    });
-    int row_fill[NROWS16] = {0};
-    int gate_q[3] = {1, 1, 1};
-    std::vector<int> first_lane(NROWGRP, 0);  // placement: first lane of each row group
-    // a lane may hold its two leaves in either order (block slots 0,1 <-> 2,3): their sums are added in the lane,
-    // and a + b == b + a exactly, so the order is free for the placement search below
-    std::vector<char> leaf_flip(NROWGRP * 16, 0);
-    for (int oi = 0; oi < NROWGRP; ++oi) {
-        const int g = order[oi], Q = lanes_of(g);
-        int best = -1;
-        for (int rw = 0; rw < NROWS16; ++rw)  // least-filled 16-lane row that still has room
-            if (row_fill[rw] + Q <= 16 && (best < 0 || row_fill[rw] < row_fill[best])) best = rw;
-        if (Q > 16 || best < 0) {
-            fpc::set_error(
-                "fpc_lpcnet_create: recurrent matrix too dense for the register-resident layout "
-                "(%d blocks of 8x4, row group %d needs %d lanes; capacity %d blocks, 64 per row group)",
-                m->nblocks, g, Q, 4 * NMAT);
-            return FPC_ERR_CAPACITY;
+    // ---- placement of the row groups on the mat-vec lanes.  Twice: the layout of k_decode, and (even = true) the one of
+    // k_decode2, whose lanes 2k, 2k+1 of a row group add their partial sums before publishing, so every group is padded
+    // to an even number of lanes (an all-zero lane contributes +0, the padding of the canonical tree).  Returns 0, 1
+    // (even only: the padded groups do not fit) or a negative status.
+    auto pack = [&](const bool even, fpc::DevBuf& dst_w, fpc::DevBuf& dst_meta, int (&gate_qp)[3], int& nleaves,
+                    int& lds_greedy, int& lds_cycles) -> int {
+        // canonical leaf = 2 consecutive blocks; a mat-vec lane owns 2 consecutive leaves (4 blocks);
+        // the lanes of one row group are consecutive lanes of ONE 16-lane DPP row
+        constexpr int NROWS16 = NMAT / 16;
+        std::vector<int> order(NROWGRP);
+        for (int g = 0; g < NROWGRP; ++g) order[g] = g;
+        auto lanes_of = [&](int g) {  // an empty row group still owns one (all-zero) lane
+            int n = ((int)grps[g].cols.size() + 3) / 4;
+            n = n > 0 ? n : 1;
+            return even ? (n + 1) & ~1 : n;  // (k_decode2: lanes 2k, 2k+1 of a group add their sums before publishing)
+        };
+        std::sort(order.begin(), order.end(), [&](int a, int b) {
+            const int la = lanes_of(a), lb = lanes_of(b);
+            return la != lb ? la > lb : a < b;
+        });
+        int row_fill[NROWS16] = {0};
+        int gate_q[3] = {1, 1, 1};
+        nleaves = 0;
+        std::vector<int> first_lane(NROWGRP, 0);  // placement: first lane of each row group
+        // a lane may hold its two leaves in either order (block slots 0,1 <-> 2,3): their sums are added in the lane,
+        // and a + b == b + a exactly, so the order is free for the placement search below
+        std::vector<char> leaf_flip(NROWGRP * 16, 0);
+        for (int oi = 0; oi < NROWGRP; ++oi) {
+            const int g = order[oi], Q = lanes_of(g);
+            int best = -1;
+            for (int rw = 0; rw < NROWS16; ++rw)  // least-filled 16-lane row that still has room
+                if (row_fill[rw] + Q <= 16 && (best < 0 || row_fill[rw] < row_fill[best])) best = rw;
+            if (even && (Q > 16 || best < 0)) return 1;  // no room for the padded groups: the handle decodes one utterance per workgroup
+            if (Q > 16 || best < 0) {
+                fpc::set_error(
+                    "fpc_lpcnet_create: recurrent matrix too dense for the register-resident layout "
+                    "(%d blocks of 8x4, row group %d needs %d lanes; capacity %d blocks, 64 per row group)",
+                    m->nblocks, g, Q, 4 * NMAT);
+                return FPC_ERR_CAPACITY;
+            }
+            first_lane[g] = best * 16 + row_fill[best];
+            row_fill[best] += Q;
+            const int gate = g / (RNN_A / 8);
+            if (Q > gate_q[gate]) gate_q[gate] = Q;
+            nleaves += Q;
         }
-        first_lane[g] = best * 16 + row_fill[best];
-        row_fill[best] += Q;
-        const int gate = g / (RNN_A / 8);
-        if (Q > gate_q[gate]) gate_q[gate] = Q;
-        m->nleaves += Q;
-    }
-    // ---- LDS bank conflicts of the state reads (speed only; the results do not depend on the placement).  Every
-    // sample each mat-vec lane fetches the 4 inputs of each of its 4 blocks with one ds_read_b128 at float 4 * cb of
-    // the state: a wave's read is served in four groups of 16 lanes, one LDS cycle per group when the lanes' addresses
-    // fall into different bank quads (cb mod 16) or coincide (MI355X_MICROARCH.md, LDS).  Row groups of equal width
-    // swap places while that lowers the cycle count (deterministic local search, a few ms at create).
-    {
-        static const int kGroupOf[64] = {0, 0, 0, 0, 1, 1, 1, 1, 1, 1, 1, 1, 0, 0, 0, 0, 1, 1, 1, 1, 0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1,
-                                         2, 2, 2, 2, 3, 3, 3, 3, 3, 3, 3, 3, 2, 2, 2, 2, 3, 3, 3, 3, 2, 2, 2, 2, 2, 2, 2, 2, 3, 3, 3, 3};
-        std::vector<int> lane_cb((size_t)NMAT * 4, 0);  // column block of (lane, block slot); 0 = padding reads block 0
-        auto emit = [&](int g) {
-            const int Q = lanes_of(g);
-            for (int q = 0; q < Q; ++q)
-                for (int bb = 0; bb < 4; ++bb) {
-                    const int bi = 4 * q + (leaf_flip[g * 16 + q] ? bb ^ 2 : bb);
-                    lane_cb[(size_t)(first_lane[g] + q) * 4 + bb] = bi < (int)grps[g].cols.size() ? grps[g].cols[bi] : 0;
-                }
-        };
-        for (int g = 0; g < NROWGRP; ++g) emit(g);
-        auto wave_cost = [&](int wv) {
-            int cost = 0;
-            for (int bb = 0; bb < 4; ++bb)
-                for (int pg = 0; pg < 4; ++pg) {
-                    int seen[16][8], cnt[16] = {0}, worst = 1;
-                    for (int l = 0; l < 64; ++l) {
-                        if (kGroupOf[l] != pg) continue;
-                        const int cb = lane_cb[(size_t)(wv * 64 + l) * 4 + bb], qd = cb & 15;
-                        bool dup = false;
-                        for (int k = 0; k < cnt[qd]; ++k) dup = dup || seen[qd][k] == cb;
-                        if (!dup && cnt[qd] < 8) seen[qd][cnt[qd]++] = cb;
-                        if (cnt[qd] > worst) worst = cnt[qd];
-                    }
-                    cost += worst;
-                }
-            return cost;
-        };
-        int cost[NMAT / 64], total = 0;
-        for (int wv = 0; wv < NMAT / 64; ++wv) total += cost[wv] = wave_cost(wv);
-        m->lds_read_cycles_greedy = total;
-        // rows as ordered lists of groups; a move swaps two groups (any widths, any rows) if both rows keep <= 16 lanes
-        std::vector<std::vector<int>> rows(NROWS16);
-        std::vector<int> row_of(NROWGRP);
+        // ---- LDS bank conflicts of the state reads (speed only; the results do not depend on the placement).  Every
+        // sample each mat-vec lane fetches the 4 inputs of each of its 4 blocks with one ds_read_b128 at float 4 * cb of
+        // the state: a wave's read is served in four groups of 16 lanes, one LDS cycle per group when the lanes' addresses
+        // fall into different bank quads (cb mod 16) or coincide (MI355X_MICROARCH.md, LDS).  Row groups of equal width
+        // swap places while that lowers the cycle count (deterministic local search, a few ms at create).
         {
-            std::vector<int> by_lane(NROWGRP);
-            for (int g = 0; g < NROWGRP; ++g) by_lane[g] = g;
-            std::sort(by_lane.begin(), by_lane.end(), [&](int x, int y) { return first_lane[x] < first_lane[y]; });
-            for (int g : by_lane) {
-                rows[first_lane[g] / 16].push_back(g);
-                row_of[g] = first_lane[g] / 16;
+            static const int kGroupOf[64] = {0, 0, 0, 0, 1, 1, 1, 1, 1, 1, 1, 1, 0, 0, 0, 0, 1, 1, 1, 1, 0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1,
+                                             2, 2, 2, 2, 3, 3, 3, 3, 3, 3, 3, 3, 2, 2, 2, 2, 3, 3, 3, 3, 2, 2, 2, 2, 2, 2, 2, 2, 3, 3, 3, 3};
+            std::vector<int> lane_cb((size_t)NMAT * 4, 0);  // column block of (lane, block slot); 0 = padding reads block 0
+            auto emit = [&](int g) {
+                const int Q = lanes_of(g);
+                for (int q = 0; q < Q; ++q)
+                    for (int bb = 0; bb < 4; ++bb) {
+                        const int bi = 4 * q + (leaf_flip[g * 16 + q] ? bb ^ 2 : bb);
+                        lane_cb[(size_t)(first_lane[g] + q) * 4 + bb] = bi < (int)grps[g].cols.size() ? grps[g].cols[bi] : 0;
+                    }
+            };
+            for (int g = 0; g < NROWGRP; ++g) emit(g);
+            auto wave_cost = [&](int wv) {
+                int cost = 0;
+                for (int bb = 0; bb < 4; ++bb)
+                    for (int pg = 0; pg < 4; ++pg) {
+                        int seen[16][8], cnt[16] = {0}, worst = 1;
+                        for (int l = 0; l < 64; ++l) {
+                            if (kGroupOf[l] != pg) continue;
+                            const int cb = lane_cb[(size_t)(wv * 64 + l) * 4 + bb], qd = (even ? cb + (cb >= RNN_A / 8) : cb) & 15;
+                            bool dup = false;
+                            for (int k = 0; k < cnt[qd]; ++k) dup = dup || seen[qd][k] == cb;
+                            if (!dup && cnt[qd] < 8) seen[qd][cnt[qd]++] = cb;
+                            if (cnt[qd] > worst) worst = cnt[qd];
+                        }
+                        cost += worst;
+                    }
+                return cost;
+            };
+            int cost[NMAT / 64], total = 0;
+            for (int wv = 0; wv < NMAT / 64; ++wv) total += cost[wv] = wave_cost(wv);
+            lds_greedy = total;
+            // rows as ordered lists of groups; a move swaps two groups (any widths, any rows) if both rows keep <= 16 lanes
+            std::vector<std::vector<int>> rows(NROWS16);
+            std::vector<int> row_of(NROWGRP);
+            {
+                std::vector<int> by_lane(NROWGRP);
+                for (int g = 0; g < NROWGRP; ++g) by_lane[g] = g;
+                std::sort(by_lane.begin(), by_lane.end(), [&](int x, int y) { return first_lane[x] < first_lane[y]; });
+                for (int g : by_lane) {
+                    rows[first_lane[g] / 16].push_back(g);
+                    row_of[g] = first_lane[g] / 16;
+                }
             }
-        }
-        auto fill_of = [&](int rw) {
-            int f = 0;
-            for (int g : rows[rw]) f += lanes_of(g);
-            return f;
-        };
-        auto relayout = [&](int rw) {  // lanes of the row's groups in list order; lanes behind them read block 0
-            for (int l = rw * 16; l < rw * 16 + 16; ++l)
-                for (int bb = 0; bb < 4; ++bb) lane_cb[(size_t)l * 4 + bb] = 0;
-            int off = 0;
-            for (int g : rows[rw]) {
-                first_lane[g] = rw * 16 + off;
-                off += lanes_of(g);
-                emit(g);
-            }
-        };
-        unsigned rng = 12345u;
-        auto next = [&]() { return rng = rng * 1664525u + 1013904223u, rng >> 8; };
-        for (int it = 0; it < 80000; ++it) {
-            const int g1 = (int)(next() % NROWGRP), g2 = (int)(next() % NROWGRP);
-            if (it & 1) {  // flip the leaf order of one lane of g1
-                const int q = (int)(next() % (unsigned)lanes_of(g1)), wv = first_lane[g1] / 64;
-                leaf_flip[g1 * 16 + q] ^= 1;
-                emit(g1);
-                const int c = wave_cost(wv);
-                if (c <= cost[wv]) {
-                    total += c - cost[wv];
-                    cost[wv] = c;
-                } else {
+            auto fill_of = [&](int rw) {
+                int f = 0;
+                for (int g : rows[rw]) f += lanes_of(g);
+                return f;
+            };
+            auto relayout = [&](int rw) {  // lanes of the row's groups in list order; lanes behind them read block 0
+                for (int l = rw * 16; l < rw * 16 + 16; ++l)
+                    for (int bb = 0; bb < 4; ++bb) lane_cb[(size_t)l * 4 + bb] = 0;
+                int off = 0;
+                for (int g : rows[rw]) {
+                    first_lane[g] = rw * 16 + off;
+                    off += lanes_of(g);
+                    emit(g);
+                }
+            };
+            unsigned rng = 12345u;
+            auto next = [&]() { return rng = rng * 1664525u + 1013904223u, rng >> 8; };
+            for (int it = 0; it < 80000; ++it) {
+                const int g1 = (int)(next() % NROWGRP), g2 = (int)(next() % NROWGRP);
+                if (it & 1) {  // flip the leaf order of one lane of g1
+                    const int q = (int)(next() % (unsigned)lanes_of(g1)), wv = first_lane[g1] / 64;
                     leaf_flip[g1 * 16 + q] ^= 1;
                     emit(g1);
-                }
-                continue;
-            }
-            if (g1 == g2) continue;
-            const int r1 = row_of[g1], r2 = row_of[g2];
-            if (r1 != r2 && (fill_of(r1) - lanes_of(g1) + lanes_of(g2) > 16 || fill_of(r2) - lanes_of(g2) + lanes_of(g1) > 16))
-                continue;
-            auto do_swap = [&]() {
-                auto& a1 = rows[row_of[g1]];
-                auto& a2 = rows[row_of[g2]];
-                auto i1 = std::find(a1.begin(), a1.end(), g1);
-                auto i2 = std::find(a2.begin(), a2.end(), g2);
-                std::iter_swap(i1, i2);
-                std::swap(row_of[g1], row_of[g2]);
-                relayout(r1);
-                if (r2 != r1) relayout(r2);
-            };
-            do_swap();
-            const int w1 = r1 / 4, w2 = r2 / 4;
-            const int c1 = wave_cost(w1), c2 = w2 != w1 ? wave_cost(w2) : 0;
-            const int delta = c1 + c2 - cost[w1] - (w2 != w1 ? cost[w2] : 0);
-            if (delta <= 0) {
-                cost[w1] = c1;
-                if (w2 != w1) cost[w2] = c2;
-                total += delta;
-            } else {
-                do_swap();  // (swaps back: g1 now sits where g2 was)
-            }
-        }
-        m->lds_read_cycles = total;  // ideal: 8 waves x 4 reads x 4 groups = 128
-    }
-    std::vector<float> lane_w((size_t)128 * NMAT, 0.0f);
-    std::vector<int> lane_meta(2 * NMAT, 0);
-    for (int l = 0; l < NMAT; ++l) lane_meta[NMAT + l] = (1 << 8);  // no group, 1 lane, lane 0
-    for (int g = 0; g < NROWGRP; ++g) {
-        const int Q = lanes_of(g);
-        const int gate = g / (RNN_A / 8), rb = g % (RNN_A / 8);
-        for (int q = 0; q < Q; ++q) {
-            const int l = first_lane[g] + q;
-            lane_meta[NMAT + l] = q | (Q << 8) | ((g + 1) << 16);
-            unsigned colp = 0;
-            for (int bb = 0; bb < 4; ++bb) {
-                const int bi = 4 * q + (leaf_flip[g * 16 + q] ? bb ^ 2 : bb);
-                if (bi >= (int)grps[g].cols.size()) continue;  // weights stay 0, column block 0
-                const int cb = grps[g].cols[bi];
-                colp |= (unsigned)cb << (8 * bb);
-                for (int r = 0; r < 8; ++r)
-                    for (int c = 0; c < 4; ++c) {
-                        const int in = cb * 4 + c, o = rb * 8 + r;
-                        lane_w[(size_t)(bb * 32 + r * 4 + c) * NMAT + l] =
-                            in == o ? 0.0f : w->gru_a_recurrent[(size_t)in * GA + gate * RNN_A + o];
+                    const int c = wave_cost(wv);
+                    if (c <= cost[wv]) {
+                        total += c - cost[wv];
+                        cost[wv] = c;
+                    } else {
+                        leaf_flip[g1 * 16 + q] ^= 1;
+                        emit(g1);
                     }
+                    continue;
+                }
+                if (g1 == g2) continue;
+                const int r1 = row_of[g1], r2 = row_of[g2];
+                if (r1 != r2 && (fill_of(r1) - lanes_of(g1) + lanes_of(g2) > 16 || fill_of(r2) - lanes_of(g2) + lanes_of(g1) > 16))
+                    continue;
+                auto do_swap = [&]() {
+                    auto& a1 = rows[row_of[g1]];
+                    auto& a2 = rows[row_of[g2]];
+                    auto i1 = std::find(a1.begin(), a1.end(), g1);
+                    auto i2 = std::find(a2.begin(), a2.end(), g2);
+                    std::iter_swap(i1, i2);
+                    std::swap(row_of[g1], row_of[g2]);
+                    relayout(r1);
+                    if (r2 != r1) relayout(r2);
+                };
+                do_swap();
+                const int w1 = r1 / 4, w2 = r2 / 4;
+                const int c1 = wave_cost(w1), c2 = w2 != w1 ? wave_cost(w2) : 0;
+                const int delta = c1 + c2 - cost[w1] - (w2 != w1 ? cost[w2] : 0);
+                if (delta <= 0) {
+                    cost[w1] = c1;
+                    if (w2 != w1) cost[w2] = c2;
+                    total += delta;
+                } else {
+                    do_swap();  // (swaps back: g1 now sits where g2 was)
+                }
             }
-            lane_meta[l] = (int)colp;
+            lds_cycles = total;  // ideal: 8 waves x 4 reads x 4 groups = 128
         }
+        std::vector<float> lane_w((size_t)128 * NMAT, 0.0f);
+        std::vector<int> lane_meta(2 * NMAT, 0);
+        for (int l = 0; l < NMAT; ++l) lane_meta[NMAT + l] = (1 << 8);  // no group, 1 lane, lane 0
+        for (int g = 0; g < NROWGRP; ++g) {
+            const int Q = lanes_of(g);
+            const int gate = g / (RNN_A / 8), rb = g % (RNN_A / 8);
+            for (int q = 0; q < Q; ++q) {
+                const int l = first_lane[g] + q;
+                lane_meta[NMAT + l] = q | (Q << 8) | ((g + 1) << 16);
+                unsigned colp = 0;
+                for (int bb = 0; bb < 4; ++bb) {
+                    const int bi = 4 * q + (leaf_flip[g * 16 + q] ? bb ^ 2 : bb);
+                    if (bi >= (int)grps[g].cols.size()) continue;  // weights stay 0, column block 0
+                    const int cb = grps[g].cols[bi];
+                    colp |= (unsigned)(even ? cb + (cb >= RNN_A / 8) : cb) << (8 * bb);  // (k_decode2: float4 index in its padded state)
+                    for (int r = 0; r < 8; ++r)
+                        for (int c = 0; c < 4; ++c) {
+                            const int in = cb * 4 + c, o = rb * 8 + r;
+                            lane_w[(size_t)(bb * 32 + r * 4 + c) * NMAT + l] =
+                                in == o ? 0.0f : w->gru_a_recurrent[(size_t)in * GA + gate * RNN_A + o];
+                        }
+                }
+                lane_meta[l] = (int)colp;
+            }
+        }
+        for (int g = 0; g < 3; ++g) {
+            int qp = 1;
+            while (qp < gate_q[g]) qp <<= 1;
+            gate_qp[g] = qp;
+        }
+        FPC_HIP(dst_w.upload(lane_w));
+        FPC_HIP(dst_meta.upload(lane_meta));
+        return 0;
+    };
+    {
+        const int rc = pack(false, m->lane_w, m->lane_meta, m->gate_qp, m->nleaves, m->lds_read_cycles_greedy,
+                            m->lds_read_cycles);
+        if (rc != 0) return rc;
+        int qp2[3], nl2 = 0, g2 = 0, c2 = 0;
+        const int rc2 = pack(true, m->lane_w2, m->lane_meta2, qp2, nl2, g2, c2);
+        if (rc2 < 0) return rc2;
+        m->pair_ok = rc2 == 0 && decode_variant_of(m->gate_qp) != 1616;
+        m->lds_read_cycles2 = c2;
     }
-    for (int g = 0; g < 3; ++g) {
-        int qp = 1;
-        while (qp < gate_q[g]) qp <<= 1;
-        m->gate_qp[g] = qp;
-    }
-    FPC_HIP(m->lane_w.upload(lane_w));
-    FPC_HIP(m->lane_meta.upload(lane_meta));
 
     // sampler-lane weights: lane = (unit u, slice kl) for GRU_B, lane = tree node for the dual FC
     std::vector<float> lane_wb(72 * NSAMP), lane_ub(3 * NSAMP), lane_fc(36 * NSAMP);
@@ -496,13 +528,7 @@ extern "C" int fpc_lpcnet_create(const fpc_lpcnet_weights* w, fpc_lpcnet** out) 
 }
 
 namespace {
-// kernel instance by the widest row group: (update/reset gates, candidate gate) partial-sum planes
-int decode_variant(const fpc_lpcnet* m) {
-    const int qzr = m->gate_qp[0] > m->gate_qp[1] ? m->gate_qp[0] : m->gate_qp[1], qn = m->gate_qp[2];
-    if (qzr <= 2 && qn <= 8) return 208;
-    if (qzr <= 4 && qn <= 8) return 408;
-    return 1616;
-}
+int decode_variant(const fpc_lpcnet* m) { return decode_variant_of(m->gate_qp); }
 }  // namespace
 
 extern "C" int fpc_lpcnet_kernel_variant(const fpc_lpcnet* m) { return m ? decode_variant(m) : -1; }
@@ -632,8 +658,12 @@ extern "C" int fpc_lpcnet_synthesize(fpc_lpcnet* m, const float* features_dev, i
     const int variant = decode_variant(m);
     // More utterances than compute units: k_decode2 walks two utterances through each workgroup (lpcnet_decode2.h; the
     // packed partial-sum planes exist for the instances whose update / reset row groups are <= 4 lanes wide).  Same PCM.
-    const bool pair = variant != 1616 && B > 1 && (m->pairing > 0 || (m->pairing == 0 && B > m->cus));
+    const bool pair = m->pair_ok && B > 1 && (m->pairing > 0 || (m->pairing == 0 && B > m->cus));
     m->last_streams_per_wg = pair ? 2 : 1;
+    if (pair) {  // (k_decode2's placement of the row groups)
+        P.lane_w = m->lane_w2.as<float>();
+        P.lane_meta = m->lane_meta2.as<int>();
+    }
 #define FPC_LAUNCH2(QZR)                                                                                      \
     do {                                                                                                      \
         if (stamp)                                                                                            \
@@ -714,6 +744,18 @@ extern "C" int fpc_lpcnet_synthesize(fpc_lpcnet* m, const float* features_dev, i
             for (int k = 0; k < 5; ++k)
                 if (k != 3) fprintf(stderr, "  %s %.0f|%.0f", nm[k], work[k] / n, wait[k] / n);
             fprintf(stderr, "  (%d samples)\n", n);
+            if (w == 0 && slot(1, 0, 5) != 0) {  // (k_decode2: two stamps inside the GRU_B phase of the sampler waves)
+                double d5 = 0, d6 = 0;
+                int n2 = 0;
+                for (int sidx = 1; sidx < FPC_STAMP_NS; ++sidx) {
+                    if (slot(sidx, w, 3) != 0 || slot(sidx, w, 5) == 0) continue;
+                    const unsigned rel = release(sidx, 0);
+                    d5 += (double)(int)(slot(sidx, w, 5) - rel);
+                    d6 += (double)(int)(slot(sidx, w, 6) - rel);
+                    ++n2;
+                }
+                if (n2) fprintf(stderr, "[fpc stamps] wave 0 inside Y..Z1: products done at +%.0f, butterfly done at +%.0f\n", d5 / n2, d6 / n2);
+            }
             if (w == 0)
                 fprintf(stderr, "[fpc stamps] phase lengths (release to release): X..Y %.0f  Y..Z1 %.0f  Z1..Z2 %.0f  ..X %.0f  sum %.0f\n",
                         phase[0] / n, phase[1] / n, phase[2] / n, phase[4] / n, (phase[0] + phase[1] + phase[2] + phase[4]) / n);

@@ -19,20 +19,31 @@
 // Launched by fpc_lpcnet_synthesize when B exceeds the device's CU count (fpc_lpcnet_set_pairing overrides).
 #pragma once
 
-constexpr int PN = RNN_A + 4;         // plane stride of planes 4..7 (candidate-gate rows only); +4 as PSTRIDE
-constexpr int PART_LO = 4 * PSTRIDE;  // planes 0..3: all 1152 gate rows
-constexpr int PART_HI = 4 * PN;       // planes 4..7
+// A plane holds the sums of TWO adjacent lanes of a row group (lanes 2k, 2k+1 add their eight row sums -- the first level
+// of the canonical tree -- with one DPP add per value before lane 2k publishes): half the planes, half the LDS traffic.
+constexpr int PN = RNN_A + 4;         // plane stride of planes 2, 3 (candidate-gate rows only); +4 as PSTRIDE
+constexpr int PART_LO = 2 * PSTRIDE;  // planes 0, 1: all 1152 gate rows
+constexpr int PART_HI = 2 * PN;       // planes 2, 3
 #ifndef FPC2_DBG_NS
 #define FPC2_DBG_NS 2
 #endif
 #ifndef FPC2_ABL
 #define FPC2_ABL 0  // timing-only ablations (bit 0: no sparse-product FMAs, 1: no window work, 2: gates of utterance 0 only)
 #endif
+#ifndef FPC2_GPRIO_PAIR
+#define FPC2_GPRIO_PAIR 3
+#endif
+#ifndef FPC2_GPRIO_SINGLE
+#define FPC2_GPRIO_SINGLE 3
+#endif
+#ifndef FPC2_PRIO3
+#define FPC2_PRIO3 1
+#endif
 #ifndef FPC2_N1
-#define FPC2_N1 13  // column steps (of 32: 16 of utterance 0, then 16 of utterance 1) of the sparse product under GRU_B ...
+#define FPC2_N1 14  // column steps (of 32: 16 of utterance 0, then 16 of utterance 1) of the sparse product under GRU_B ...
 #endif
 #ifndef FPC2_N2
-#define FPC2_N2 8   // ... and under the dual FC; the rest under the draw
+#define FPC2_N2 11  // ... and under the dual FC; the rest under the draw
 #endif
 
 // Field order matters (as in DecodeLds): everything a lane addresses with a lane-constant register plus a constant sits in
@@ -40,7 +51,8 @@ constexpr int PART_HI = 4 * PN;       // planes 4..7
 // address register serves both; the activation table's base (indexed by a computed value) folds likewise.  Behind them
 // the arrays that are addressed through a base register anyway.
 struct __attribute__((aligned(16))) PairStream {
-    float s1[RNN_A];
+    float s1[RNN_A + 4];  // units 192..383 sit 4 floats up (s1_at): GRU_B's sixteen 24-unit slices then start in sixteen
+                          // different bank quads (6 kl + (kl >> 3) mod 16), its reads are conflict-free
     float cfa[GA];
     float s2[RNN_B];
     float hist[16];
@@ -49,6 +61,7 @@ struct __attribute__((aligned(16))) PairStream {
     float4 qq[128];
     float4 cand[256];
 };
+__device__ __forceinline__ constexpr int s1_at(int unit) { return unit + (unit >= RNN_A / 2 ? 4 : 0); }
 struct __attribute__((aligned(16))) PairStreamFar {
     float p[256];
     float uframe[FPC_FRAME_SIZE];
@@ -62,6 +75,7 @@ struct __attribute__((aligned(16))) Decode2Lds {
     float2 tt[FPC_TANH_TABLE_SIZE - 1];
     PairStreamFar F[2];
     float4 fcw[9 * NSAMP];  // dual-FC weights of node = lane: chunk c = (fcw[2c], fcw[2c+1]) of k_decode's register array
+    float4 lw[3 * NMAT];    // the last twelve sparse weights of every mat-vec lane (w2[58..63] of k_decode): see k_decode2
 };
 static_assert(offsetof(Decode2Lds, tt) < 65536, "the activation table's base must fold into a DS offset");
 static_assert(sizeof(Decode2Lds) <= 160 * 1024, "Decode2Lds exceeds the LDS of a CU");
@@ -105,6 +119,57 @@ __device__ __forceinline__ void lut_batch(const float2* T2, const float (&x)[N],
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int k = 0; k < N; ++k) y[k] = copysignf(fmaf(f[k], td[k].y, td[k].x), x[k]);
+}
+
+// A table activation in two halves, so that the two utterances' chains can be skewed by half a step: the wave issues in
+// order, and what hides an LDS round trip is the OTHER utterance's arithmetic placed between the read and its use.
+struct LutReq {
+    float x, f;
+    float2 td;
+};
+__device__ __forceinline__ void lut_issue(const float2* T2, LutReq& q, const float x, const float scale) {
+    const float u = fminf(fabsf(x) * scale, 4095.99976f);
+    q.x = x;
+    q.f = __builtin_amdgcn_fractf(u);
+    q.td = T2[(uint32_t)u];
+}
+__device__ __forceinline__ float lut_finish(const LutReq& q) { return copysignf(fmaf(q.f, q.td.y, q.td.x), q.x); }
+
+// fpc_lin2ulaw_tab (include/fpc_numerics.h) in two halves, for the same reason as LutReq: the table pair of the value's
+// bin is requested, other work runs, the level is finished.  Integer arithmetic on the same bits: the same level.
+struct UlawReq {
+    float x;
+    uint32_t iv;
+    float2 tc;  // (threshold inside the bin, thresholds below the bin)
+};
+__device__ __forceinline__ void ulaw_issue(const float* tab, UlawReq& q, const float x) {
+    q.x = x;
+    q.iv = __float_as_uint(fmaf(255.0f / 32768.0f, fabsf(x), 1.0f));
+    q.tc = reinterpret_cast<const float2*>(tab)[(q.iv >> 18) & 31u];
+}
+__device__ __forceinline__ unsigned ulaw_finish(const UlawReq& q) {
+    const int e = (int)(q.iv >> 23) - 127;
+    const float m = __uint_as_float((q.iv & 0x007fffffu) | 0x3f800000u);
+    int K = 16 * e + (int)q.tc.y + (m >= q.tc.x ? 1 : 0);
+    K = K > 128 ? 128 : K;
+    const int u = q.x < 0.0f ? 128 - K : 128 + K;
+    return (unsigned)(u > 255 ? 255 : u);
+}
+// eight independent row butterflies interleaved (see row_bfly16x6)
+__device__ __forceinline__ void row_bfly16x8(float& a, float& b, float& c, float& d, float& e, float& f, float& g, float& h) {
+#define FPC_B8(CTRL)                                                              \
+    "v_add_f32_dpp %0, %0, %0 " CTRL " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t" \
+    "v_add_f32_dpp %1, %1, %1 " CTRL " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t" \
+    "v_add_f32_dpp %2, %2, %2 " CTRL " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t" \
+    "v_add_f32_dpp %3, %3, %3 " CTRL " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t" \
+    "v_add_f32_dpp %4, %4, %4 " CTRL " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t" \
+    "v_add_f32_dpp %5, %5, %5 " CTRL " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t" \
+    "v_add_f32_dpp %6, %6, %6 " CTRL " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t" \
+    "v_add_f32_dpp %7, %7, %7 " CTRL " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+    asm volatile("s_nop 1\n\t" FPC_B8("quad_perm:[1,0,3,2]") FPC_B8("quad_perm:[2,3,0,1]") FPC_B8("row_half_mirror")
+                     FPC_B8("row_mirror")
+                 : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f), "+v"(g), "+v"(h));
+#undef FPC_B8
 }
 
 // the draw of one utterance by one wave (k_decode's drawing wave): normaliser, tail cut, scan, search, control block
@@ -164,7 +229,7 @@ __global__ __launch_bounds__(NTHREADS) void k_decode2(const DecodeParams P, cons
     for (int s = 0; s < 2; ++s) rec[s] = P.state != nullptr ? P.state + (size_t)bs[s] * STATE_FLOATS : nullptr;
     for (int i = tid; i < RNN_A; i += NTHREADS) {
 #pragma unroll
-        for (int s = 0; s < 2; ++s) L.S[s].s1[i] = resume ? rec[s][i] : 0.0f;
+        for (int s = 0; s < 2; ++s) L.S[s].s1[s1_at(i)] = resume ? rec[s][i] : 0.0f;
         L.brn_a[i] = P.brn_a[i];
     }
     for (int i = tid; i < GA; i += NTHREADS) L.diag[i] = P.diag[i];
@@ -219,28 +284,40 @@ __global__ __launch_bounds__(NTHREADS) void k_decode2(const DecodeParams P, cons
     if (wave >= 4) {
         // =========================== mat-vec role ===========================
         const int ml_ = tid - NSAMP;
-        f2 w2[64];
+        // 116 of the lane's 128 sparse weights live in registers; the last twelve (the pairs 58..63: column 2 of block 3 for
+        // the rows 4..7, column 3 for all rows) are read from LDS once per product -- three ds_read_b128 at a lane-consecutive
+        // address, issued eight columns ahead.  The twelve registers are what lets the gate phase hold both utterances'
+        // table rows and a round of plane reads at once (it ran out of registers otherwise: spills and copy chains)
+        f2 w2[58];
 #pragma unroll
         for (int j = 0; j < 64; ++j) {
             const int bc = j >> 2, rp = j & 3;
             const int bb = bc >> 2, c = bc & 3;
-            w2[j] = mk2(P.lane_w[(bb * 32 + (2 * rp) * 4 + c) * NMAT + ml_],
-                        P.lane_w[(bb * 32 + (2 * rp + 1) * 4 + c) * NMAT + ml_]);
+            const f2 w = mk2(P.lane_w[(bb * 32 + (2 * rp) * 4 + c) * NMAT + ml_],
+                             P.lane_w[(bb * 32 + (2 * rp + 1) * 4 + c) * NMAT + ml_]);
+            if (j < 58)
+                w2[j] = w;
+            else
+                reinterpret_cast<f2*>(&L.lw[((j - 58) >> 1) * NMAT + ml_])[(j - 58) & 1] = w;  // (read back by this lane only)
         }
         const unsigned colp_ = (unsigned)P.lane_meta[ml_];
         const unsigned metap_ = (unsigned)P.lane_meta[NMAT + ml_];
-        const bool gate_lane = ml_ < RNN_A;
-        const unsigned ml_wave0 = (unsigned)__builtin_amdgcn_readfirstlane(ml_ & ~63);  // first lane of this wave (SGPR)
+        // Gate jobs (unit, utterance): waves 4..7 evaluate units 0..255 of BOTH utterances (lane = unit), waves 8, 9 units
+        // 256..383 of utterance 0, waves 10, 11 the same units of utterance 1 -- every SIMD then carries three jobs beside
+        // its sampler wave (with all 768 jobs on waves 4..9, SIMDs 0 and 1 carried four, SIMDs 2 and 3 two)
+        const int gu_ = wave < 10 ? ml_ : ml_ - 128;  // the unit of this lane's gate job(s)
+        const unsigned gu_wave0 = (unsigned)__builtin_amdgcn_readfirstlane(gu_ & ~63);  // first unit of this wave (SGPR)
+        const unsigned s1_pad = gu_wave0 >= RNN_A / 2 ? 4u : 0u;  // (s1_at of this wave's units: wave-uniform, 192 = 3 waves)
         typedef __attribute__((address_space(3))) float lds_float;
         // where this lane's 8 partial row sums of utterance 0 go (utterance 1: + sizeof(PairStreamFar)); 0 = no group
         unsigned paddr_ = 0u;
         if ((metap_ >> 16) != 0) {
             const int grp = (int)(metap_ >> 16) - 1;
             const int gate = grp / (RNN_A / 8), rb = grp - gate * (RNN_A / 8);
-            const int q = (int)(metap_ & 0xff);
-            float* dst = q < 4 ? &L.F[0].part[q * PSTRIDE + gate * RNN_A + rb * 8]
-                               : &L.F[0].part[PART_LO + (q - 4) * PN + rb * 8];  // (q >= 4: candidate gate only)
-            paddr_ = (unsigned)(size_t)(lds_float*)dst;
+            const int q = (int)(metap_ & 0xff), pq = q >> 1;  // lane q of the group; its pair's plane
+            float* dst = pq < 2 ? &L.F[0].part[pq * PSTRIDE + gate * RNN_A + rb * 8]
+                                : &L.F[0].part[PART_LO + (pq - 2) * PN + rb * 8];  // (planes 2, 3: candidate gate only)
+            if ((q & 1) == 0) paddr_ = (unsigned)(size_t)(lds_float*)dst;  // (the odd lane's sums go out through its neighbour)
         }
         paddr_ = opaque(paddr_);
 
@@ -263,15 +340,24 @@ __global__ __launch_bounds__(NTHREADS) void k_decode2(const DecodeParams P, cons
             const float4 hd = *reinterpret_cast<const float4*>(&L.S[s].s1[(colp >> 24) * 4]);                     \
             hv1[0] = hc.x, hv1[1] = hc.y, hv1[2] = hc.z, hv1[3] = hc.w;                                           \
             hv1[4] = hd.x, hv1[5] = hd.y, hv1[6] = hd.z, hv1[7] = hd.w;                                           \
+            const unsigned mlx = opaque((unsigned)ml_);                                                           \
+            const float4 l0 = L.lw[mlx], l1 = L.lw[NMAT + mlx], l2 = L.lw[2 * NMAT + mlx];                        \
+            wl[0] = mk2(l0.x, l0.y), wl[1] = mk2(l0.z, l0.w), wl[2] = mk2(l1.x, l1.y);                            \
+            wl[3] = mk2(l1.z, l1.w), wl[4] = mk2(l2.x, l2.y), wl[5] = mk2(l2.z, l2.w);                            \
         }                                                                                                         \
         _Pragma("unroll") for (int rp = 0; rp < (FPC2_ABL & 1 ? 0 : 4); ++rp) {                                   \
             if (bc < 8)                                                                                           \
                 acc[rp] = fma2(w2[bc * 4 + rp], splat2(hv0[bc]), acc[rp]);                                        \
             else                                                                                                  \
-                a[rp] = fma2(w2[bc * 4 + rp], splat2(hv1[bc - 8]), a[rp]);                                        \
+                a[rp] = fma2(bc * 4 + rp < 58 ? w2[bc * 4 + rp < 58 ? bc * 4 + rp : 0] : wl[bc * 4 + rp - 58],        \
+                             splat2(hv1[bc - 8]), a[rp]);                                                         \
         }                                                                                                         \
         if (bc == 15) {                                                                                           \
-            _Pragma("unroll") for (int rp = 0; rp < 4; ++rp) acc[rp] = acc[rp] + a[rp];                           \
+            _Pragma("unroll") for (int rp = 0; rp < 4; ++rp) {                                                    \
+                acc[rp] = acc[rp] + a[rp];                                                                        \
+                acc[rp].x = acc[rp].x + dpp_f<DPP_ROW_SHL + 1>(acc[rp].x); /* + the next lane's: tree level 1 */  \
+                acc[rp].y = acc[rp].y + dpp_f<DPP_ROW_SHL + 1>(acc[rp].y);                                        \
+            }                                                                                                     \
             if (paddr_ != 0u) {                                                                                   \
                 typedef float v4f __attribute__((ext_vector_type(4)));                                            \
                 typedef __attribute__((address_space(3))) v4f lds_v4f;                                            \
@@ -290,7 +376,7 @@ __global__ __launch_bounds__(NTHREADS) void k_decode2(const DecodeParams P, cons
     }
         if (P.state != nullptr) {
             if (resume) {  // the sparse products of the states the chunk starts from
-                f2 acc[4], a[4];
+                f2 acc[4], a[4], wl[6];
                 float hv0[8], hv1[8];
                 FPC2_STEPS(0, 32)
             }
@@ -300,28 +386,73 @@ __global__ __launch_bounds__(NTHREADS) void k_decode2(const DecodeParams P, cons
             const bool voiced =
                 fpc_shape_exponent(P.features[((size_t)bs[0] * T + fr) * FPC_NB_FEATURES + 19]) > 0.0f ||
                 fpc_shape_exponent(P.features[((size_t)bs[1] * T + fr) * FPC_NB_FEATURES + 19]) > 0.0f;
-            if (gate_lane) {
+            // this frame's conditioning rows of the unit(s) whose gates this lane evaluates: written and read by the same lane
 #pragma unroll
-                for (int s = 0; s < 2; ++s) {
+            for (int s = 0; s < 2; ++s) {
+                if (wave < 8 || (wave >= 10) == (s == 1)) {
                     const float* cfa = P.cfa + ((size_t)bs[s] * P.cf_T + (fr - P.f0)) * GA;
-                    L.S[s].cfa[ml_] = cfa[ml_];
-                    L.S[s].cfa[RNN_A + ml_] = cfa[RNN_A + ml_];
-                    L.S[s].cfa[2 * RNN_A + ml_] = cfa[2 * RNN_A + ml_];
+                    L.S[s].cfa[gu_] = cfa[gu_];
+                    L.S[s].cfa[RNN_A + gu_] = cfa[RNN_A + gu_];
+                    L.S[s].cfa[2 * RNN_A + gu_] = cfa[2 * RNN_A + gu_];
                 }
             }
             for (int i = (fr == 0 ? FPC_LPC_ORDER + 1 : 0); i < FPC_FRAME_SIZE; ++i) {
                 const int st_t = fr * FPC_FRAME_SIZE + i;
                 const bool stamp_on = STAMP && blockIdx.x == 0 && st_t >= FPC_STAMP_T0 && st_t < FPC_STAMP_T0 + FPC_STAMP_NS;
                 // ---- X..Y: both utterances' table rows gathered together, gates of both ----
-#if FPC_PRIO
-                __builtin_amdgcn_s_setprio(FPC_PRIO);
-#endif
-                if (gate_lane) {
-                    const unsigned ml = lane_index_here() + ml_wave0;
-                    struct F3 {
-                        float x, y, z;
-                    };
-                    const char* tabc = reinterpret_cast<const char*>(P.tab);
+                // (both gate paths are on the sample-to-sample chain; the one-utterance path is the shorter one)
+                if (wave >= 8)
+                    __builtin_amdgcn_s_setprio(FPC2_GPRIO_SINGLE);
+                else
+                    __builtin_amdgcn_s_setprio(FPC2_GPRIO_PAIR);
+                struct F3 {
+                    float x, y, z;
+                };
+                const char* tabc = reinterpret_cast<const char*>(P.tab);
+                if (wave >= 8) {
+                    // one utterance's gates of unit ml (k_decode's gate phase on the pair planes)
+                    const unsigned ml = lane_index_here() + gu_wave0;
+                    PairStream& S = L.S[wave >= 10 ? 1 : 0];
+                    const float* pl = &L.F[wave >= 10 ? 1 : 0].part[ml];
+                    const unsigned oa = S.o_sig, ob = S.o_pred, oc = S.o_exc;
+                    const F3 ta = *reinterpret_cast<const F3*>(tabc + (size_t)((oa + 3u * ml) * 4u));
+                    const F3 tb = *reinterpret_cast<const F3*>(tabc + (size_t)((ob + 3u * ml) * 4u));
+                    const F3 tc = *reinterpret_cast<const F3*>(tabc + (size_t)((oc + 3u * ml) * 4u));
+                    __builtin_amdgcn_sched_barrier(0);
+                    const float h_own = S.s1[ml + 4];  // (units 256..383: s1_at = + 4)
+                    float unb, uz, ur;
+                    {
+                        const float dn = L.diag[2 * RNN_A + ml], bn = L.brn_a[ml];
+                        const float n0 = pl[2 * RNN_A], n1 = pl[2 * RNN_A + PSTRIDE], n2 = pl[PART_LO], n3 = pl[PART_LO + PN];
+                        const float dz = L.diag[ml], dr = L.diag[RNN_A + ml];
+                        const float z0 = pl[0], r0 = pl[RNN_A];
+                        float tz = z0, tr = r0;
+                        if (QZR == 4) {
+                            const float z1 = pl[PSTRIDE], r1 = pl[RNN_A + PSTRIDE];
+                            __builtin_amdgcn_sched_barrier(0);
+                            tz = z0 + z1;
+                            tr = r0 + r1;
+                        } else {
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                        unb = fmaf(dn, h_own, (n0 + n1) + (n2 + n3)) + bn;
+                        uz = fmaf(dz, h_own, tz);
+                        ur = fmaf(dr, h_own, tr);
+                    }
+                    const float cz = S.cfa[ml], cr = S.cfa[RNN_A + ml], cn = S.cfa[2 * RNN_A + ml];
+                    __builtin_amdgcn_sched_barrier(0);
+                    LutReq qz, qr, qn;
+                    lut_issue(L.tt, qz, (((ta.x + tb.x) + tc.x) + cz) + uz, 256.0f);
+                    lut_issue(L.tt, qr, (((ta.y + tb.y) + tc.y) + cr) + ur, 256.0f);
+                    const float gn = ((ta.z + tb.z) + tc.z) + cn;
+                    __builtin_amdgcn_sched_barrier(0);
+                    const float z = fmaf(0.5f, lut_finish(qz), 0.5f);
+                    lut_issue(L.tt, qn, fmaf(fmaf(0.5f, lut_finish(qr), 0.5f), unb, gn), 512.0f);
+                    __builtin_amdgcn_sched_barrier(0);
+                    const float n = lut_finish(qn);
+                    S.s1[ml + 4] = fmaf(z, h_own - n, n);
+                } else {
+                    const unsigned ml = lane_index_here() + gu_wave0;
                     F3 ta[2], tb[2], tc[2];
 #pragma unroll
                     for (int s = 0; s < (FPC2_ABL & 4 ? 1 : 2); ++s) {
@@ -331,76 +462,60 @@ __global__ __launch_bounds__(NTHREADS) void k_decode2(const DecodeParams P, cons
                         tc[s] = *reinterpret_cast<const F3*>(tabc + (size_t)((oc + 3u * ml) * 4u));
                     }
                     __builtin_amdgcn_sched_barrier(0);
-                    // while the six rows are in flight: recurrent terms of the unit's three rows, utterance by utterance,
-                    // eight plane reads per LDS round trip
-                    float unb[2], uz[2], ur[2];
+                    // while the six rows are in flight: recurrent terms of the unit's three rows (diagonal + the upper levels of
+                    // the tree over the pair planes).  The diagonal / bias values once for both utterances; each utterance's
+                    // state value and eight plane values as one round of reads, the second requested before the first is used
+                    const float dz = L.diag[ml], dr = L.diag[RNN_A + ml], dn = L.diag[2 * RNN_A + ml], bn = L.brn_a[ml];
+                    float h_own[2], cz[2], cr[2], cn[2], unb[2], uz[2], ur[2];
 #pragma unroll
                     for (int s = 0; s < (FPC2_ABL & 4 ? 1 : 2); ++s) {
                         const float* pl = &L.F[s].part[ml];
-                        {
-                            const float p0 = pl[2 * RNN_A], p1 = pl[2 * RNN_A + PSTRIDE], p2 = pl[2 * RNN_A + 2 * PSTRIDE],
-                                        p3 = pl[2 * RNN_A + 3 * PSTRIDE];
-                            __builtin_amdgcn_sched_barrier(0);
-                            const float lo4 = (p0 + p1) + (p2 + p3);
-                            const float p4 = pl[PART_LO], p5 = pl[PART_LO + PN], p6 = pl[PART_LO + 2 * PN],
-                                        p7 = pl[PART_LO + 3 * PN];
-                            __builtin_amdgcn_sched_barrier(0);
-                            const float hi4 = (p4 + p5) + (p6 + p7);
-                            const float h_own = L.S[s].s1[ml], dn = L.diag[2 * RNN_A + ml], bn = L.brn_a[ml];
-                            __builtin_amdgcn_sched_barrier(0);
-                            unb[s] = fmaf(dn, h_own, lo4 + hi4) + bn;
-                        }
-                        {
-                            float tz, tr;
-                            const float h_own = L.S[s].s1[ml], dz = L.diag[ml], dr = L.diag[RNN_A + ml];
-                            if (QZR == 4) {
-                                const float z0 = pl[0], z1 = pl[PSTRIDE], z2 = pl[2 * PSTRIDE], z3 = pl[3 * PSTRIDE];
-                                __builtin_amdgcn_sched_barrier(0);
-                                tz = (z0 + z1) + (z2 + z3);
-                                const float r0 = pl[RNN_A], r1 = pl[RNN_A + PSTRIDE], r2 = pl[RNN_A + 2 * PSTRIDE],
-                                            r3 = pl[RNN_A + 3 * PSTRIDE];
-                                __builtin_amdgcn_sched_barrier(0);
-                                tr = (r0 + r1) + (r2 + r3);
-                            } else {
-                                const float z0 = pl[0], z1 = pl[PSTRIDE];
-                                const float r0 = pl[RNN_A], r1 = pl[RNN_A + PSTRIDE];
-                                __builtin_amdgcn_sched_barrier(0);
-                                tz = z0 + z1;
-                                tr = r0 + r1;
-                            }
-                            uz[s] = fmaf(dz, h_own, tz);
-                            ur[s] = fmaf(dr, h_own, tr);
-                        }
+                        float pz[2], pr[2], pn[4];
+                        h_own[s] = L.S[s].s1[ml + s1_pad];
+                        pn[0] = pl[2 * RNN_A], pn[1] = pl[2 * RNN_A + PSTRIDE], pn[2] = pl[PART_LO], pn[3] = pl[PART_LO + PN];
+                        pz[0] = pl[0], pr[0] = pl[RNN_A];
+                        if (QZR == 4) pz[1] = pl[PSTRIDE], pr[1] = pl[RNN_A + PSTRIDE];
+                        __builtin_amdgcn_sched_barrier(0);
+                        unb[s] = fmaf(dn, h_own[s], (pn[0] + pn[1]) + (pn[2] + pn[3])) + bn;
+                        uz[s] = fmaf(dz, h_own[s], QZR == 4 ? pz[0] + pz[1] : pz[0]);
+                        ur[s] = fmaf(dr, h_own[s], QZR == 4 ? pr[0] + pr[1] : pr[0]);
+                        cz[s] = L.S[s].cfa[ml], cr[s] = L.S[s].cfa[RNN_A + ml], cn[s] = L.S[s].cfa[2 * RNN_A + ml];
                         __builtin_amdgcn_sched_barrier(0);
                     }
-                    float xs[4];
+                    // gates: utterance 1 half a step behind utterance 0 (its arithmetic hides the other's table read)
+                    LutReq qz[2], qr[2], qn[2];
+                    float gn[2];
 #pragma unroll
                     for (int s = 0; s < (FPC2_ABL & 4 ? 1 : 2); ++s) {
-                        const float cz = L.S[s].cfa[ml], cr = L.S[s].cfa[RNN_A + ml];
-                        xs[2 * s] = (((ta[s].x + tb[s].x) + tc[s].x) + cz) + uz[s];
-                        xs[2 * s + 1] = (((ta[s].y + tb[s].y) + tc[s].y) + cr) + ur[s];
+                        lut_issue(L.tt, qz[s], (((ta[s].x + tb[s].x) + tc[s].x) + cz[s]) + uz[s], 256.0f);
+                        lut_issue(L.tt, qr[s], (((ta[s].y + tb[s].y) + tc[s].y) + cr[s]) + ur[s], 256.0f);
+                        gn[s] = ((ta[s].z + tb[s].z) + tc[s].z) + cn[s];
+                        __builtin_amdgcn_sched_barrier(0);
                     }
-                    float zr[4];
-                    lut_batch<4>(L.tt, xs, 256.0f, zr);
-                    float xn[2];
+                    float zg[2];
 #pragma unroll
                     for (int s = 0; s < (FPC2_ABL & 4 ? 1 : 2); ++s) {
-                        const float gn = ((ta[s].z + tb[s].z) + tc[s].z) + L.S[s].cfa[2 * RNN_A + ml];
-                        xn[s] = fmaf(fmaf(0.5f, zr[2 * s + 1], 0.5f), unb[s], gn);
+                        zg[s] = fmaf(0.5f, lut_finish(qz[s]), 0.5f);
+                        lut_issue(L.tt, qn[s], fmaf(fmaf(0.5f, lut_finish(qr[s]), 0.5f), unb[s], gn[s]), 512.0f);
+                        __builtin_amdgcn_sched_barrier(0);
                     }
-                    float nn[2];
-                    lut_batch<2>(L.tt, xn, 512.0f, nn);
 #pragma unroll
                     for (int s = 0; s < (FPC2_ABL & 4 ? 1 : 2); ++s) {
-                        const float h_own = L.S[s].s1[ml];
-                        L.S[s].s1[ml] = fmaf(fmaf(0.5f, zr[2 * s], 0.5f), h_own - nn[s], nn[s]);
+                        const float n = lut_finish(qn[s]);
+                        L.S[s].s1[ml + s1_pad] = fmaf(zg[s], h_own[s] - n, n);
+                        __builtin_amdgcn_sched_barrier(0);
                     }
                 }
 #if FPC_PRIO
-                __builtin_amdgcn_s_setprio(0);
+                // the third wave of each SIMD (8..11) would get what the sampler wave and the second wave leave over:
+                // its product steps end each phase last.  One priority step above the second wave evens them out
+                if (FPC2_PRIO3 && wave >= 8)
+                    __builtin_amdgcn_s_setprio(FPC2_PRIO3);
+                else
+                    __builtin_amdgcn_s_setprio(0);
 #endif
                 FPC_BARRIER(0)  // Y
-                f2 acc[4], a[4];
+                f2 acc[4], a[4], wl[6];
                 float hv0[8], hv1[8];
                 FPC2_STEPS(0, FPC2_N1)
                 FPC_BARRIER(1)  // Z1
@@ -414,11 +529,9 @@ __global__ __launch_bounds__(NTHREADS) void k_decode2(const DecodeParams P, cons
             }
         }
 #undef FPC2_STEPS
-        if (gate_lane) {
 #pragma unroll
-            for (int s = 0; s < 2; ++s)
-                if (rec[s] != nullptr) rec[s][ml_] = L.S[s].s1[ml_];
-        }
+        for (int s = 0; s < 2; ++s)  // (the carried state: by the lanes that hold the gate jobs)
+            if (rec[s] != nullptr && (wave < 8 || (wave >= 10) == (s == 1))) rec[s][gu_] = L.S[s].s1[s1_at(gu_)];
     } else {
         // =========================== sampler role ===========================
         __builtin_amdgcn_s_setprio(3);
@@ -469,28 +582,56 @@ __global__ __launch_bounds__(NTHREADS) void k_decode2(const DecodeParams P, cons
 #if FPC_PRIO
                 __builtin_amdgcn_s_setprio(0);
 #endif
-                // ---- X..Y: GRU_B recurrent parts, LPC taps, leaf candidates of both utterances ----
+                // ---- X..Y: GRU_B recurrent parts, LPC taps, leaf candidates of both utterances: one round of state reads,
+                //      one eight-way butterfly (GRU_B's three recurrent sums and the tap tree, per utterance), the four
+                //      mu-law levels requested together ----
                 float ub_z[2], ub_r[2], ub_n[2];
+#if !(FPC2_ABL & 2)
+                {
+                    const bool lastsmp = i == FPC_FRAME_SIZE - 1;
+                    float s2k[2], hk[2], prd[2], tap[2];
+#pragma unroll
+                    for (int s = 0; s < 2; ++s) {
+                        s2k[s] = L.S[s].s2[kl];
+                        hk[s] = L.S[s].hist[(t - kl) & 15];
+                        prd[s] = L.S[s].pred;
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int s = 0; s < 2; ++s) {
+                        ub_z[s] = ub0 * s2k[s], ub_r[s] = ub1 * s2k[s], ub_n[s] = ub2 * s2k[s];
+                        const float am = lastsmp ? a_nxt[s] : a_cur[s];
+                        tap[s] = kl ? am * hk[s] : 0.0f;
+                    }
+                    row_bfly16x8(ub_z[0], ub_r[0], ub_n[0], tap[0], ub_z[1], ub_r[1], ub_n[1], tap[1]);
+                    float cpcm[2], cpred[2];
+                    UlawReq qs[2], qp[2];
+#pragma unroll
+                    for (int s = 0; s < 2; ++s) {
+                        const float a0 = lastsmp ? a0_nxt[s] : a0_cur[s];
+                        cpcm[s] = prd[s] + my_ulaw;
+                        cpred[s] = -fmaf(a0, cpcm[s], tap[s]);
+                        ulaw_issue(L.ulaw_thr, qs[s], cpcm[s]);
+                        ulaw_issue(L.ulaw_thr, qp[s], cpred[s]);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+#pragma unroll
+                    for (int s = 0; s < 2; ++s) {
+                        const unsigned es = ulaw_finish(qs[s]);
+                        const unsigned ep = 256u + ulaw_finish(qp[s]);
+                        L.S[s].cand[sl] = make_float4(cpcm[s], cpred[s], __uint_as_float((es << 10) + (es << 7)),
+                                                      __uint_as_float((ep << 10) + (ep << 7)));
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+#else
 #pragma unroll
                 for (int s = 0; s < 2; ++s) {
                     const float s2k = L.S[s].s2[kl];
                     ub_z[s] = ub0 * s2k, ub_r[s] = ub1 * s2k, ub_n[s] = ub2 * s2k;
                 }
                 row_bfly16x6(ub_z[0], ub_r[0], ub_n[0], ub_z[1], ub_r[1], ub_n[1]);
-#pragma unroll
-                for (int s = 0; s < (FPC2_ABL & 2 ? 0 : 2); ++s) {
-                    const bool lastsmp = i == FPC_FRAME_SIZE - 1;
-                    const float am = lastsmp ? a_nxt[s] : a_cur[s];
-                    const float a0 = lastsmp ? a0_nxt[s] : a0_cur[s];
-                    const float hk = L.S[s].hist[(t - kl) & 15];
-                    const float part = row_bfly16(kl ? am * hk : 0.0f);
-                    const float cpcm = L.S[s].pred + my_ulaw;
-                    const float cpred = -fmaf(a0, cpcm, part);
-                    const unsigned es = (unsigned)fpc_lin2ulaw_tab(cpcm, L.ulaw_thr);
-                    const unsigned ep = 256u + (unsigned)fpc_lin2ulaw_tab(cpred, L.ulaw_thr);
-                    L.S[s].cand[sl] = make_float4(cpcm, cpred, __uint_as_float((es << 10) + (es << 7)),
-                                                  __uint_as_float((ep << 10) + (ep << 7)));
-                }
+#endif
 #if FPC2_ABL & 2
                 L.S[0].cand[sl] = L.S[1].cand[sl] = make_float4(0.0f, 0.0f, __uint_as_float(128u * GA), __uint_as_float(384u * GA));
 #endif
@@ -499,6 +640,11 @@ __global__ __launch_bounds__(NTHREADS) void k_decode2(const DecodeParams P, cons
 #endif
                 FPC_BARRIER(0)  // Y
                 // ---- Y..Z1: GRU_B of both utterances (one weight register feeds two chains) ----
+                const unsigned slv = opaque((unsigned)sl);
+                float4 wa[2], wb[2], bf;  // dual-FC weight chunks in flight (loaded from the end of this phase on)
+#define FPC2_FC_LOADW(k4)                                                                \
+    wa[(k4) & 1] = L.fcw[(2 * (k4)) * NSAMP + slv];                                      \
+    wb[(k4) & 1] = L.fcw[(2 * (k4) + 1) * NSAMP + slv];
                 {
                     const unsigned klv = (unsigned)kl;
                     f2 acc[2][3][2];
@@ -507,10 +653,10 @@ __global__ __launch_bounds__(NTHREADS) void k_decode2(const DecodeParams P, cons
 #pragma unroll
                         for (int g = 0; g < 3; ++g) acc[s][g][0] = acc[s][g][1] = splat2(0.0f);
 #pragma unroll
-                    for (int m = 0; m < 6; ++m) {
+                    for (int m = 0; m < (FPC2_ABL & 8 ? 0 : 6); ++m) {
 #pragma unroll
                         for (int s = 0; s < 2; ++s) {
-                            const float4 h4 = *reinterpret_cast<const float4*>(&L.S[s].s1[24 * klv + 4 * m]);
+                            const float4 h4 = *reinterpret_cast<const float4*>(&L.S[s].s1[24 * klv + 4 * (klv >> 3) + 4 * m]);
 #pragma unroll
                             for (int g = 0; g < 3; ++g) {
                                 acc[s][g][0] = fma2(wB[g][m][0], mk2(h4.x, h4.y), acc[s][g][0]);
@@ -526,49 +672,59 @@ __global__ __launch_bounds__(NTHREADS) void k_decode2(const DecodeParams P, cons
                             const f2 pr = acc[s][g][0] + acc[s][g][1];
                             a3[s][g] = pr.x + pr.y;
                         }
-                    row_bfly16x6(a3[0][0], a3[0][1], a3[0][2], a3[1][0], a3[1][1], a3[1][2]);
-                    {
-                        // gates of both utterances: the four sigmoids in one LDS round trip, the two tanh in a second
-                        const float xs[4] = {(a3[0][0] + cfb_z[0]) + ub_z[0], (a3[0][1] + cfb_r[0]) + ub_r[0],
-                                             (a3[1][0] + cfb_z[1]) + ub_z[1], (a3[1][1] + cfb_r[1]) + ub_r[1]};
-                        float zr[4];
-                        lut_batch<4>(L.tt, xs, 256.0f, zr);
-                        const float xn[2] = {fmaf(fmaf(0.5f, zr[1], 0.5f), ub_n[0] + brnb, a3[0][2] + cfb_n[0]),
-                                             fmaf(fmaf(0.5f, zr[3], 0.5f), ub_n[1] + brnb, a3[1][2] + cfb_n[1])};
-                        float nn[2];
-                        lut_batch<2>(L.tt, xn, 512.0f, nn);
+                    if (!(FPC2_ABL & 16)) row_bfly16x6(a3[0][0], a3[0][1], a3[0][2], a3[1][0], a3[1][1], a3[1][2]);
+                    // the accumulators are dead: the dual FC's first weight chunks (they depend on nothing) start their way
+                    // from LDS here, under the gates and the barrier
+                    FPC2_FC_LOADW(0)
+                    FPC2_FC_LOADW(1)
+                    bf = L.fcw[8 * NSAMP + slv];
+                    // gates, utterance 1 half a step behind utterance 0
+                    LutReq qz[2], qr[2], qn[2];
+#if FPC2_ABL & 32
 #pragma unroll
-                        for (int s = 0; s < 2; ++s) {
-                            const float z = fmaf(0.5f, zr[2 * s], 0.5f);
-                            s2_own[s] = fmaf(z, s2_own[s] - nn[s], nn[s]);
-                        }
-                        if (kl == 0) {
-                            L.S[0].s2[u] = s2_own[0];
-                            L.S[1].s2[u] = s2_own[1];
-                        }
+                    for (int s = 0; s < 2; ++s) {
+                        const float z = 0.5f + 1e-3f * a3[s][0], n = 1e-3f * (a3[s][1] + a3[s][2]);
+                        s2_own[s] = fmaf(z, s2_own[s] - n, n);
+                        if (kl == 0) L.S[s].s2[u] = s2_own[s];
                     }
+#else
+                    lut_issue(L.tt, qz[0], (a3[0][0] + cfb_z[0]) + ub_z[0], 256.0f);
+                    lut_issue(L.tt, qr[0], (a3[0][1] + cfb_r[0]) + ub_r[0], 256.0f);
+                    __builtin_amdgcn_sched_barrier(0);
+                    lut_issue(L.tt, qz[1], (a3[1][0] + cfb_z[1]) + ub_z[1], 256.0f);
+                    lut_issue(L.tt, qr[1], (a3[1][1] + cfb_r[1]) + ub_r[1], 256.0f);
+                    __builtin_amdgcn_sched_barrier(0);
+                    float zg[2];
+#pragma unroll
+                    for (int s = 0; s < 2; ++s) {
+                        zg[s] = fmaf(0.5f, lut_finish(qz[s]), 0.5f);
+                        const float r = fmaf(0.5f, lut_finish(qr[s]), 0.5f);
+                        lut_issue(L.tt, qn[s], fmaf(r, ub_n[s] + brnb, a3[s][2] + cfb_n[s]), 512.0f);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+#pragma unroll
+                    for (int s = 0; s < 2; ++s) {
+                        const float n = lut_finish(qn[s]);
+                        s2_own[s] = fmaf(zg[s], s2_own[s] - n, n);
+                        if (kl == 0) L.S[s].s2[u] = s2_own[s];
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+#endif
                 }
                 FPC_BARRIER(1)  // Z1
-                // ---- Z1..Z2: dual FC of tree node `sl`, both utterances; weights from LDS, read once, a stage
-                //      (two weight chunks + four state values per utterance) ahead of the products ----
+                // ---- Z1..Z2: dual FC of tree node `sl`, both utterances; weights from LDS, read once, two chunks ahead ----
                 {
-                    const unsigned slv = opaque((unsigned)sl);
-                    float4 wa[2], wb[2], sv[2][2];
-#define FPC2_FC_LOAD(k4)                                                                 \
-    wa[(k4) & 1] = L.fcw[(2 * (k4)) * NSAMP + slv];                                      \
-    wb[(k4) & 1] = L.fcw[(2 * (k4) + 1) * NSAMP + slv];                                  \
+                    float4 sv[2][2];
+#define FPC2_FC_LOADS(k4)                                                                \
     sv[(k4) & 1][0] = *reinterpret_cast<const float4*>(&L.S[0].s2[4 * (k4)]);            \
     sv[(k4) & 1][1] = *reinterpret_cast<const float4*>(&L.S[1].s2[4 * (k4)]);
-                    const float4 bf = L.fcw[8 * NSAMP + slv];  // (bias pair, factor pair)
-                    FPC2_FC_LOAD(0)
+                    FPC2_FC_LOADS(0)
+                    FPC2_FC_LOADS(1)
                     f2 a01[2], b01[2];
 #pragma unroll
                     for (int s = 0; s < 2; ++s) a01[s] = mk2(bf.x, bf.y), b01[s] = splat2(0.0f);
 #pragma unroll
                     for (int k4 = 0; k4 < 4; ++k4) {
-                        if (k4 < 3) {
-                            FPC2_FC_LOAD(k4 + 1)
-                        }
                         __builtin_amdgcn_sched_barrier(0);
                         const float4 w0 = wa[k4 & 1], w1 = wb[k4 & 1];
 #pragma unroll
@@ -580,23 +736,35 @@ __global__ __launch_bounds__(NTHREADS) void k_decode2(const DecodeParams P, cons
                             b01[s] = fma2(mk2(w1.z, w1.w), splat2(v.w), b01[s]);
                         }
                         __builtin_amdgcn_sched_barrier(0);
-                    }
-#undef FPC2_FC_LOAD
-                    {
-                        const f2 c0 = a01[0] + b01[0], c1 = a01[1] + b01[1];
-                        const float xt[4] = {c0.x, c0.y, c1.x, c1.y};
-                        float t4[4];
-                        lut_batch<4>(L.tt, xt, 512.0f, t4);
-                        const float xv[2] = {fmaf(bf.w, t4[1], bf.z * t4[0]), fmaf(bf.w, t4[3], bf.z * t4[2])};
-                        float qs[2];
-                        lut_batch<2>(L.tt, xv, 256.0f, qs);
-#pragma unroll
-                        for (int s = 0; s < 2; ++s) {
-                            const float qv = fmaf(0.5f, qs[s], 0.5f);
-                            reinterpret_cast<float2*>(L.S[s].qq)[slv] = make_float2(1.0f - qv, qv);
+                        if (k4 < 2) {  // (the buffers just consumed take the chunks two steps ahead)
+                            FPC2_FC_LOADW(k4 + 2)
+                            FPC2_FC_LOADS(k4 + 2)
                         }
                     }
+#undef FPC2_FC_LOADS
+                    // tanh of both channels, factor sum, sigmoid: utterance 1 half a step behind utterance 0
+                    LutReq q0[2], q1[2], qq[2];
+#pragma unroll
+                    for (int s = 0; s < 2; ++s) {
+                        const f2 c = a01[s] + b01[s];
+                        lut_issue(L.tt, q0[s], c.x, 512.0f);
+                        lut_issue(L.tt, q1[s], c.y, 512.0f);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+#pragma unroll
+                    for (int s = 0; s < 2; ++s) {
+                        const float t0 = lut_finish(q0[s]), t1 = lut_finish(q1[s]);
+                        lut_issue(L.tt, qq[s], fmaf(bf.w, t1, bf.z * t0), 256.0f);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+#pragma unroll
+                    for (int s = 0; s < 2; ++s) {
+                        const float qv = fmaf(0.5f, lut_finish(qq[s]), 0.5f);
+                        reinterpret_cast<float2*>(L.S[s].qq)[slv] = make_float2(1.0f - qv, qv);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
                 }
+#undef FPC2_FC_LOADW
                 const float uf = L.F[dw].uframe[i];
                 FPC_BARRIER(2)  // Z2
                 // ---- voiced frames: leaf probability + sharpening on all 256 lanes, per voiced utterance ----
