@@ -143,6 +143,39 @@ def decode_kernel_hash():
     return h.hexdigest()
 
 
+def decode2_kernel_hash():
+    """the same for k_decode2 (two utterances per workgroup: lpcnet_decode2.h on top of k_decode's helpers)"""
+    import hashlib
+    h = hashlib.sha256()
+    for rel in ("lpcnet_decode.h", "lpcnet_decode2.h", "lpcnet.hip"):
+        with open(os.path.join(ROOT, "feature-predictor-for-speech-codec_amd", "csrc", rel), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()
+
+
+def predictor_kernel_hash():
+    import hashlib
+    h = hashlib.sha256()
+    for rel in ("predictor.hip", "predictor_ws.h", "predictor_wsd.h", "predictor_df.h"):
+        with open(os.path.join(ROOT, "feature-predictor-for-speech-codec_amd", "csrc", rel), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()
+
+
+def counters_record(kernel, khash):
+    """occupancy / issue shares of a kernel from the committed SQ-counter passes (profiles/*_counters.json, written by
+    tools/counters_round.py from separate rocprofv3 --pmc passes): only a record taken on THESE sources is quoted"""
+    pdir = os.path.join(ROOT, "profiles")
+    for name in sorted((n for n in os.listdir(pdir) if n.endswith("_counters.json")), reverse=True):
+        try:
+            rec = json.load(open(os.path.join(pdir, name))).get(kernel)
+        except Exception:
+            continue
+        if rec and rec.get("kernel_source_sha256") == khash:
+            return dict(rec, source=f"profiles/{name}")
+    return None
+
+
 def _pci_bus_id(dev):
     try:
         import ctypes
@@ -198,31 +231,79 @@ def e2e_config5(voc, torch, synth, parallel, rank, world, L=300):
     voc.synthesize(feats, seeds, out=pcm)
     torch.cuda.synchronize()
     t2 = time.perf_counter()
-    # ---- the same share as a pipeline: the encoder of batch k + 1 on a side stream while the vocoder decodes batch k.  The
-    # decode holds half of every XCD for its 65 ms, so the encoder's groups cannot become resident: each decides for the
-    # row-split fallback (fpcodec.h "Kernel forms": a busy GPU costs speed, never a timeout) and still hides behind the decode.
+    # ---- the one-GPU THROUGHPUT form of the same path: a 128-utterance batch fills the chip for the encoder (8 groups of 16
+    # utterances x 32 workgroups) but only half of it for the vocoder (128 of 256 CUs), and k_decode costs the same 65 ms for
+    # 256 streams as for 128.  So: encode two batches back to back, decode both in ONE 256-stream launch.
+    nm2 = np.zeros((B, L, 36), np.float32)
+    nm2[:, :, :20] = synth.predictor_features(B, L, utt0=9000 + lo)
+    nm2_d = torch.from_numpy(nm2).cuda()
+    seeds2 = torch.from_numpy(synth.seeds(B, utt0=9000 + lo).astype(np.int64)).cuda()
+    pcm2 = torch.empty(2 * B, L * 160, dtype=torch.int16, device="cuda")
+    sd2 = torch.cat([seeds, seeds2])
+
+    def two_batches():
+        fa = encode_features(model, cfg, nm_d)[0]
+        fb_ = encode_features(model, cfg, nm2_d)[0]
+        voc.synthesize(torch.cat([fa, fb_]), sd2, out=pcm2)
+        return fa
+    two_batches()
+    torch.cuda.synchronize()
+    tq0 = time.perf_counter()
+    fa = two_batches()
+    torch.cuda.synchronize()
+    tq1 = time.perf_counter()
+    pair_ok = bool(torch.equal(fa, feats)) and bool(torch.equal(pcm2[:B], pcm))  # same utterances, same waveforms
+    two = {"utterances_per_launch": 2 * B, "ms_per_two_batches": (tq1 - tq0) * 1e3,
+           "rtf_aggregate_this_rank": 2 * B * (L * 160 - 17) / (tq1 - tq0) / 16000.0,
+           "first_batch_identical_to_the_per_batch_run": pair_ok,
+           "note": "encode batch A, encode batch B, ceps2lpc, ONE decode launch over both (2 x 128 = one workgroup per CU): "
+                   "the form to run on one GPU; encode_ms / decode_ms above are the per-128 figures of BASELINE config 5's share"}
+    # ---- diagnostic: the encoder of batch k + 1 on a side stream while the vocoder decodes batch k.  The decode holds half of
+    # every XCD, so some of the encoder's groups cannot become resident and decide for the row-split fallback (fpcodec.h
+    # "Kernel forms": a busy GPU costs speed, never a timeout) -- fallback_groups_per_batch of its 8 groups; the launches of
+    # those batches take 10 ms instead of 4 (profiles/r05_kernel_stats.csv).  Kept as a check of that guarantee, not as
+    # the schedule to use: the two-batch form above is.
     pipe = None
     try:
         s_enc = torch.cuda.Stream()
-        keep, cur, fb, nb = [feats], feats, 0, 3
+        keep, cur, nb, evs = [feats], feats, 3, []
         torch.cuda.synchronize()
         tp0 = time.perf_counter()
         for _ in range(nb):
             voc.synthesize(cur, seeds, out=pcm)                      # asynchronous, on the current stream
             with torch.cuda.stream(s_enc):
+                ea, eb = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                ea.record()
                 nxt = encode_features(model, cfg, nm_d)[0]
-                fb += model.fallback_groups()                        # (synchronises: the decode of this batch is through too)
+                eb.record()
+                evs.append((ea, eb))
             torch.cuda.current_stream().wait_stream(s_enc)
             keep.append(nxt)                                          # (allocated on the side stream: alive until the end)
             cur = nxt
         torch.cuda.synchronize()
-        pipe = {"batches": nb, "ms_per_batch": (time.perf_counter() - tp0) / nb * 1e3, "fallback_groups_per_batch": fb / nb,
-                "note": "decode of batch k and encode of batch k + 1 concurrently (two streams, one process); sequential: "
-                        "encode_ms + decode_ms"}
-        assert torch.equal(keep[-1], feats), "the pipelined encoder's features differ from the sequential run's"
+        t_pipe = (time.perf_counter() - tp0) / nb * 1e3
+        enc_beside = [a.elapsed_time(b) for a, b in evs]
+        same = bool(torch.equal(keep[-1], feats))
         del keep
-    except Exception as e:  # (a diagnostic leg: it must not take the line down)
-        pipe = {"error": repr(e)[:200]}
+        # how many of the encoder's 8 groups fell back: a second pass that reads the count after every batch (the read
+        # synchronises, so this pass is not the one that is timed)
+        fb = 0
+        for _ in range(nb):
+            voc.synthesize(feats, seeds, out=pcm)
+            with torch.cuda.stream(s_enc):
+                encode_features(model, cfg, nm_d)
+                fb += model.fallback_groups()
+            torch.cuda.current_stream().wait_stream(s_enc)
+        torch.cuda.synchronize()
+        pipe = {"batches": nb, "ms_per_batch": t_pipe, "encode_ms_beside_the_decode": enc_beside,
+                "fallback_groups_per_batch": fb / nb,
+                "note": "diagnostic, not the schedule to use: decode of batch k and encode of batch k + 1 concurrently (two streams, "
+                        "one process); encode_ms_beside_the_decode: HIP events on the side stream around the encoder of each batch "
+                        "(alone: encode_ms); fallback_groups_per_batch of the encoder's 8 groups, from a second, synchronising pass"}
+    except RuntimeError as e:  # (launch / availability errors only: this diagnostic leg must not take the line down)
+        pipe, same = {"error": repr(e)[:200]}, True
+    if not same:  # a wrong result is not a diagnostic: the run fails
+        raise AssertionError("the pipelined encoder's features differ from the sequential run's")
     # receiver side: the same utterances rebuilt from the symbols alone
     enc = model.encoder(cfg, nm_d[:, :, :20], None, cfg["l1"], cfg["l2"], qtz=True, return_indices=True)
     idx = enc[7]
@@ -296,7 +377,7 @@ def e2e_config5(voc, torch, synth, parallel, rank, world, L=300):
            "encode_ms": (t1 - t0) * 1e3, "decode_ms": (t2 - t1) * 1e3,
            "rtf_aggregate": rep["samples"] / rep["elapsed_s"] / 16000.0, "keep_rates": keep,
            "entropy_bits_per_symbol": ent, "bits_per_frame": bits_frame, "bitrate_bps": bits_frame * 100.0,
-           "decode_features_ms": (t4 - t3) * 1e3, "pipelined": pipe,
+           "decode_features_ms": (t4 - t3) * 1e3, "two_batches_one_decode": two, "pipelined": pipe,
            "predictor_roofline": {
                "bound": "mfma", "unit": "TFLOP/s", "peak": PEAK_F32_TFLOPS, "kernel": "k_encode_wsd",
                "kernel_ms": enc_ms, "call_ms": enc_call_ms, "achieved": enc_flop / (enc_ms * 1e-3) / 1e12,
@@ -314,7 +395,7 @@ def e2e_config5(voc, torch, synth, parallel, rank, world, L=300):
                           "loss": float(tloss),
                           "note": "fpc_trainer_step, 5 steps back to back (host clock): forward k_forward_ws<true>, loss, "
                                   "backward k_train_bwd_ws, weight gradients on f32 MFMA, Adam (train_frame.py:53-120)"},
-           "gpu_time_s": (t2 - t0) + (t4 - t2) + (enc_call_ms + 6 * (enc_ms + fwd_ms)) * 1e-3 + 6 * train_ms * 1e-3}
+           "gpu_time_s": (t2 - t0) + (t4 - t2) + 2 * (tq1 - tq0) + (enc_call_ms + 6 * (enc_ms + fwd_ms)) * 1e-3 + 6 * train_ms * 1e-3}
     if rank == 0:  # framing figures on rank 0's share (the arithmetic coder is plain Python: a sample of it)
         idx_h = idx.cpu().numpy()
         fixed_bits = bitstream.bits_per_frame(idx_h, sizes)
@@ -482,6 +563,8 @@ def main():
             "launch_ms": dec_s * 1e3, "cycles_per_sample_at_2p4GHz": dec_s * 2.4e9 / (T * 160 - 17),
             "hbm": {"achieved": dec_rate * HBM_BYTES_PER_SAMPLE / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                     "frac": dec_rate * HBM_BYTES_PER_SAMPLE / 1e9 / PEAK_HBM_GBS},
+            # waves per SIMD, CUs busy, issue shares per sample, the issue floor (north_star: "occupancy against gfx950 peak")
+            "occupancy": counters_record("k_decode", khash),
         },
     }
     e2e = None
@@ -506,12 +589,43 @@ def main():
         out["voiced_50"] = {"voiced_fraction": float((1.5 * fv[:, :, 19] - 0.5 > 0).float().mean().item()),
                             "decode_ms": msv, "samples_per_s": samples_step / (msv / 1e3),
                             "rtf_per_stream": samples_step / (msv / 1e3) / B / 16000.0}
+        # ---- more utterances than compute units: k_decode2 walks two utterances through each workgroup (lpcnet_decode2.h);
+        # beside it the same batch as rounds of k_decode (fpc_lpcnet_set_pairing(-1)).  Same PCM (checked here by hash).
+        many, many_s = [], 0.0
+        for Bm in (512, 1024):
+            fm = feats.repeat((Bm + B - 1) // B, 1, 1)[:Bm].contiguous()
+            sm = torch.from_numpy(synth.seeds(Bm, utt0=20000).astype(np.int64)).cuda()
+            pm = torch.empty(Bm, T * 160, dtype=torch.int16, device="cuda")
+            rec = {"streams": Bm}
+            for mode, key in ((0, "two_per_workgroup"), (-1, "one_per_workgroup")):
+                voc.set_pairing(mode)
+                voc.synthesize(fm, sm, out=pm)
+                torch.cuda.synchronize()
+                voc.synthesize(fm, sm, out=pm)
+                ms = voc.last_decode_ms()
+                many_s += 2 * ms / 1e3
+                n = Bm * (T * 160 - 17)
+                rec[key] = {"decode_ms": ms, "samples_per_s": n / (ms / 1e3), "streams_per_workgroup": voc.last_streams_per_workgroup(),
+                            "frac": n / (ms / 1e3) * FLOP_PER_SAMPLE / 1e12 / PEAK_F32_TFLOPS,
+                            "pcm_sha1": __import__("hashlib").sha1(pm.cpu().numpy().tobytes()).hexdigest()[:16]}
+            voc.set_pairing(0)
+            rec["ratio"] = rec["one_per_workgroup"]["decode_ms"] / rec["two_per_workgroup"]["decode_ms"]
+            rec["same_pcm"] = rec["one_per_workgroup"]["pcm_sha1"] == rec["two_per_workgroup"]["pcm_sha1"]
+            many.append(rec)
+            del fm, pm
+        out["many_stream"] = {"kernel": "k_decode2", "cases": many, "occupancy": counters_record("k_decode2", decode2_kernel_hash()),
+                              "note": "B > compute units on ONE GPU (configs 4 / 5 on fewer than 8 GPUs): decode launch by HIP "
+                                      "events; frac = samples/s x 145 600 FLOP / 157.3 TF as in `roofline`; one_per_workgroup = "
+                                      "the grid of B workgroups of k_decode running in rounds"}
+        if not all(c["same_pcm"] for c in many):
+            raise AssertionError("k_decode2 and k_decode disagree on the PCM of the many_stream leg")
         if e2e is not None:
             out["e2e"] = e2e
+            e2e["predictor_roofline"]["occupancy"] = counters_record("k_encode_wsd", predictor_kernel_hash())
         # how long the GPU worked inside this process (host clock around synchronised sections; the rest of the run is input
         # synthesis and, at --gpus 1, the CPU baseline): timed steps + warm-up + the e2e legs + the two latency views
         out["gpu_time_s"] = float(dt_local) + args.warmup * dec_s + (e2e["gpu_time_s"] if e2e is not None else 0.0) + \
-            2 * ms1 / 1e3 + 2 * msv / 1e3
+            2 * ms1 / 1e3 + 2 * msv / 1e3 + many_s
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)

@@ -1266,3 +1266,41 @@ EXPORT float orc_train_step(int in, int H1, int H2, int F, orc_params* P, orc_pa
     for (size_t k = 0; k < sizeof fr / sizeof fr[0]; ++k) free(fr[k]);
     return (float)loss;
 }
+
+/* ---- the two loops of oracle/kmeans1d_oracle.py's Lloyd iteration that numpy makes slow at the production sizes
+ * (k = 256, n = 400 000: a 400 000 x 256 float64 matrix per E-step, np.add.at per block in the M-step).  The SAME
+ * operations in the same order as kmeans1d_oracle._assign / _sums (tests/test_host_cpu.py holds the two equal); the numpy
+ * functions stay the definition.  scikit-learn (third party, _k_means_lloyd.pyx): label = argmin_j c_j^2 + (-2)(x c_j), the
+ * first minimum on ties. ---- */
+EXPORT void orc_km_assign(const double* x, long long n, const double* centers, int k, int* labels) {
+    for (long long i = 0; i < n; ++i) {
+        int best = 0;
+        double bd = centers[0] * centers[0] + (-2.0 * (x[i] * centers[0]));
+        for (int j = 1; j < k; ++j) {
+            const double d = centers[j] * centers[j] + (-2.0 * (x[i] * centers[j]));
+            if (d < bd) {
+                bd = d;
+                best = j;
+            }
+        }
+        labels[i] = best;
+    }
+}
+/* cluster sums and counts: per block of `ch` points the members' values one after the other in index order, then the blocks'
+ * partial sums one after the other (tot = tot + ps) */
+EXPORT void orc_km_sums(const double* x, const int* labels, long long n, int k, int ch, double* tot, double* cnt,
+                        double* ps /* [k] scratch */, double* pc /* [k] scratch */) {
+    for (int j = 0; j < k; ++j) tot[j] = cnt[j] = 0.0;
+    for (long long i0 = 0; i0 < n; i0 += ch) {
+        for (int j = 0; j < k; ++j) ps[j] = pc[j] = 0.0;
+        const long long i1 = i0 + ch < n ? i0 + ch : n;
+        for (long long i = i0; i < i1; ++i) {
+            ps[labels[i]] = ps[labels[i]] + x[i];
+            pc[labels[i]] = pc[labels[i]] + 1.0;
+        }
+        for (int j = 0; j < k; ++j) {
+            tot[j] = tot[j] + ps[j];
+            cnt[j] = cnt[j] + pc[j];
+        }
+    }
+}

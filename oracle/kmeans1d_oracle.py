@@ -131,6 +131,29 @@ def _sums(x, labels, k):
     return tot, cnt
 
 
+def _assign_c(x, centers):
+    """_assign through oracle/fpc_oracle.c::orc_km_assign: the same operations per (point, centre), the first minimum"""
+    import ctypes as C
+    from oracle import oracle as O
+    labels = np.empty(len(x), dtype=np.int32)
+    c = np.ascontiguousarray(centers, dtype=np.float64)
+    O.lib().orc_km_assign(x.ctypes.data_as(C.c_void_p), C.c_longlong(len(x)), c.ctypes.data_as(C.c_void_p), C.c_int(len(c)),
+                          labels.ctypes.data_as(C.c_void_p))
+    return labels
+
+
+def _sums_c(x, labels, k):
+    """_sums through oracle/fpc_oracle.c::orc_km_sums: the same adds in the same order"""
+    import ctypes as C
+    from oracle import oracle as O
+    tot, cnt, ps, pc = np.zeros(k), np.zeros(k), np.zeros(k), np.zeros(k)
+    lab = np.ascontiguousarray(labels, dtype=np.int32)
+    O.lib().orc_km_sums(x.ctypes.data_as(C.c_void_p), lab.ctypes.data_as(C.c_void_p), C.c_longlong(len(x)), C.c_int(k), C.c_int(CH),
+                        tot.ctypes.data_as(C.c_void_p), cnt.ctypes.data_as(C.c_void_p), ps.ctypes.data_as(C.c_void_p),
+                        pc.ctypes.data_as(C.c_void_p))
+    return tot, cnt
+
+
 def _relocate(x, labels, centers_old, s, cnt):
     empty = np.nonzero(cnt == 0.0)[0]
     if len(empty) == 0:
@@ -173,8 +196,12 @@ def _same_clustering(l1, l2, k):
     return True
 
 
-def kmeans1d(x, k, first_ids, uniforms, tol, max_iter=300):
-    """x: centred float64 values.  Returns (centers (k,), inertia, n_iter, seeds (n_init, k)) of the winning run"""
+def kmeans1d(x, k, first_ids, uniforms, tol, max_iter=300, fast=False):
+    """x: centred float64 values.  Returns (centers (k,), inertia, n_iter, seeds (n_init, k)) of the winning run.
+    fast: the E-step's argmin and the M-step's ordered sums through their C twins (orc_km_assign / orc_km_sums: the same
+    operations in the same order, held equal to the numpy forms by tests/test_host_cpu.py) -- what makes the production
+    sizes (k = 256, n = 400 000) run in seconds per iteration instead of a minute"""
+    assign, sums = (_assign_c, _sums_c) if fast else (_assign, _sums)
     x = np.ascontiguousarray(x, dtype=np.float64)
     xx = x * x
     best = None
@@ -186,8 +213,8 @@ def kmeans1d(x, k, first_ids, uniforms, tol, max_iter=300):
         labels_old = np.full(len(x), -1, dtype=np.int32)
         strict = False
         for it in range(max_iter):
-            labels = _assign(x, centers)
-            s, cnt = _sums(x, labels, k)
+            labels = assign(x, centers)
+            s, cnt = sums(x, labels, k)
             _relocate(x, labels, centers, s, cnt)
             new = _average(s, cnt)
             d = centers - new
@@ -201,7 +228,7 @@ def kmeans1d(x, k, first_ids, uniforms, tol, max_iter=300):
                 break
             labels_old = labels
         if not strict:
-            labels = _assign(x, centers)
+            labels = assign(x, centers)
         d = x - centers[labels]
         inertia = _seq(_block_sums(d * d))
         if best is None or (inertia < best[1] and not _same_clustering(labels, best[3], k)):
@@ -209,7 +236,7 @@ def kmeans1d(x, k, first_ids, uniforms, tol, max_iter=300):
     return best[0], best[1], best[2], np.array(all_seeds)
 
 
-def fit(values, k, n_init=10, seed=0, max_iter=300):
+def fit(values, k, n_init=10, seed=0, max_iter=300, fast=False):
     """sklearn.cluster.KMeans(n_clusters=k, random_state=seed, n_init=n_init).fit(values[:, None]).cluster_centers_ restated:
     the tolerance from the data as given (KMeans._tol, before the mean is subtracted), the mean subtracted, added back at the end"""
     v = np.asarray(values, dtype=np.float64).reshape(-1, 1).copy()
@@ -217,5 +244,5 @@ def fit(values, k, n_init=10, seed=0, max_iter=300):
     mean = v.mean(axis=0)
     v -= mean
     first, u, _ = draws(len(v), k, n_init, seed)
-    centers, inertia, n_iter, seeds = kmeans1d(v[:, 0], k, first, u, tol, max_iter)
+    centers, inertia, n_iter, seeds = kmeans1d(v[:, 0], k, first, u, tol, max_iter, fast)
     return (centers[:, None] + mean), inertia, n_iter, seeds

@@ -333,6 +333,93 @@ def test_lpcnet_more_utterances_than_cus(torch_cuda, vocoder, synth, oracle):
         assert np.array_equal(pcm[b], orc.synthesize(f[b], int(sd[b]))), f"utt {b}"
 
 
+@pytest.mark.parametrize("density,variant", [((0.02, 0.02, 0.10), 208), ((0.05, 0.05, 0.20), 408),
+                                             ((0.05, 0.05, 0.26), 1616)])
+def test_lpcnet_two_utterances_per_workgroup_small(torch_cuda, synth, oracle, density, variant):
+    """k_decode2 (fpc_lpcnet_set_pairing, lpcnet_decode2.h) against the oracle and against k_decode: an odd batch (the last
+    workgroup decodes its one utterance twice), pairs whose members are voiced / unvoiced in different frames (the fifth
+    barrier is taken when either is), both instances of the kernel; a model whose row groups are too wide for the packed
+    planes (1616) keeps one utterance per workgroup whatever is asked"""
+    from fpcodec_amd.lpcnet import LPCNet
+    w = synth.lpcnet_weights(density=density)
+    voc = LPCNet(w)
+    assert voc.kernel_variant() == variant
+    orc = oracle.LPCNet(w)
+    B, T = 5, 5
+    f = _voc_features(synth, oracle, B, T, utt0=11)
+    f[0, :, 19] = -0.4         # unvoiced throughout, paired with ...
+    f[1, :, 19] = 0.9          # ... a voiced utterance
+    f[2, 1:3, 19] = 0.8        # a pair voiced in different frames
+    f[3, 2:4, 19] = 0.7
+    sd = synth.seeds(B, utt0=11)
+    ref = np.stack([orc.synthesize(f[b], int(sd[b])) for b in range(B)])
+    for mode in (-1, 1):
+        voc.set_pairing(mode)
+        pcm = voc.synthesize(f, sd).cpu().numpy()
+        assert voc.last_streams_per_workgroup() == (2 if mode == 1 and variant != 1616 else 1)
+        nz = np.argwhere(pcm != ref)
+        assert nz.size == 0, f"variant {variant} pairing {mode}: first mismatch at {nz[:3].tolist()}"
+    # one utterance alone is never paired; the default pairs only when the batch exceeds the compute units
+    voc.set_pairing(1)
+    assert np.array_equal(voc.synthesize(f[2:3], sd[2:3]).cpu().numpy()[0], ref[2]) and voc.last_streams_per_workgroup() == 1
+    voc.set_pairing(0)
+    voc.synthesize(f, sd)
+    assert voc.last_streams_per_workgroup() == 1
+
+
+def test_lpcnet_512_utterances_two_per_workgroup_full_size(torch_cuda, vocoder, synth, oracle):
+    """B = 512 x 3 s on one GPU (configs 4 / 5 on fewer than 8 GPUs; SURVEY.md 7: "more than one stream per CU is the
+    lever for B > 256"): by default two utterances per workgroup; every sample equal to the rounds of k_decode, four rows
+    equal to the oracle; B = 256 still takes one utterance per workgroup"""
+    import concurrent.futures as cf
+    voc, w = vocoder
+    B, T, nu = 512, 300, 8
+    base = _voc_features(synth, oracle, nu, T, utt0=1200)
+    base[1, 0::2, 19] = 0.9   # one of the eight alternates voiced / unvoiced frames
+    f = np.tile(base, (B // nu, 1, 1))
+    sd = synth.seeds(B, utt0=1200)
+    voc.set_pairing(0)
+    pcm = voc.synthesize(f, sd).cpu().numpy()
+    assert voc.last_streams_per_workgroup() == 2
+    t_pair = voc.last_decode_ms()
+    voc.set_pairing(-1)
+    rounds = voc.synthesize(f, sd).cpu().numpy()
+    assert voc.last_streams_per_workgroup() == 1
+    t_rounds = voc.last_decode_ms()
+    voc.set_pairing(0)
+    assert np.array_equal(pcm, rounds), "k_decode2 and k_decode disagree"
+    assert t_pair < t_rounds, f"two per workgroup {t_pair:.1f} ms, rounds of k_decode {t_rounds:.1f} ms"
+    orc = oracle.LPCNet(w)
+    rows = (0, 255, 257, 511)
+    with cf.ThreadPoolExecutor(4) as ex:
+        refs = list(ex.map(lambda b: orc.synthesize(f[b], int(sd[b])), rows))
+    for b, ref in zip(rows, refs):
+        nz = np.nonzero(pcm[b] != ref)[0]
+        assert nz.size == 0, f"utt {b}: first mismatch at sample {nz[:5]}"
+    voc.synthesize(f[:256], sd[:256])
+    assert voc.last_streams_per_workgroup() == 1
+
+
+def test_vocoder_long_utterances_two_per_workgroup(torch_cuda, vocoder, synth, oracle):
+    """two 15-second utterances through one workgroup of k_decode2 (see test_vocoder_long_utterance_parity)"""
+    import concurrent.futures as cf
+    voc, w = vocoder
+    T = 1500
+    f = _voc_features(synth, oracle, 2, T, utt0=17)
+    f[1, 100:900, 19] = 0.8
+    sd = synth.seeds(2, utt0=17)
+    voc.set_pairing(1)
+    pcm = voc.synthesize(f, sd).cpu().numpy()
+    assert voc.last_streams_per_workgroup() == 2
+    voc.set_pairing(0)
+    orc = oracle.LPCNet(w)
+    with cf.ThreadPoolExecutor(2) as ex:
+        refs = list(ex.map(lambda b: orc.synthesize(f[b], int(sd[b])), range(2)))
+    for b in range(2):
+        nz = np.nonzero(pcm[b] != refs[b])[0]
+        assert nz.size == 0, f"utt {b}: first mismatch at sample {nz[:5]}"
+
+
 def test_lpcnet_shortest_inputs(torch_cuda, vocoder, synth, oracle):
     """one frame (143 audible samples after the 17 skipped ones) and a single utterance"""
     voc, w = vocoder
@@ -595,6 +682,51 @@ def test_train_backward_weights_stationary_equals_row_split_and_oracle(torch_cud
         assert np.array_equal(got[1 + k], ref.g[name]), name
     for k, name in enumerate(sorted(ref.p)):
         assert np.array_equal(got[1 + len(ref.g) + k], ref.p[name]), name
+
+
+def test_train_step_at_the_reference_batch_bitwise(torch_cuda, synth, oracle, monkeypatch):
+    """the reference's batch (train_frame.py:188-204: 100 utterances x 150 frames = 7 groups of 16, the last one part-filled,
+    150 steps of the two-track backward): loss, every gradient and every parameter over THREE steps bit for bit between the
+    weights-stationary backward kernel and the row-split one (FPC_TRAIN_BWD_ROWSPLIT=1), and the first step bit for bit
+    against the CPU oracle (one host thread, running beside the GPU work)"""
+    import threading
+    from fpcodec_amd.train_frame import Trainer
+    from fpcodec_amd.wavernn import Wavernn
+    feat = synth.predictor_features(100, 150, utt0=6000)
+    ref = oracle.Trainer(synth.predictor_state_dict(), lr=1e-3)
+    box = {}
+    th = threading.Thread(target=lambda: box.setdefault("loss", ref.step(feat)))
+    th.start()
+
+    def run(steps):
+        m = Wavernn(20, 384, 128, 18)
+        m.load_state_dict(synth.predictor_state_dict())
+        tr = Trainer(m, lr=1e-3, max_batch=100, max_frames=150)
+        losses, first = [], None
+        for k in range(steps):
+            losses.append(tr.step(feat))
+            if k == 0:
+                g0 = tr.gradients()
+                tr.sync()
+                first = [g0[n] for n in sorted(g0)] + [v.numpy().copy() for _, v in sorted(m.state_dict().items())]
+        g = tr.gradients()
+        tr.sync()
+        sd = m.state_dict()
+        return [np.float32(losses)] + [g[n] for n in sorted(g)] + [sd[n].numpy() for n in sorted(sd)], first
+
+    monkeypatch.setenv("FPC_TRAIN_BWD_ROWSPLIT", "1")
+    rs, _ = run(3)
+    monkeypatch.delenv("FPC_TRAIN_BWD_ROWSPLIT")
+    ws, first = run(3)
+    for k, (a, b) in enumerate(zip(rs, ws)):
+        assert not np.isnan(b).any() and np.array_equal(a, b), k
+    th.join()
+    assert np.float32(box["loss"]) == ws[0][0]
+    names_g, names_p = sorted(ref.g), sorted(ref.p)
+    for k, name in enumerate(names_g):
+        assert np.array_equal(first[k], ref.g[name]), name
+    for k, name in enumerate(names_p):
+        assert np.array_equal(first[len(names_g) + k], ref.p[name]), name
 
 
 def test_train_converges_at_reference_batch(torch_cuda, synth):
@@ -1081,8 +1213,11 @@ def test_injected_quantizers_are_honoured(torch_cuda, model, synth, cb_paths):
         model.encoder(cfg, feat, None, 0.09, 0.28, vq_zero, scl_zero, qtz=True, return_indices=True)
 
 
-def test_vocoder_stress_parity_randomised(torch_cuda, synth, oracle):
-    """the vocoder guard that used to be a tool (tools/stress_parity.py), now in the driver-run suite: three weight sets
+@pytest.mark.parametrize("pairing", [0, 1])
+def test_vocoder_stress_parity_randomised(torch_cuda, synth, oracle, pairing):
+    """(pairing 0: one utterance per workgroup, k_decode; 1: two per workgroup, k_decode2 -- the third weight set selects
+    k_decode2<2>, the first two k_decode2<4>)
+    the vocoder guard that used to be a tool (tools/stress_parity.py), now in the driver-run suite: three weight sets
     with other seeds and densities than the benchmark's (they select different decode-kernel instances and
     placements), pitch correlations drawn over the whole range (a wide mix of voiced and unvoiced frames), random
     64-bit seeds: 3 x 16 utterances x 40 frames = 306 k samples, every one equal to the oracle's"""
@@ -1092,12 +1227,14 @@ def test_vocoder_stress_parity_randomised(torch_cuda, synth, oracle):
     for wseed, dens in ((1004, (0.05, 0.05, 0.2)), (77, (0.03, 0.06, 0.18)), (5, (0.02, 0.02, 0.1))):
         w = synth.lpcnet_weights(seed=wseed, density=dens)
         voc, orc = LPCNet(w), oracle.LPCNet(w)
+        voc.set_pairing(pairing)
         B, T = 16, 40
         f = synth.vocoder_features_raw(B, T, utt0=wseed * 10)
         f[:, :, 19] = np.random.default_rng(wseed).uniform(-0.5, 1.0, (B, T))
         f[:, :, 20:] = oracle.ceps2lpc(f.reshape(-1, 36)[:, :20])[0].reshape(B, T, 16)
         sd = np.random.default_rng(wseed + 1).integers(0, 2 ** 62, B).astype(np.uint64)
         pcm = voc.synthesize(f, sd).cpu().numpy()
+        assert voc.last_streams_per_workgroup() == 1 + pairing
         with cf.ThreadPoolExecutor(16) as ex:
             refs = list(ex.map(lambda b: orc.synthesize(f[b], int(sd[b])), range(B)))
         for b in range(B):
@@ -1125,14 +1262,17 @@ def test_vocoder_long_utterance_parity(torch_cuda, vocoder, synth, oracle):
     assert int(np.abs(pcm[0].astype(np.int32)).max()) > 100  # a live signal, not silence
 
 
-def test_vocoder_chunked_pass_same_samples_bounded_workspace(torch_cuda, synth, oracle):
-    """fpc_lpcnet_set_chunk_frames: the frame-rate layers, the conditioning products and the sample loop chunk by chunk
+@pytest.mark.parametrize("pairing", [0, 1])
+def test_vocoder_chunked_pass_same_samples_bounded_workspace(torch_cuda, synth, oracle, pairing):
+    """(pairing 1: the same on k_decode2 -- three utterances = one pair and a workgroup that decodes its one utterance twice)
+    fpc_lpcnet_set_chunk_frames: the frame-rate layers, the conditioning products and the sample loop chunk by chunk
     with the per-stream state carried in a record -- the same samples bit for bit as the one-pass form and as the oracle
     (chunks of 1, 5 and 7 frames over 23: ragged last chunk, halo frames at both ends of the utterance, a voiced and an
     unvoiced stream), the conditioning vectors too, and a workspace that does not grow with T"""
     from fpcodec_amd.lpcnet import LPCNet
     w = synth.lpcnet_weights()
     voc = LPCNet(w)
+    voc.set_pairing(pairing)
     B, T = 3, 23
     f = _voc_features(synth, oracle, B, T, utt0=3)
     f[1, :, 19] = 0.9   # a voiced stream: the sharpened-pdf path through every chunk
@@ -1507,6 +1647,29 @@ def test_scalar_codebook_kmeans_equals_oracle_bitwise_and_sklearn(torch_cuda, n,
     d2 = {}
     c2 = train_cb.train_scalar_codebook(v, k, n_init=3, details=d2)
     assert np.array_equal(c, c2) and d2["inertia"] == d["inertia"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("k", [256, 16])
+def test_scalar_codebook_kmeans_production_sizes(torch_cuda, k):
+    """the sizes the path uses (README.md:29: 256 scalar entries above the threshold, 16 below; train_cb.py:219-226 on the
+    residuals of a corpus: n = 400 000): the seeding's three-level candidate search and the two-level M-step over 196 blocks of
+    2 048 points.  Seeds, iteration count, inertia and centres bit-identical to the oracle (its Lloyd loops through their C
+    twins, which tests/test_host_cpu.py holds equal to the numpy definition), and scikit-learn itself to 1e-9"""
+    from sklearn.cluster import KMeans
+    from fpcodec_amd import train_cb
+    from oracle import kmeans1d_oracle as KO
+    n = 400000
+    rs = np.random.RandomState(100 + k)
+    v = (rs.laplace(size=n) * 0.1).astype(np.float32).astype(np.float64)
+    d = {}
+    c = train_cb.train_scalar_codebook(v, k, n_init=2, details=d)
+    oc, oinertia, oiter, oseeds = KO.fit(v, k, n_init=2, fast=True)
+    assert np.array_equal(d["seeds"], oseeds)
+    assert d["n_iter"] == oiter and d["inertia"] == oinertia
+    assert np.array_equal(c, oc)
+    km = KMeans(n_clusters=k, random_state=0, n_init=2).fit(v[:, None])
+    assert np.abs(c - km.cluster_centers_).max() < 1e-9 and d["n_iter"] == km.n_iter_
 
 
 @pytest.mark.gpu

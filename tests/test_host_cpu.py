@@ -45,7 +45,7 @@ def test_binding_names_a_library_of_another_abi_version(built, tmp_path, monkeyp
     subprocess.check_call(["gcc", "-shared", "-fPIC", "-o", str(so), str(src)])
     monkeypatch.setattr(built, "LIB_PATH", str(so))
     monkeypatch.setattr(built, "_lib", None)
-    with pytest.raises(built.FpcError, match="ABI version 1, this binding needs 3"):
+    with pytest.raises(built.FpcError, match="ABI version 1, this binding needs 4"):
         built.lib()
 
 
@@ -516,6 +516,24 @@ def test_kmeans_oracle_is_pinned_to_sklearn(n, k):
     f0, u0, t0 = KO.draws(n, k, 3)
     f1, u1, t1 = train_cb.kmeans_draws(n, k, 3)
     assert t0 == t1 == 2 + int(np.log(k)) and np.array_equal(f0, f1) and np.array_equal(u0, u1)
+
+
+@pytest.mark.parametrize("n,k", [(5000, 8), (12000, 32), (3000, 64)])
+def test_kmeans_oracle_c_twins_equal_the_numpy_definition(n, k):
+    """oracle/fpc_oracle.c::orc_km_assign / orc_km_sums (what lets the oracle run the production sizes in the GPU suite) against
+    kmeans1d_oracle._assign / _sums: the same labels, the same sums bit for bit, and the same fit"""
+    from oracle import kmeans1d_oracle as KO
+    rs = np.random.RandomState(7 + k)
+    v = (rs.laplace(size=n) * 0.1).astype(np.float32).astype(np.float64)
+    x = v - v.mean()
+    centers = np.sort(rs.choice(x, k, replace=False))
+    centers[1] = centers[0]  # a tie: the first minimum wins in both
+    la, lb = KO._assign(x, centers), KO._assign_c(x, centers)
+    assert np.array_equal(la, lb)
+    (ta, ca), (tb, cb) = KO._sums(x, la, k), KO._sums_c(x, la, k)
+    assert np.array_equal(ta, tb) and np.array_equal(ca, cb)
+    a, b = KO.fit(v, k, n_init=2), KO.fit(v, k, n_init=2, fast=True)
+    assert all(np.array_equal(p, q) for p, q in zip(a, b))
 
 
 def test_kmeans_oracle_relocates_an_empty_cluster_like_sklearn():
