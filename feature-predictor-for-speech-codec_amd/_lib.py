@@ -10,7 +10,7 @@ _lib = None
 ABI_VERSION = 4  # the FPC_ABI_VERSION of include/fpcodec.h this binding is written against
 
 SYMBOLS = [
-    "fpc_last_error", "fpc_abi_version", "fpc_build_info", "fpc_device_count",
+    "fpc_last_error", "fpc_abi_version", "fpc_build_info", "fpc_device_count", "fpc_selftest",
     "fpc_predictor_create", "fpc_predictor_destroy", "fpc_predictor_forward", "fpc_predictor_status",
     "fpc_predictor_set_split", "fpc_predictor_fallback_groups",
     "fpc_codebooks_create", "fpc_codebooks_destroy", "fpc_codebooks_hist_size",

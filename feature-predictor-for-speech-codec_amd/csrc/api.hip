@@ -32,3 +32,18 @@ extern "C" int fpc_device_count(void) {
     if (hipGetDeviceCount(&n) != hipSuccess) return 0;
     return n;
 }
+extern "C" int fpc_selftest(void) {
+    fpc::DevBuf b;
+    // without a device every hipMalloc fails; with one, a request beyond any card's memory does
+    const size_t absurd = (size_t)1 << 60;
+    FPC_REQUIRE(b.alloc(absurd) != hipSuccess, "fpc_selftest: an allocation of 2^60 bytes succeeded");
+    (void)hipGetLastError();
+    FPC_REQUIRE(b.p == nullptr && b.bytes == 0, "fpc_selftest: a failed allocation left p=%p bytes=%zu", b.p, b.bytes);
+    if (fpc::have_device()) {
+        FPC_REQUIRE(b.alloc(256) == hipSuccess && b.p != nullptr && b.bytes == 256, "fpc_selftest: a 256-byte allocation failed");
+        FPC_REQUIRE(b.alloc(absurd) != hipSuccess, "fpc_selftest: an allocation of 2^60 bytes succeeded");
+        (void)hipGetLastError();
+        FPC_REQUIRE(b.p == nullptr && b.bytes == 0, "fpc_selftest: a failed re-allocation left p=%p bytes=%zu", b.p, b.bytes);
+    }
+    return FPC_OK;
+}

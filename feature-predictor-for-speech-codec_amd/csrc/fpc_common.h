@@ -38,9 +38,22 @@ struct DevBuf {
     ~DevBuf() {
         if (p) (void)hipFree(p);
     }
+    // (re)allocates: the old block is released first; `bytes` says what `p` holds -- 0 with p == nullptr after a failure, so
+    // a caller's "large enough?" test can never pass on a block that is not there
     hipError_t alloc(size_t n) {
+        release();
+        const hipError_t e = hipMalloc(&p, n ? n : 1);
+        if (e != hipSuccess) {
+            p = nullptr;
+            return e;
+        }
         bytes = n;
-        return hipMalloc(&p, n ? n : 1);
+        return hipSuccess;
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        bytes = 0;
     }
     template <class T>
     hipError_t upload(const std::vector<T>& v) {
@@ -53,6 +66,12 @@ struct DevBuf {
         return static_cast<T*>(p);
     }
 };
+
+// an environment switch documented as NAME=1 (include/fpcodec.h): set to anything else -- NAME=0 included -- it is off
+inline bool env_is_one(const char* name) {
+    const char* e = getenv(name);
+    return e != nullptr && e[0] == '1';
+}
 
 inline bool have_device() {
     int n = 0;

@@ -19,7 +19,7 @@
 // picks.  What differs from sklearn is the ASSOCIATION of the long float64 sums (potentials, cluster sums, inertia): sklearn's
 // are BLAS / OpenMP reductions whose order is not specified (and not reproducible across thread counts); here every sum has
 // one fixed shape -- per block of 2 048 points thread t adds the points t, t + 256, .. in index order, then a halving tree over
-// the 256 threads, the block sums one after the other; cluster sums: per block the members in index order, then the blocks in order -- restated in oracle/oracle.py (orc_kmeans1d), to which this file is bit-identical; the oracle is
+// the 256 threads, the block sums one after the other; cluster sums: per block the members in index order, then the blocks in order -- restated in oracle/kmeans1d_oracle.py (fit / kmeans1d), to which this file is bit-identical; the oracle is
 // pinned to sklearn itself (same seeds, centres to 1e-9) in the CPU suite.
 #include "fpc_common.h"
 

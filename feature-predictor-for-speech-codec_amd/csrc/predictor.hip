@@ -1593,8 +1593,7 @@ static int split_args(fpc_predictor* p, int B, hipStream_t st, SplitArgs* out) {
     if (p->xg.bytes < bytes) {
         if (p->xg.p) {
             FPC_HIP(hipDeviceSynchronize());  // nothing may still be polling the old block (on any stream)
-            (void)hipFree(p->xg.p);
-            p->xg.p = nullptr;
+            p->xg.release();  // (bytes = 0: a failed allocation below leaves no size behind)
         }
         FPC_HIP(p->xg.alloc(bytes));
     }
@@ -1659,8 +1658,7 @@ static int ws_args(fpc_predictor* p, int B, hipStream_t st, WsArgs* out, int gra
     if (p->wsg.bytes < bytes) {
         if (p->wsg.p) {
             FPC_HIP(hipDeviceSynchronize());  // nothing may still be polling the old block (on any stream)
-            (void)hipFree(p->wsg.p);
-            p->wsg.p = nullptr;
+            p->wsg.release();  // (bytes = 0: a failed allocation below leaves no size behind)
         }
         FPC_HIP(p->wsg.alloc(bytes));
     }
@@ -1787,10 +1785,10 @@ extern "C" int fpc_predictor_forward(fpc_predictor* p, const float* x_dev, int B
         const size_t hbytes = sizeof(float) * (size_t)B * (size_t)(L > 0 ? L : 1) * WH2;  // relu(h2) of every sample, for k_out_layer
         if (p->h2hist.bytes < hbytes) {
             FPC_HIP(hipDeviceSynchronize());  // (a launch in flight -- on this stream or another -- may still read the old block)
-            if (p->h2hist.p) (void)hipFree(p->h2hist.p);
-            p->h2hist.p = nullptr;
-            FPC_HIP(p->h2hist.alloc(hbytes));
+            p->h2hist.release();  // (bytes = 0: if the allocation fails, a later, smaller call allocates again instead of
+            FPC_HIP(p->h2hist.alloc(hbytes));  //  launching on a block that is not there)
         }
+        FPC_REQUIRE(p->h2hist.p != nullptr, "fpc_predictor_forward: no scratch block");
         WsSave hs{};
         hs.relu = p->h2hist.as<float>();
         hipLaunchKernelGGL(k_forward_ws<false>, dim3(ws_grid(wa)), dim3(NT), 0, static_cast<hipStream_t>(s), p->d, x_dev, L, h1_dev,
@@ -1935,8 +1933,7 @@ extern "C" int fpc_encode(fpc_predictor* p, const fpc_codebooks* cb, const float
             if (p->wsidx.bytes < need) {
                 if (p->wsidx.p) {
                     FPC_HIP(hipDeviceSynchronize());
-                    (void)hipFree(p->wsidx.p);
-                    p->wsidx.p = nullptr;
+                    p->wsidx.release();
                 }
                 FPC_HIP(p->wsidx.alloc(need));
             }
@@ -2144,7 +2141,7 @@ extern "C" int fpc_trainer_step(fpc_trainer* t, const float* feat_dev, int B, in
     hipLaunchKernelGGL(k_train_loss, dim3(B), dim3(256), 0, st, feat_dev, in, F, L,
                        (float)(2.0 / cnt), T);
     const BwdW bw{t->wt[0].as<float>(), t->wt[1].as<float>(), t->wt[2].as<float>()};
-    if (ws_wanted(p) && !getenv("FPC_TRAIN_BWD_ROWSPLIT")) {
+    if (ws_wanted(p) && !fpc::env_is_one("FPC_TRAIN_BWD_ROWSPLIT")) {
         // back-propagation on the weights-stationary kernel (predictor_bwd_ws.h); behind it, for the groups whose workgroups
         // could not all become resident, the row-split kernel with one workgroup per utterance
         WsArgs wb;

@@ -55,6 +55,11 @@ FPC_API int fpc_abi_version(void);
 FPC_API const char* fpc_build_info(void);
 /* number of visible HIP devices (0 on a CPU-only host); never fails */
 FPC_API int fpc_device_count(void);
+/* Self-check of the library's device-buffer bookkeeping, runnable with or without a GPU: a failed allocation (no device, or an
+ * absurd size on a device) must leave a buffer empty -- pointer NULL, size 0 -- so that a later "large enough?" test cannot
+ * pass on a block that is not there (a forward call would otherwise launch on a null scratch block).  0 when the invariants
+ * hold, a negative fpc_status with text in fpc_last_error otherwise.  (No reference counterpart.) */
+FPC_API int fpc_selftest(void);
 
 /* ------------------------------------------------------------------------
  * Feature predictor  (src/models/wavernn.py:24-52 parameters,
@@ -151,7 +156,7 @@ FPC_API void fpc_predictor_destroy(fpc_predictor* p);
  * frames carry the symbols -2 and were not searched); clears the condition. */
 FPC_API int fpc_predictor_status(fpc_predictor* p);
 /* Diagnostic: how many groups of 16 utterances of the handle's LAST weights-stationary launch could not get their 32
- * workgroups resident within the bound and were served by the row-split launch behind it ("Kernel forms" below: correct
+ * workgroups resident within the bound and were served by the row-split launch behind it ("Kernel forms" above: correct
  * either way, slower).  Synchronises the device; >= 0, or a negative fpc_status.  (No reference counterpart.) */
 FPC_API int fpc_predictor_fallback_groups(fpc_predictor* p);
 /* workgroups per utterance: 0 automatic (default), 1 never split, 2 / 4 / 8 exactly that many when the shape allows */

@@ -49,6 +49,14 @@ def test_binding_names_a_library_of_another_abi_version(built, tmp_path, monkeyp
         built.lib()
 
 
+def test_device_buffer_is_empty_after_a_failed_allocation(built):
+    """ADVICE round 5: DevBuf::alloc wrote the size before hipMalloc; a failed grow left p == NULL with the new size, and a later,
+    smaller forward call would have launched on the null block.  fpc_selftest exercises the failure (no device here: every
+    hipMalloc fails) and checks pointer and size"""
+    L = built.lib()
+    assert L.fpc_selftest() == 0, L.fpc_last_error()
+
+
 def test_no_cpu_fallback(built):
     import torch
     if torch.cuda.is_available():
