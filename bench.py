@@ -14,8 +14,12 @@ gathers the report).  Inputs (features, seeds, weights) are resident in HBM befo
 region.  Rank 0 prints ONE JSON line.  Outside the timed region the line also carries BASELINE
 config 5 (`e2e`: predictor + residual VQ encode -> ceps2lpc -> decode on this rank's share of
 128 x N utterances, codebook-usage histograms summed over all ranks before the entropy, as
-src/generate_qtz_features.py:184,202 sums them over utterances), the single-stream latency view
-(config 2), a second decode at 50 % voiced frames, and the CPU baselines.
+src/generate_qtz_features.py:184,202 sums them over utterances; `two_batches_one_decode`: the one-GPU
+throughput form, two encode batches per 256-stream decode launch), `many_stream` (512 and 1 024
+utterances on one GPU: k_decode2, two utterances per workgroup, beside rounds of k_decode), the
+single-stream latency view (config 2), a second decode at 50 % voiced frames, and the CPU baselines.
+`roofline.occupancy` / `many_stream.occupancy` / `e2e.predictor_roofline.occupancy`: waves per SIMD, CUs
+busy and issue shares from the committed SQ-counter passes (profiles/*_counters.json, tied to the sources).
 """
 import argparse
 import json

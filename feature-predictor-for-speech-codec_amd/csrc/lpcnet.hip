@@ -658,25 +658,48 @@ extern "C" int fpc_lpcnet_synthesize(fpc_lpcnet* m, const float* features_dev, i
     const int variant = decode_variant(m);
     // More utterances than compute units: k_decode2 walks two utterances through each workgroup (lpcnet_decode2.h; the
     // packed partial-sum planes exist for the instances whose update / reset row groups are <= 4 lanes wide).  Same PCM.
-    const bool pair = m->pair_ok && B > 1 && (m->pairing > 0 || (m->pairing == 0 && B > m->cus));
-    m->last_streams_per_wg = pair ? 2 : 1;
-    if (pair) {  // (k_decode2's placement of the row groups)
-        P.lane_w = m->lane_w2.as<float>();
-        P.lane_meta = m->lane_meta2.as<int>();
+    // The batch is decoded as its first NP utterances on k_decode2 (NP / 2 workgroups) and the rest on k_decode.  Default
+    // policy (pairing 0): a round of k_decode2 (2 x CUs utterances) costs about 1.7 rounds of k_decode (CUs utterances
+    // each); take the number of full-or-partial pair rounds p that minimises 1.7 p + ceil(rest / CUs) -- B <= CUs: none;
+    // CUs < B <= 2 CUs: all paired; 2 CUs < B <= 3 CUs: one pair round + one round of k_decode; ...  pairing 1: all paired.
+    int NP = 0;
+    if (m->pair_ok && B > 1 && m->pairing > 0) NP = B;
+    if (m->pair_ok && B > 1 && m->pairing == 0 && B > m->cus) {
+        const int cu = m->cus > 0 ? m->cus : 256;
+        double best = 1e30;
+        for (int p = 0; p <= (B + 2 * cu - 1) / (2 * cu); ++p) {
+            const int np = std::min(B, 2 * cu * p), rest = B - np;
+            const double cost = 1.7 * p + (rest + cu - 1) / cu;
+            if (cost < best - 1e-9) best = cost, NP = np;
+        }
     }
+    const bool pair = NP > 0;
+    m->last_streams_per_wg = pair ? 2 : 1;
+    DecodeParams P2 = P;  // k_decode2's launch: its own placement of the row groups
+    P2.lane_w = m->lane_w2.as<float>();
+    P2.lane_meta = m->lane_meta2.as<int>();
+    // k_decode's launch over the utterances behind the paired ones: the kernel indexes by workgroup, so the bases move
+    DecodeParams P1 = P;
+    P1.features += (size_t)NP * T * FPC_NB_FEATURES;
+    P1.seeds += NP;
+    P1.pcm += (size_t)NP * T * FPC_FRAME_SIZE;
+    P1.cfa += (size_t)NP * C * GA;
+    P1.cfb += (size_t)NP * C * GB;
+    if (P1.state) P1.state += (size_t)NP * STATE_FLOATS;
+    const int B1 = B - NP;
 #define FPC_LAUNCH2(QZR)                                                                                      \
     do {                                                                                                      \
         if (stamp)                                                                                            \
-            hipLaunchKernelGGL((k_decode2<true, QZR>), dim3((B + 1) / 2), dim3(NTHREADS), 0, st, P, B);       \
+            hipLaunchKernelGGL((k_decode2<true, QZR>), dim3((NP + 1) / 2), dim3(NTHREADS), 0, st, P2, NP);    \
         else                                                                                                  \
-            hipLaunchKernelGGL((k_decode2<false, QZR>), dim3((B + 1) / 2), dim3(NTHREADS), 0, st, P, B);      \
+            hipLaunchKernelGGL((k_decode2<false, QZR>), dim3((NP + 1) / 2), dim3(NTHREADS), 0, st, P2, NP);   \
     } while (0)
 #define FPC_LAUNCH(QZR, QN)                                                                       \
     do {                                                                                          \
         if (stamp)                                                                                \
-            hipLaunchKernelGGL((k_decode<true, QZR, QN>), dim3(B), dim3(NTHREADS), 0, st, P);     \
+            hipLaunchKernelGGL((k_decode<true, QZR, QN>), dim3(B1), dim3(NTHREADS), 0, st, P1);   \
         else                                                                                      \
-            hipLaunchKernelGGL((k_decode<false, QZR, QN>), dim3(B), dim3(NTHREADS), 0, st, P);    \
+            hipLaunchKernelGGL((k_decode<false, QZR, QN>), dim3(B1), dim3(NTHREADS), 0, st, P1);  \
     } while (0)
     for (int f0 = 0; f0 < T; f0 += C) {
         const int f1 = std::min(T, f0 + C);
@@ -689,19 +712,21 @@ extern "C" int fpc_lpcnet_synthesize(fpc_lpcnet* m, const float* features_dev, i
                         c.cfa, B, v, 0, nullptr, st);
         launch_frame<0>(cfeat, 128, 128, 128, m->gb_k.as<float>() + (size_t)RNN_A * GB, m->bias_b.as<float>(), GB,
                         c.cfb, B, v, 0, nullptr, st);
-        P.f0 = f0;
-        P.f1 = f1;
+        P1.f0 = P2.f0 = f0;
+        P1.f1 = P2.f1 = f1;
         if (f0 == 0) FPC_HIP(hipEventRecord(m->ev0, st));  // (chunked: the span from the first sample loop to the last)
         if (pair && variant == 208)
             FPC_LAUNCH2(2);
         else if (pair)
             FPC_LAUNCH2(4);
-        else if (variant == 208)
-            FPC_LAUNCH(2, 8);
-        else if (variant == 408)
-            FPC_LAUNCH(4, 8);
-        else
-            FPC_LAUNCH(16, 16);
+        if (B1 > 0) {
+            if (variant == 208)
+                FPC_LAUNCH(2, 8);
+            else if (variant == 408)
+                FPC_LAUNCH(4, 8);
+            else
+                FPC_LAUNCH(16, 16);
+        }
     }
 #undef FPC_LAUNCH
 #undef FPC_LAUNCH2

@@ -77,7 +77,7 @@ for B in [int(x) for x in args.B.split(",")]:
     f = torch.from_numpy(np.tile(raw, (B // nu + 1, 1, 1))[:B].copy()).cuda()
     sd = synth.seeds(B, utt0=500)
     res = {}
-    for mode in (-1, 1):
+    for mode in (-1, 0):  # rounds of k_decode; the default policy (k_decode2, + a round of k_decode where that is cheaper)
         voc.set_pairing(mode)
         ms = []
         for _ in range(3):
@@ -86,10 +86,8 @@ for B in [int(x) for x in args.B.split(",")]:
             ms.append(voc.last_decode_ms())
         res[mode] = (min(ms[1:]), hashlib.sha1(pcm.cpu().numpy().tobytes()).hexdigest()[:12])
     n = B * (T * 160 - 17)
-    same = res[-1][1] == res[1][1]
+    same = res[-1][1] == res[0][1]
     bad += not same
-    rounds = -(-B // 256)
-    print(f"B={B:5d} T={T}: one/wg {res[-1][0]:8.2f} ms ({n / res[-1][0] / 1e3:7.1f} M samples/s)   two/wg {res[1][0]:8.2f} ms "
-          f"({n / res[1][0] / 1e3:7.1f} M samples/s)   ratio {res[-1][0] / res[1][0]:.3f}   "
-          f"cycles per sample pair {res[1][0] * 1e-3 * 2.4e9 / (T * 160 - 17) / -(-B // 512):.0f}   pcm {'same' if same else 'DIFFERENT'}", flush=True)
+    print(f"B={B:5d} T={T}: one/wg {res[-1][0]:8.2f} ms ({n / res[-1][0] / 1e3:7.1f} M samples/s)   default policy {res[0][0]:8.2f} ms "
+          f"({n / res[0][0] / 1e3:7.1f} M samples/s)   ratio {res[-1][0] / res[0][0]:.3f}   pcm {'same' if same else 'DIFFERENT'}", flush=True)
 sys.exit(1 if bad else 0)
