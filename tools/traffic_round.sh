@@ -15,7 +15,8 @@ sys.path.insert(0, ".")
 import bench
 def mean(counter):
     v = [float(r["Counter_Value"]) for r in csv.DictReader(open("$out/%s/runc_counter_collection.csv" % counter))
-         if "k_decode" in r["Kernel_Name"] and r["Counter_Name"] == counter and int(r["Grid_Size"]) >= 256 * 768]
+         if "k_decode<" in r["Kernel_Name"] and r["Counter_Name"] == counter and int(r["Grid_Size"]) == 256 * 768]  # (the timed step's launches:
+    # not k_decode2's, not the 512 / 1 024-workgroup rounds of the many_stream leg)
     return sum(v) / len(v), len(v)
 f, nf = mean("FETCH_SIZE")
 w, nw = mean("WRITE_SIZE")
