@@ -257,8 +257,10 @@ def e2e_config5(voc, torch, synth, parallel, rank, world, L=300):
     torch.cuda.synchronize()
     tq1 = time.perf_counter()
     pair_ok = bool(torch.equal(fa, feats)) and bool(torch.equal(pcm2[:B], pcm))  # same utterances, same waveforms
+    rep2 = parallel.gather_report(tq1 - tq0, 2 * B * (L * 160 - 17))  # MAX elapsed, SUM samples over the ranks
     two = {"utterances_per_launch": 2 * B, "ms_per_two_batches": (tq1 - tq0) * 1e3,
            "rtf_aggregate_this_rank": 2 * B * (L * 160 - 17) / (tq1 - tq0) / 16000.0,
+           "rtf_aggregate": rep2["samples"] / rep2["elapsed_s"] / 16000.0, "utterances_all_ranks": 2 * E2E_PER_GPU * world,
            "first_batch_identical_to_the_per_batch_run": pair_ok,
            "note": "encode batch A, encode batch B, ceps2lpc, ONE decode launch over both (2 x 128 = one workgroup per CU): "
                    "the form to run on one GPU; encode_ms / decode_ms above are the per-128 figures of BASELINE config 5's share"}
