@@ -14,8 +14,9 @@ gathers the report).  Inputs (features, seeds, weights) are resident in HBM befo
 region.  Rank 0 prints ONE JSON line.  Outside the timed region the line also carries BASELINE
 config 5 (`e2e`: predictor + residual VQ encode -> ceps2lpc -> decode on this rank's share of
 128 x N utterances, codebook-usage histograms summed over all ranks before the entropy, as
-src/generate_qtz_features.py:184,202 sums them over utterances; `two_batches_one_decode`: the one-GPU
-throughput form, two encode batches per 256-stream decode launch), `many_stream` (512 and 1 024
+src/generate_qtz_features.py:184,202 sums them over utterances; `two_batches_one_decode` /
+`four_batches_one_paired_decode`: the one-GPU throughput forms, two encode batches per 256-stream decode
+launch, four per 512-stream launch of k_decode2), `many_stream` (512 and 1 024
 utterances on one GPU: k_decode2, two utterances per workgroup, beside rounds of k_decode), the
 single-stream latency view (config 2), a second decode at 50 % voiced frames, and the CPU baselines.
 `roofline.occupancy` / `many_stream.occupancy` / `e2e.predictor_roofline.occupancy`: waves per SIMD, CUs
@@ -262,8 +263,39 @@ def e2e_config5(voc, torch, synth, parallel, rank, world, L=300):
            "rtf_aggregate_this_rank": 2 * B * (L * 160 - 17) / (tq1 - tq0) / 16000.0,
            "rtf_aggregate": rep2["samples"] / rep2["elapsed_s"] / 16000.0, "utterances_all_ranks": 2 * E2E_PER_GPU * world,
            "first_batch_identical_to_the_per_batch_run": pair_ok,
-           "note": "encode batch A, encode batch B, ceps2lpc, ONE decode launch over both (2 x 128 = one workgroup per CU): "
-                   "the form to run on one GPU; encode_ms / decode_ms above are the per-128 figures of BASELINE config 5's share"}
+           "note": "encode batch A, encode batch B, ceps2lpc, ONE decode launch over both (2 x 128 = one workgroup per CU); "
+                   "encode_ms / decode_ms above are the per-128 figures of BASELINE config 5's share; four batches per launch "
+                   "(k_decode2): four_batches_one_paired_decode"}
+    # ---- and with k_decode2 (two utterances per workgroup for batches larger than the CU count): FOUR encode batches, one
+    # 512-stream decode launch
+    nm4 = [nm_d, nm2_d]
+    sd4 = [seeds, seeds2]
+    for k in (2, 3):
+        x = np.zeros((B, L, 36), np.float32)
+        x[:, :, :20] = synth.predictor_features(B, L, utt0=9000 + 1000 * k + lo)
+        nm4.append(torch.from_numpy(x).cuda())
+        sd4.append(torch.from_numpy(synth.seeds(B, utt0=9000 + 1000 * k + lo).astype(np.int64)).cuda())
+    sd4c = torch.cat(sd4)
+    pcm4 = torch.empty(4 * B, L * 160, dtype=torch.int16, device="cuda")
+
+    def four_batches():
+        fs = [encode_features(model, cfg, x)[0] for x in nm4]
+        voc.synthesize(torch.cat(fs), sd4c, out=pcm4)
+    four_batches()
+    torch.cuda.synchronize()
+    tr0 = time.perf_counter()
+    four_batches()
+    torch.cuda.synchronize()
+    tr1 = time.perf_counter()
+    rep4 = parallel.gather_report(tr1 - tr0, 4 * B * (L * 160 - 17))
+    four = {"utterances_per_launch": 4 * B, "ms_per_four_batches": (tr1 - tr0) * 1e3,
+            "streams_per_workgroup": voc.last_streams_per_workgroup(),
+            "rtf_aggregate_this_rank": 4 * B * (L * 160 - 17) / (tr1 - tr0) / 16000.0,
+            "rtf_aggregate": rep4["samples"] / rep4["elapsed_s"] / 16000.0,
+            "first_two_batches_identical_to_the_two_batch_run": bool(torch.equal(pcm4[:2 * B], pcm2)),
+            "note": "four encode batches, ONE decode launch over 4 x 128 utterances on k_decode2 (two utterances per workgroup: "
+                    "lpcnet_decode2.h) -- the one-GPU form with the highest throughput"}
+    del pcm4
     # ---- diagnostic: the encoder of batch k + 1 on a side stream while the vocoder decodes batch k.  The decode holds half of
     # every XCD, so some of the encoder's groups cannot become resident and decide for the row-split fallback (fpcodec.h
     # "Kernel forms": a busy GPU costs speed, never a timeout) -- fallback_groups_per_batch of its 8 groups; the launches of
@@ -383,7 +415,7 @@ def e2e_config5(voc, torch, synth, parallel, rank, world, L=300):
            "encode_ms": (t1 - t0) * 1e3, "decode_ms": (t2 - t1) * 1e3,
            "rtf_aggregate": rep["samples"] / rep["elapsed_s"] / 16000.0, "keep_rates": keep,
            "entropy_bits_per_symbol": ent, "bits_per_frame": bits_frame, "bitrate_bps": bits_frame * 100.0,
-           "decode_features_ms": (t4 - t3) * 1e3, "two_batches_one_decode": two, "pipelined": pipe,
+           "decode_features_ms": (t4 - t3) * 1e3, "two_batches_one_decode": two, "four_batches_one_paired_decode": four, "pipelined": pipe,
            "predictor_roofline": {
                "bound": "mfma", "unit": "TFLOP/s", "peak": PEAK_F32_TFLOPS, "kernel": "k_encode_wsd",
                "kernel_ms": enc_ms, "call_ms": enc_call_ms, "achieved": enc_flop / (enc_ms * 1e-3) / 1e12,
@@ -401,7 +433,7 @@ def e2e_config5(voc, torch, synth, parallel, rank, world, L=300):
                           "loss": float(tloss),
                           "note": "fpc_trainer_step, 5 steps back to back (host clock): forward k_forward_ws<true>, loss, "
                                   "backward k_train_bwd_ws, weight gradients on f32 MFMA, Adam (train_frame.py:53-120)"},
-           "gpu_time_s": (t2 - t0) + (t4 - t2) + 2 * (tq1 - tq0) + (enc_call_ms + 6 * (enc_ms + fwd_ms)) * 1e-3 + 6 * train_ms * 1e-3}
+           "gpu_time_s": (t2 - t0) + (t4 - t2) + 2 * (tq1 - tq0) + 2 * (tr1 - tr0) + (enc_call_ms + 6 * (enc_ms + fwd_ms)) * 1e-3 + 6 * train_ms * 1e-3}
     if rank == 0:  # framing figures on rank 0's share (the arithmetic coder is plain Python: a sample of it)
         idx_h = idx.cpu().numpy()
         fixed_bits = bitstream.bits_per_frame(idx_h, sizes)
