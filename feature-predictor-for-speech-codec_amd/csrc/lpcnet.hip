@@ -16,6 +16,7 @@
 //                    dual-FC weights live in VGPRs for the whole utterance, recurrent state, activation
 //                    table and the partial sums of the sparse product live in LDS, HBM is touched only
 //                    for the per-frame conditioning vectors, the embedding-table rows and the PCM output.
+//   k_decode2        the same loop for TWO utterances per workgroup (lpcnet_decode2.h): batches larger than the CU count
 #include "fpc_common.h"
 #include <string>
 #include <algorithm>
@@ -153,6 +154,12 @@ void lpcnet_build_info(std::string& out) {
     FPC_TUNE("FPC_NA", FPC_NA, 6)
     FPC_TUNE("FPC_NB", FPC_NB, 4)
     FPC_TUNE("FPC_PCM_WHERE", FPC_PCM_WHERE, 0)
+    FPC_TUNE("FPC2_N1", FPC2_N1, 14)
+    FPC_TUNE("FPC2_N2", FPC2_N2, 11)
+    FPC_TUNE("FPC2_PRIO3", FPC2_PRIO3, 1)
+    FPC_TUNE("FPC2_GPRIO_PAIR", FPC2_GPRIO_PAIR, 3)
+    FPC_TUNE("FPC2_GPRIO_SINGLE", FPC2_GPRIO_SINGLE, 3)
+    FPC_TUNE("FPC2_ABL", FPC2_ABL, 0)
 #undef FPC_TUNE
 }
 }  // namespace fpc

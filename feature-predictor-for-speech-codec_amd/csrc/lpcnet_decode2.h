@@ -1,22 +1,29 @@
 // lpcnet_decode2.h -- the sample loop for MORE UTTERANCES THAN COMPUTE UNITS: two utterances per workgroup
 // (included by lpcnet.hip behind lpcnet_decode.h, whose helpers it uses; gfx950).
 //
-// k_decode (one utterance per workgroup) is a latency chain: per sample its vector pipes are busy 61 % of the
-// time and the LDS pipe 42 % (profiles/r05_pmc_decode.txt).  With more utterances than CUs the chip runs the
-// grid in rounds; this kernel instead walks TWO utterances through one workgroup in lockstep -- the same four
-// barriers per sample (five if either utterance's frame is voiced), every phase carrying both utterances, so
-// that each wave has two independent dependency chains to issue from and every barrier, L2 round trip and LDS
-// hop is paid once per PAIR of samples:
-//   * the sparse GRU_A weights (128 registers per mat-vec lane), the GRU_B weights (72 per sampler lane), the
-//     activation table and the diagonal / bias rows are shared by both utterances;
-//   * the dual-FC weights (36 registers per sampler lane in k_decode) move to LDS -- one ds_read_b128 serves both
-//     utterances -- which is what frees the registers for the second set of accumulators;
-//   * the partial-sum planes are packed (planes 4..7 exist for the candidate gate only: the update / reset gates'
-//     row groups are <= 4 lanes wide in the instances this kernel has), 24.7 kB per utterance instead of 74 kB;
-//   * the draw of utterance 0 runs on wave 0, that of utterance 1 on wave 1, side by side.
+// k_decode (one utterance per workgroup) is a latency chain: per sample its vector issue is busy 62 % of the time and the
+// LDS pipe 43 % (profiles/r06_counters.json).  With more utterances than CUs the chip runs the grid in rounds; this kernel
+// instead walks TWO utterances through one workgroup in lockstep -- the same four barriers per sample (five if either
+// utterance's frame is voiced), every phase carrying both -- so that every barrier, L2 round trip and LDS hop is paid once
+// per PAIR of samples and a wave has the other utterance's arithmetic to issue while one waits for LDS:
+//   waves 0-3  "sampler":  window (GRU_B recurrent sums, LPC taps, leaf candidates), GRU_B, dual FC of BOTH utterances;
+//                          the draw of utterance 0 on wave 0, of utterance 1 on wave 1, side by side
+//   waves 4-7  "mat-vec":  gates of units 0..255 of both utterances (six table rows in flight)        + the sparse products
+//   waves 8-11 "mat-vec":  gates of units 256..383 of utterance 0 (waves 8, 9) / 1 (waves 10, 11)      + the sparse products
+//   (three gate jobs per SIMD); the two sparse products of a pair of samples run one after the other on one accumulator set.
+// Shared by both utterances: the sparse GRU_A weights (116 registers per mat-vec lane + 12 in LDS, read once per product --
+// the twelve registers are the gate phase's head-room), GRU_B's (72 registers per sampler lane), the dual FC's (in LDS here,
+// one ds_read_b128 serves both; the 36 registers they hold in k_decode are what the second utterance's accumulators live in),
+// the activation table, diagonal and bias rows.
+// Partial sums of the sparse product: lanes 2k, 2k+1 of a row group add their eight row sums with one DPP add per value
+// (level 1 of the canonical tree) before lane 2k publishes: 2 planes for the update / reset gates, 4 for the candidate gate
+// (fpc_lpcnet_create pads the row groups to even widths in a second placement; an all-zero lane is the tree's +0 padding).
+// Table activations and mu-law lookups come in two halves (issue / finish): waves issue in order, so what hides an LDS
+// round trip is the other utterance's arithmetic placed between a read and its use, by hand (sched_barrier fences).
 // Every value is produced by the same operations in the same order as in k_decode (and in
 // oracle/fpc_oracle.c::orc_lpcnet_synthesize): the PCM is bit-identical, whichever kernel decodes an utterance.
-// Launched by fpc_lpcnet_synthesize when B exceeds the device's CU count (fpc_lpcnet_set_pairing overrides).
+// Launched by fpc_lpcnet_synthesize for batches larger than the device's CU count (fpc_lpcnet_set_pairing overrides);
+// 512 x 3 s in 110 ms against 131 ms as two rounds of k_decode.  What was tried and what it stops at: profiles/r06_ablations.txt.
 #pragma once
 
 // A plane holds the sums of TWO adjacent lanes of a row group (lanes 2k, 2k+1 add their eight row sums -- the first level
@@ -24,11 +31,9 @@
 constexpr int PN = RNN_A + 4;         // plane stride of planes 2, 3 (candidate-gate rows only); +4 as PSTRIDE
 constexpr int PART_LO = 2 * PSTRIDE;  // planes 0, 1: all 1152 gate rows
 constexpr int PART_HI = 2 * PN;       // planes 2, 3
-#ifndef FPC2_DBG_NS
-#define FPC2_DBG_NS 2
-#endif
 #ifndef FPC2_ABL
-#define FPC2_ABL 0  // timing-only ablations (bit 0: no sparse-product FMAs, 1: no window work, 2: gates of utterance 0 only)
+#define FPC2_ABL 0  // timing-only ablations, results wrong (bits: 1 no sparse-product FMAs, 2 no window work, 4 gates of utterance 0 only
+                    // in the two-utterance path, 8 / 16 / 32 no GRU_B products / butterfly / gate activations); reported by fpc_build_info
 #endif
 #ifndef FPC2_GPRIO_PAIR
 #define FPC2_GPRIO_PAIR 3
