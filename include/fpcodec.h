@@ -31,7 +31,7 @@ extern "C" {
  * 3: exports fpc_kmeans1d (scalar-codebook k-means) and fpc_predictor_fallback_groups; fpc_predictor_forward keeps a scratch
  *    block in the handle (relu(h2) of all frames for the batched output layer).
  * 4: exports fpc_lpcnet_set_pairing and fpc_lpcnet_last_streams_per_workgroup (fpc_lpcnet_synthesize decodes two utterances
- *    per workgroup when the batch exceeds the device's compute units). */
+ *    per workgroup when the batch exceeds the device's compute units) and fpc_selftest. */
 #define FPC_ABI_VERSION 4
 #define FPC_API __attribute__((visibility("default")))
 
