@@ -18,7 +18,7 @@ SYMBOLS = [
     "fpc_lpcnet_create", "fpc_lpcnet_destroy", "fpc_lpcnet_workspace_bytes",
     "fpc_lpcnet_synthesize", "fpc_lpcnet_condition", "fpc_lpcnet_last_decode_ms",
     "fpc_lpcnet_kernel_variant", "fpc_lpcnet_set_chunk_frames", "fpc_lpcnet_set_pairing",
-    "fpc_lpcnet_last_streams_per_workgroup",
+    "fpc_lpcnet_last_streams_per_workgroup", "fpc_lpcnet_paired_utterances",
     "fpc_trainer_create", "fpc_trainer_destroy", "fpc_trainer_step", "fpc_trainer_export",
     "fpc_cb_workspace_bytes", "fpc_cb_find_nearest", "fpc_cb_update", "fpc_cb_mean0", "fpc_kmeans1d",
 ]
@@ -86,6 +86,7 @@ def lib():
         L.fpc_lpcnet_set_chunk_frames.argtypes = [C.c_void_p, C.c_int]
         L.fpc_lpcnet_set_pairing.argtypes = [C.c_void_p, C.c_int]
         L.fpc_lpcnet_last_streams_per_workgroup.argtypes = [C.c_void_p]
+        L.fpc_lpcnet_paired_utterances.argtypes = [C.c_int, C.c_int]
         L.fpc_trainer_create.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
         L.fpc_trainer_destroy.argtypes = [C.c_void_p]
         L.fpc_trainer_step.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_double, C.POINTER(C.c_float),

@@ -208,6 +208,20 @@ static int decode_variant_of(const int (&gate_qp)[3]) {
     return 1616;
 }
 
+// the default mapping's split (fpcodec.h): how many of B utterances go two per workgroup on a device of `cus` compute units
+extern "C" int fpc_lpcnet_paired_utterances(int B, int cus) {
+    if (cus <= 0) cus = 256;
+    if (B <= cus) return 0;
+    int NP = 0;
+    double best = 1e30;
+    for (int p = 0; p <= (B + 2 * cus - 1) / (2 * cus); ++p) {
+        const int np = std::min(B, 2 * cus * p), rest = B - np;
+        const double cost = 1.7 * p + (rest + cus - 1) / cus;  // a paired round of 2 x cus utterances ~ 1.7 plain rounds of cus
+        if (cost < best - 1e-9) best = cost, NP = np;
+    }
+    return NP;
+}
+
 extern "C" int fpc_lpcnet_set_pairing(fpc_lpcnet* m, int mode) {
     FPC_REQUIRE(m && mode >= -1 && mode <= 1, "fpc_lpcnet_set_pairing: bad argument");
     m->pairing = mode;
@@ -671,15 +685,7 @@ extern "C" int fpc_lpcnet_synthesize(fpc_lpcnet* m, const float* features_dev, i
     // CUs < B <= 2 CUs: all paired; 2 CUs < B <= 3 CUs: one pair round + one round of k_decode; ...  pairing 1: all paired.
     int NP = 0;
     if (m->pair_ok && B > 1 && m->pairing > 0) NP = B;
-    if (m->pair_ok && B > 1 && m->pairing == 0 && B > m->cus) {
-        const int cu = m->cus > 0 ? m->cus : 256;
-        double best = 1e30;
-        for (int p = 0; p <= (B + 2 * cu - 1) / (2 * cu); ++p) {
-            const int np = std::min(B, 2 * cu * p), rest = B - np;
-            const double cost = 1.7 * p + (rest + cu - 1) / cu;
-            if (cost < best - 1e-9) best = cost, NP = np;
-        }
-    }
+    if (m->pair_ok && m->pairing == 0) NP = fpc_lpcnet_paired_utterances(B, m->cus);
     const bool pair = NP > 0;
     m->last_streams_per_wg = pair ? 2 : 1;
     DecodeParams P2 = P;  // k_decode2's launch: its own placement of the row groups

@@ -31,7 +31,7 @@ extern "C" {
  * 3: exports fpc_kmeans1d (scalar-codebook k-means) and fpc_predictor_fallback_groups; fpc_predictor_forward keeps a scratch
  *    block in the handle (relu(h2) of all frames for the batched output layer).
  * 4: exports fpc_lpcnet_set_pairing and fpc_lpcnet_last_streams_per_workgroup (fpc_lpcnet_synthesize decodes two utterances
- *    per workgroup when the batch exceeds the device's compute units) and fpc_selftest. */
+ *    per workgroup when the batch exceeds the device's compute units), fpc_lpcnet_paired_utterances and fpc_selftest. */
 #define FPC_ABI_VERSION 4
 #define FPC_API __attribute__((visibility("default")))
 
@@ -292,6 +292,9 @@ FPC_API int fpc_lpcnet_set_chunk_frames(fpc_lpcnet* m, int frames);
  * 4 lanes (fpc_lpcnet_kernel_variant 1616), or whose row groups do not fit the mat-vec lanes once padded to even widths,
  * always take one utterance per workgroup. */
 FPC_API int fpc_lpcnet_set_pairing(fpc_lpcnet* m, int mode);
+/* The split mode 0 makes (a pure function, no device needed): of B utterances on a device of `cus` compute units, how many --
+ * the first ones of the batch -- go two per workgroup; the rest go one per workgroup in one more round.  0 for B <= cus. */
+FPC_API int fpc_lpcnet_paired_utterances(int B, int cus);
 /* utterances per workgroup of the last fpc_lpcnet_synthesize on this handle: 1 or 2 (0 before the first call, <0 on a
  * null handle) */
 FPC_API int fpc_lpcnet_last_streams_per_workgroup(const fpc_lpcnet* m);

@@ -49,6 +49,24 @@ def test_binding_names_a_library_of_another_abi_version(built, tmp_path, monkeyp
         built.lib()
 
 
+def test_default_mapping_of_utterances_onto_workgroups(built):
+    """fpc_lpcnet_paired_utterances: the split fpc_lpcnet_synthesize makes by default (include/fpcodec.h).  Nothing paired up to the
+    CU count; everything up to twice that; then paired rounds plus one plain round where that is cheaper; never dearer than rounds
+    of one utterance per workgroup (a paired round of 2 x CUs counts 1.7 plain rounds)"""
+    f = built.lib().fpc_lpcnet_paired_utterances
+    cus = 256
+    assert [f(b, cus) for b in (1, 2, 255, 256)] == [0, 0, 0, 0]
+    assert [f(b, cus) for b in (257, 300, 384, 512)] == [257, 300, 384, 512]
+    assert [f(b, cus) for b in (513, 600, 768)] == [512, 512, 512]       # one paired round + one plain round
+    assert [f(b, cus) for b in (769, 1000, 1024)] == [769, 1000, 1024]   # two paired rounds
+    assert f(1100, cus) == 1024 and f(10, 4) == 8 and f(9, 4) == 8 and f(5, 4) == 5
+    for b in range(1, 3000, 7):
+        npair = f(b, cus)
+        assert 0 <= npair <= b and (npair == b or npair % (2 * cus) == 0)
+        cost = 1.7 * -(-npair // (2 * cus)) + -(-(b - npair) // cus)
+        assert cost <= -(-b // cus) + 1e-9, b
+
+
 def test_device_buffer_is_empty_after_a_failed_allocation(built):
     """ADVICE round 5: DevBuf::alloc wrote the size before hipMalloc; a failed grow left p == NULL with the new size, and a later,
     smaller forward call would have launched on the null block.  fpc_selftest exercises the failure (no device here: every
