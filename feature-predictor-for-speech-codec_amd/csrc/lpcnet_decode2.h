@@ -45,10 +45,10 @@ constexpr int PART_HI = 2 * PN;       // planes 2, 3
 #define FPC2_PRIO3 1
 #endif
 #ifndef FPC2_N1
-#define FPC2_N1 14  // column steps (of 32: 16 of utterance 0, then 16 of utterance 1) of the sparse product under GRU_B ...
+#define FPC2_N1 13  // column steps (of 32: 16 of utterance 0, then 16 of utterance 1) of the sparse product under GRU_B ...
 #endif
 #ifndef FPC2_N2
-#define FPC2_N2 11  // ... and under the dual FC; the rest under the draw
+#define FPC2_N2 12  // ... and under the dual FC; the rest under the draw
 #endif
 
 // Field order matters (as in DecodeLds): everything a lane addresses with a lane-constant register plus a constant sits in
@@ -331,20 +331,28 @@ __global__ __launch_bounds__(NTHREADS) void k_decode2(const DecodeParams P, cons
 #define FPC2_STEPS(FROM, TO)                                                                                      \
     _Pragma("unroll") for (int k = (FROM); k < (TO); ++k) {                                                       \
         const int s = k >> 4, bc = k & 15;                                                                        \
+        /* state reads run ahead of their columns: the second half's (columns 8..15) four columns early, the LDS-resident   \
+           weights eight, the NEXT utterance's first half (its registers are free after column 7) four columns before  \
+           this product ends -- only utterance 0's first read, right behind barrier Y, is waited for */               \
         if (bc == 0) {                                                                                            \
             _Pragma("unroll") for (int rp = 0; rp < 4; ++rp) acc[rp] = a[rp] = splat2(0.0f);                      \
+        }                                                                                                         \
+        if ((bc == 0 && s == 0) || (bc == 12 && s == 0)) {                                                        \
+            const int sn = bc == 0 ? 0 : 1;                                                                       \
             const unsigned colp = opaque(colp_);                                                                  \
-            const float4 ha = *reinterpret_cast<const float4*>(&L.S[s].s1[(colp & 0xff) * 4]);                    \
-            const float4 hb = *reinterpret_cast<const float4*>(&L.S[s].s1[((colp >> 8) & 0xff) * 4]);             \
+            const float4 ha = *reinterpret_cast<const float4*>(&L.S[sn].s1[(colp & 0xff) * 4]);                   \
+            const float4 hb = *reinterpret_cast<const float4*>(&L.S[sn].s1[((colp >> 8) & 0xff) * 4]);            \
             hv0[0] = ha.x, hv0[1] = ha.y, hv0[2] = ha.z, hv0[3] = ha.w;                                           \
             hv0[4] = hb.x, hv0[5] = hb.y, hv0[6] = hb.z, hv0[7] = hb.w;                                           \
         }                                                                                                         \
-        if (bc == 8) {                                                                                            \
+        if (bc == 4) {                                                                                            \
             const unsigned colp = opaque(colp_);                                                                  \
             const float4 hc = *reinterpret_cast<const float4*>(&L.S[s].s1[((colp >> 16) & 0xff) * 4]);            \
             const float4 hd = *reinterpret_cast<const float4*>(&L.S[s].s1[(colp >> 24) * 4]);                     \
             hv1[0] = hc.x, hv1[1] = hc.y, hv1[2] = hc.z, hv1[3] = hc.w;                                           \
             hv1[4] = hd.x, hv1[5] = hd.y, hv1[6] = hd.z, hv1[7] = hd.w;                                           \
+        }                                                                                                         \
+        if (bc == 8) {                                                                                            \
             const unsigned mlx = opaque((unsigned)ml_);                                                           \
             const float4 l0 = L.lw[mlx], l1 = L.lw[NMAT + mlx], l2 = L.lw[2 * NMAT + mlx];                        \
             wl[0] = mk2(l0.x, l0.y), wl[1] = mk2(l0.z, l0.w), wl[2] = mk2(l1.x, l1.y);                            \
@@ -358,8 +366,8 @@ __global__ __launch_bounds__(NTHREADS) void k_decode2(const DecodeParams P, cons
                              splat2(hv1[bc - 8]), a[rp]);                                                         \
         }                                                                                                         \
         if (bc == 15) {                                                                                           \
+            _Pragma("unroll") for (int rp = 0; rp < 4; ++rp) acc[rp] = acc[rp] + a[rp];                           \
             _Pragma("unroll") for (int rp = 0; rp < 4; ++rp) {                                                    \
-                acc[rp] = acc[rp] + a[rp];                                                                        \
                 acc[rp].x = acc[rp].x + dpp_f<DPP_ROW_SHL + 1>(acc[rp].x); /* + the next lane's: tree level 1 */  \
                 acc[rp].y = acc[rp].y + dpp_f<DPP_ROW_SHL + 1>(acc[rp].y);                                        \
             }                                                                                                     \
@@ -555,6 +563,10 @@ __global__ __launch_bounds__(NTHREADS) void k_decode2(const DecodeParams P, cons
         const float ub0 = P.lane_ub[sl], ub1 = P.lane_ub[NSAMP + sl], ub2 = P.lane_ub[2 * NSAMP + sl];
         const float brnb = P.brn_b[u];
         const float my_ulaw = P.ulaw_tab[sl];
+        // this wave's utterance's PCM: kernel argument + offset, so that the store in the sample loop is a global_store -- as a
+        // FLAT store (what indexing a pointer array by the wave gives) it leaves the waitcnt bookkeeping with a pending flat
+        // operation, and every LDS wait of the loop then becomes lgkmcnt(0): the staged reads lose their stagger
+        int16_t* const out_dw = P.pcm + (size_t)(dw ? bs[1] : bs[0]) * T * FPC_FRAME_SIZE;
         float mem = resume ? rec[dw][RNN_A + 36] : 0.0f;
         float pcm_new = 0.0f;
         float s2_own[2];
@@ -657,18 +669,43 @@ __global__ __launch_bounds__(NTHREADS) void k_decode2(const DecodeParams P, cons
                     for (int s = 0; s < 2; ++s)
 #pragma unroll
                         for (int g = 0; g < 3; ++g) acc[s][g][0] = acc[s][g][1] = splat2(0.0f);
+#if !(FPC2_ABL & 8)
+                    {
+                        // twelve state reads (six per utterance) through FOUR register quads, always four reads ahead of the
+                        // products: the quads are consumed in the order A0..A3 B0..B3 A4 A5 B4 B5 (per utterance ascending: the
+                        // chains' order), and the quad a step frees takes the read four steps ahead -- every read has three
+                        // steps (18 packed FMAs) in front of its use.  (Left to itself the compiler alternates the utterances
+                        // and consumes each late read right after issuing it: eight exposed LDS round trips.)
+                        float4 hq[4];
+#define FPC2_GB_STEP_S(q) ((q) < 4 ? 0 : (q) < 8 ? 1 : (q) < 10 ? 0 : 1)
+#define FPC2_GB_STEP_M(q) ((q) < 4 ? (q) : (q) < 8 ? (q) - 4 : (q) < 10 ? (q) - 4 : (q) - 6)
+#define FPC2_GB_READ(q) \
+    hq[(q) & 3] = *reinterpret_cast<const float4*>(&L.S[FPC2_GB_STEP_S(q)].s1[24 * klv + 4 * (klv >> 3) + 4 * FPC2_GB_STEP_M(q)]);
+                        FPC2_GB_READ(0)
+                        FPC2_GB_READ(1)
+                        FPC2_GB_READ(2)
+                        FPC2_GB_READ(3)
 #pragma unroll
-                    for (int m = 0; m < (FPC2_ABL & 8 ? 0 : 6); ++m) {
-#pragma unroll
-                        for (int s = 0; s < 2; ++s) {
-                            const float4 h4 = *reinterpret_cast<const float4*>(&L.S[s].s1[24 * klv + 4 * (klv >> 3) + 4 * m]);
+                        for (int q = 0; q < 12; ++q) {
+                            __builtin_amdgcn_sched_barrier(0);
+                            const int s = FPC2_GB_STEP_S(q), m = FPC2_GB_STEP_M(q);
+                            const float4 h4 = hq[q & 3];
 #pragma unroll
                             for (int g = 0; g < 3; ++g) {
                                 acc[s][g][0] = fma2(wB[g][m][0], mk2(h4.x, h4.y), acc[s][g][0]);
                                 acc[s][g][1] = fma2(wB[g][m][1], mk2(h4.z, h4.w), acc[s][g][1]);
                             }
+                            __builtin_amdgcn_sched_barrier(0);
+                            if (q + 4 < 12) {
+                                FPC2_GB_READ(q + 4)
+                            }
                         }
+                        __builtin_amdgcn_sched_barrier(0);
+#undef FPC2_GB_READ
+#undef FPC2_GB_STEP_S
+#undef FPC2_GB_STEP_M
                     }
+#endif
                     float a3[2][3];
 #pragma unroll
                     for (int s = 0; s < 2; ++s)
@@ -818,7 +855,7 @@ __global__ __launch_bounds__(NTHREADS) void k_decode2(const DecodeParams P, cons
                 FPC_BARRIER(4)  // X
                 if (wave < 2) {
                     mem = fmaf(FPC_PREEMPH, mem, pcm_new);
-                    if (lane == 0) out[dw][t] = fpc_pcm16(mem);
+                    if (lane == 0) out_dw[t] = fpc_pcm16(mem);
                 }
             }
         }
