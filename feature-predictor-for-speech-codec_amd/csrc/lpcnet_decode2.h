@@ -58,7 +58,7 @@ constexpr int PART_HI = 2 * PN;       // planes 2, 3
 struct __attribute__((aligned(16))) PairStream {
     float s1[RNN_A + 4];  // units 192..383 sit 4 floats up (s1_at): GRU_B's sixteen 24-unit slices then start in sixteen
                           // different bank quads (6 kl + (kl >> 3) mod 16), its reads are conflict-free
-    float cfa[GA];
+    float4 cfa4[RNN_A];  // this frame's GRU_A conditioning values of a unit as (z, r, h, -): one ds_read_b128 per gate job
     float s2[RNN_B];
     float hist[16];
     unsigned o_sig, o_pred, o_exc;
@@ -74,8 +74,7 @@ struct __attribute__((aligned(16))) PairStreamFar {
 };
 struct __attribute__((aligned(16))) Decode2Lds {
     PairStream S[2];
-    float diag[GA];
-    float brn_a[RNN_A];
+    float4 cdiag[RNN_A];  // per unit (diagonal z, r, h; recurrent bias of the candidate gate): one ds_read_b128 per gate job
     float ulaw_thr[64];
     float2 tt[FPC_TANH_TABLE_SIZE - 1];
     PairStreamFar F[2];
@@ -235,9 +234,8 @@ __global__ __launch_bounds__(NTHREADS) void k_decode2(const DecodeParams P, cons
     for (int i = tid; i < RNN_A; i += NTHREADS) {
 #pragma unroll
         for (int s = 0; s < 2; ++s) L.S[s].s1[s1_at(i)] = resume ? rec[s][i] : 0.0f;
-        L.brn_a[i] = P.brn_a[i];
+        L.cdiag[i] = make_float4(P.diag[i], P.diag[RNN_A + i], P.diag[2 * RNN_A + i], P.brn_a[i]);
     }
-    for (int i = tid; i < GA; i += NTHREADS) L.diag[i] = P.diag[i];
     for (int i = tid; i < PART_LO + PART_HI; i += NTHREADS) L.F[0].part[i] = L.F[1].part[i] = 0.0f;
     if (tid < 64) L.ulaw_thr[tid] = k_ulaw_thr[tid];
     for (int k = tid; k < FPC_TANH_TABLE_SIZE - 1; k += NTHREADS) {
@@ -404,9 +402,7 @@ __global__ __launch_bounds__(NTHREADS) void k_decode2(const DecodeParams P, cons
             for (int s = 0; s < 2; ++s) {
                 if (wave < 8 || (wave >= 10) == (s == 1)) {
                     const float* cfa = P.cfa + ((size_t)bs[s] * P.cf_T + (fr - P.f0)) * GA;
-                    L.S[s].cfa[gu_] = cfa[gu_];
-                    L.S[s].cfa[RNN_A + gu_] = cfa[RNN_A + gu_];
-                    L.S[s].cfa[2 * RNN_A + gu_] = cfa[2 * RNN_A + gu_];
+                    L.S[s].cfa4[gu_] = make_float4(cfa[gu_], cfa[RNN_A + gu_], cfa[2 * RNN_A + gu_], 0.0f);
                 }
             }
             for (int i = (fr == 0 ? FPC_LPC_ORDER + 1 : 0); i < FPC_FRAME_SIZE; ++i) {
@@ -435,9 +431,10 @@ __global__ __launch_bounds__(NTHREADS) void k_decode2(const DecodeParams P, cons
                     const float h_own = S.s1[ml + 4];  // (units 256..383: s1_at = + 4)
                     float unb, uz, ur;
                     {
-                        const float dn = L.diag[2 * RNN_A + ml], bn = L.brn_a[ml];
+                        const float4 cd = L.cdiag[ml];
+                        const float dn = cd.z, bn = cd.w;
                         const float n0 = pl[2 * RNN_A], n1 = pl[2 * RNN_A + PSTRIDE], n2 = pl[PART_LO], n3 = pl[PART_LO + PN];
-                        const float dz = L.diag[ml], dr = L.diag[RNN_A + ml];
+                        const float dz = cd.x, dr = cd.y;
                         const float z0 = pl[0], r0 = pl[RNN_A];
                         float tz = z0, tr = r0;
                         if (QZR == 4) {
@@ -452,7 +449,8 @@ __global__ __launch_bounds__(NTHREADS) void k_decode2(const DecodeParams P, cons
                         uz = fmaf(dz, h_own, tz);
                         ur = fmaf(dr, h_own, tr);
                     }
-                    const float cz = S.cfa[ml], cr = S.cfa[RNN_A + ml], cn = S.cfa[2 * RNN_A + ml];
+                    const float4 cf = S.cfa4[ml];
+                    const float cz = cf.x, cr = cf.y, cn = cf.z;
                     __builtin_amdgcn_sched_barrier(0);
                     LutReq qz, qr, qn;
                     lut_issue(L.tt, qz, (((ta.x + tb.x) + tc.x) + cz) + uz, 256.0f);
@@ -478,7 +476,8 @@ __global__ __launch_bounds__(NTHREADS) void k_decode2(const DecodeParams P, cons
                     // while the six rows are in flight: recurrent terms of the unit's three rows (diagonal + the upper levels of
                     // the tree over the pair planes).  The diagonal / bias values once for both utterances; each utterance's
                     // state value and eight plane values as one round of reads, the second requested before the first is used
-                    const float dz = L.diag[ml], dr = L.diag[RNN_A + ml], dn = L.diag[2 * RNN_A + ml], bn = L.brn_a[ml];
+                    const float4 cd = L.cdiag[ml];
+                    const float dz = cd.x, dr = cd.y, dn = cd.z, bn = cd.w;
                     float h_own[2], cz[2], cr[2], cn[2], unb[2], uz[2], ur[2];
 #pragma unroll
                     for (int s = 0; s < (FPC2_ABL & 4 ? 1 : 2); ++s) {
@@ -492,7 +491,8 @@ __global__ __launch_bounds__(NTHREADS) void k_decode2(const DecodeParams P, cons
                         unb[s] = fmaf(dn, h_own[s], (pn[0] + pn[1]) + (pn[2] + pn[3])) + bn;
                         uz[s] = fmaf(dz, h_own[s], QZR == 4 ? pz[0] + pz[1] : pz[0]);
                         ur[s] = fmaf(dr, h_own[s], QZR == 4 ? pr[0] + pr[1] : pr[0]);
-                        cz[s] = L.S[s].cfa[ml], cr[s] = L.S[s].cfa[RNN_A + ml], cn[s] = L.S[s].cfa[2 * RNN_A + ml];
+                        const float4 cf = L.S[s].cfa4[ml];
+                        cz[s] = cf.x, cr[s] = cf.y, cn[s] = cf.z;
                         __builtin_amdgcn_sched_barrier(0);
                     }
                     // gates: utterance 1 half a step behind utterance 0 (its arithmetic hides the other's table read)
