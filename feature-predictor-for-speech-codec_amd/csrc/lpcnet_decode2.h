@@ -569,19 +569,22 @@ __global__ __launch_bounds__(NTHREADS) void k_decode2(const DecodeParams P, cons
         int16_t* const out_dw = P.pcm + (size_t)(dw ? bs[1] : bs[0]) * T * FPC_FRAME_SIZE;
         float mem = resume ? rec[dw][RNN_A + 36] : 0.0f;
         float pcm_new = 0.0f;
-        float s2_own[2];
-#pragma unroll
-        for (int s = 0; s < 2; ++s) s2_own[s] = resume ? rec[s][RNN_A + u] : 0.0f;
+        // GRU_B's gates: after the row butterfly all 16 lanes of a unit's row hold both utterances' three sums; lanes 0..7
+        // of the row evaluate utterance 0's gates, lanes 8..15 utterance 1's (one triple of table activations per lane
+        // instead of two), and lanes 0 / 8 store the new state value
+        const bool hb = (kl & 8) != 0;
+        float s2_mine = resume ? rec[hb ? 1 : 0][RNN_A + u] : 0.0f;
         if (P.state != nullptr) __syncthreads();
 
         for (int fr = P.f0; fr < P.f1; ++fr) {
-            float shape_e[2], cfb_z[2], cfb_r[2], cfb_n[2], a_cur[2], a_nxt[2], a0_cur[2], a0_nxt[2];
+            float shape_e[2], a_cur[2], a_nxt[2], a0_cur[2], a0_nxt[2];
+            float cfb_z, cfb_r, cfb_n;  // of this lane's utterance (hb)
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
                 const float* feat = P.features + ((size_t)bs[s] * T + fr) * FPC_NB_FEATURES;
                 shape_e[s] = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(fpc_shape_exponent(feat[19]))));
                 const float* cfb = P.cfb + ((size_t)bs[s] * P.cf_T + (fr - P.f0)) * GB;
-                cfb_z[s] = cfb[u], cfb_r[s] = cfb[RNN_B + u], cfb_n[s] = cfb[2 * RNN_B + u];
+                if (hb == (s == 1)) cfb_z = cfb[u], cfb_r = cfb[RNN_B + u], cfb_n = cfb[2 * RNN_B + u];
                 const float* fa = feat + (FPC_NB_FEATURES - FPC_LPC_ORDER);
                 const float* fan = fa + (fr + 1 < T ? FPC_NB_FEATURES : 0);
                 a_cur[s] = fa[kl], a_nxt[s] = fan[kl];
@@ -720,38 +723,25 @@ __global__ __launch_bounds__(NTHREADS) void k_decode2(const DecodeParams P, cons
                     FPC2_FC_LOADW(0)
                     FPC2_FC_LOADW(1)
                     bf = L.fcw[8 * NSAMP + slv];
-                    // gates, utterance 1 half a step behind utterance 0
-                    LutReq qz[2], qr[2], qn[2];
+                    // gates of this lane's utterance
+                    {
+                        const float xz = hb ? a3[1][0] : a3[0][0], xr = hb ? a3[1][1] : a3[0][1], xn = hb ? a3[1][2] : a3[0][2];
+                        const float uz_ = hb ? ub_z[1] : ub_z[0], ur_ = hb ? ub_r[1] : ub_r[0], un_ = hb ? ub_n[1] : ub_n[0];
 #if FPC2_ABL & 32
-#pragma unroll
-                    for (int s = 0; s < 2; ++s) {
-                        const float z = 0.5f + 1e-3f * a3[s][0], n = 1e-3f * (a3[s][1] + a3[s][2]);
-                        s2_own[s] = fmaf(z, s2_own[s] - n, n);
-                        if (kl == 0) L.S[s].s2[u] = s2_own[s];
-                    }
+                        const float z = 0.5f + 1e-3f * xz, n = 1e-3f * (xr + xn);
 #else
-                    lut_issue(L.tt, qz[0], (a3[0][0] + cfb_z[0]) + ub_z[0], 256.0f);
-                    lut_issue(L.tt, qr[0], (a3[0][1] + cfb_r[0]) + ub_r[0], 256.0f);
-                    __builtin_amdgcn_sched_barrier(0);
-                    lut_issue(L.tt, qz[1], (a3[1][0] + cfb_z[1]) + ub_z[1], 256.0f);
-                    lut_issue(L.tt, qr[1], (a3[1][1] + cfb_r[1]) + ub_r[1], 256.0f);
-                    __builtin_amdgcn_sched_barrier(0);
-                    float zg[2];
-#pragma unroll
-                    for (int s = 0; s < 2; ++s) {
-                        zg[s] = fmaf(0.5f, lut_finish(qz[s]), 0.5f);
-                        const float r = fmaf(0.5f, lut_finish(qr[s]), 0.5f);
-                        lut_issue(L.tt, qn[s], fmaf(r, ub_n[s] + brnb, a3[s][2] + cfb_n[s]), 512.0f);
+                        LutReq qz, qr, qn;
+                        lut_issue(L.tt, qz, (xz + cfb_z) + uz_, 256.0f);
+                        lut_issue(L.tt, qr, (xr + cfb_r) + ur_, 256.0f);
                         __builtin_amdgcn_sched_barrier(0);
-                    }
-#pragma unroll
-                    for (int s = 0; s < 2; ++s) {
-                        const float n = lut_finish(qn[s]);
-                        s2_own[s] = fmaf(zg[s], s2_own[s] - n, n);
-                        if (kl == 0) L.S[s].s2[u] = s2_own[s];
+                        const float z = fmaf(0.5f, lut_finish(qz), 0.5f);
+                        lut_issue(L.tt, qn, fmaf(fmaf(0.5f, lut_finish(qr), 0.5f), un_ + brnb, xn + cfb_n), 512.0f);
                         __builtin_amdgcn_sched_barrier(0);
-                    }
+                        const float n = lut_finish(qn);
 #endif
+                        s2_mine = fmaf(z, s2_mine - n, n);
+                        if ((kl & 7) == 0) (hb ? L.S[1].s2 : L.S[0].s2)[u] = s2_mine;
+                    }
                 }
                 FPC_BARRIER(1)  // Z1
                 // ---- Z1..Z2: dual FC of tree node `sl`, both utterances; weights from LDS, read once, two chunks ahead ----
