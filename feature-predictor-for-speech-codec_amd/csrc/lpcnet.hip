@@ -157,6 +157,7 @@ void lpcnet_build_info(std::string& out) {
     FPC_TUNE("FPC2_N1", FPC2_N1, 13)
     FPC_TUNE("FPC2_N2", FPC2_N2, 12)
     FPC_TUNE("FPC2_PRIO3", FPC2_PRIO3, 1)
+    FPC_TUNE("FPC2_WPRIO", FPC2_WPRIO, 0)
     FPC_TUNE("FPC2_GPRIO_PAIR", FPC2_GPRIO_PAIR, 3)
     FPC_TUNE("FPC2_GPRIO_SINGLE", FPC2_GPRIO_SINGLE, 3)
     FPC_TUNE("FPC2_ABL", FPC2_ABL, 0)
@@ -216,7 +217,7 @@ extern "C" int fpc_lpcnet_paired_utterances(int B, int cus) {
     double best = 1e30;
     for (int p = 0; p <= (B + 2 * cus - 1) / (2 * cus); ++p) {
         const int np = std::min(B, 2 * cus * p), rest = B - np;
-        const double cost = 1.7 * p + (rest + cus - 1) / cus;  // a paired round of 2 x cus utterances ~ 1.7 plain rounds of cus
+        const double cost = 1.56 * p + (rest + cus - 1) / cus;  // a paired round of 2 x cus utterances ~ 1.56 plain rounds of cus
         if (cost < best - 1e-9) best = cost, NP = np;
     }
     return NP;
@@ -680,8 +681,8 @@ extern "C" int fpc_lpcnet_synthesize(fpc_lpcnet* m, const float* features_dev, i
     // More utterances than compute units: k_decode2 walks two utterances through each workgroup (lpcnet_decode2.h; the
     // packed partial-sum planes exist for the instances whose update / reset row groups are <= 4 lanes wide).  Same PCM.
     // The batch is decoded as its first NP utterances on k_decode2 (NP / 2 workgroups) and the rest on k_decode.  Default
-    // policy (pairing 0): a round of k_decode2 (2 x CUs utterances) costs about 1.7 rounds of k_decode (CUs utterances
-    // each); take the number of full-or-partial pair rounds p that minimises 1.7 p + ceil(rest / CUs) -- B <= CUs: none;
+    // policy (pairing 0): a round of k_decode2 (2 x CUs utterances) costs about 1.56 rounds of k_decode (CUs utterances
+    // each); take the number of full-or-partial pair rounds p that minimises 1.56 p + ceil(rest / CUs) -- B <= CUs: none;
     // CUs < B <= 2 CUs: all paired; 2 CUs < B <= 3 CUs: one pair round + one round of k_decode; ...  pairing 1: all paired.
     int NP = 0;
     if (m->pair_ok && B > 1 && m->pairing > 0) NP = B;

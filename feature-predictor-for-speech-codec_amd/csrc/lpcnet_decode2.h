@@ -20,10 +20,17 @@
 // (fpc_lpcnet_create pads the row groups to even widths in a second placement; an all-zero lane is the tree's +0 padding).
 // Table activations and mu-law lookups come in two halves (issue / finish): waves issue in order, so what hides an LDS
 // round trip is the other utterance's arithmetic placed between a read and its use, by hand (sched_barrier fences).
+// The same holds for the loops' LDS reads: GRU_B's state quads are read on a fixed schedule four quads ahead of the products
+// that consume them, the mat-vec waves' state columns and LDS-resident weights a few column steps ahead (FPC2_STEPS).
+// GRU_B's gates run on half-rows (lanes 0..7 of a unit's row finish utterance 0, lanes 8..15 utterance 1); a unit's
+// per-frame and per-model constants are packed (cfa4, cdiag: one ds_read_b128 per gate job).
+// The PCM goes out through a pointer the compiler can see is GLOBAL (kernarg base + offset): a FLAT store in the sample
+// loop leaves the wait-count pass with a pending flat access, after which every LDS wait in the loop becomes lgkmcnt(0).
 // Every value is produced by the same operations in the same order as in k_decode (and in
 // oracle/fpc_oracle.c::orc_lpcnet_synthesize): the PCM is bit-identical, whichever kernel decodes an utterance.
 // Launched by fpc_lpcnet_synthesize for batches larger than the device's CU count (fpc_lpcnet_set_pairing overrides);
-// 512 x 3 s in 110 ms against 131 ms as two rounds of k_decode.  What was tried and what it stops at: profiles/r06_ablations.txt.
+// 512 x 3 s in 102.7 ms against 131.7 ms as two rounds of k_decode (1.28x).  What was tried, what each step bought and what
+// bounds it now: profiles/r06_ablations.txt.
 #pragma once
 
 // A plane holds the sums of TWO adjacent lanes of a row group (lanes 2k, 2k+1 add their eight row sums -- the first level
@@ -40,6 +47,9 @@ constexpr int PART_HI = 2 * PN;       // planes 2, 3
 #endif
 #ifndef FPC2_GPRIO_SINGLE
 #define FPC2_GPRIO_SINGLE 3
+#endif
+#ifndef FPC2_WPRIO
+#define FPC2_WPRIO 0  // priority of the sampler waves' window work (the gate waves run at 3)
 #endif
 #ifndef FPC2_PRIO3
 #define FPC2_PRIO3 1
@@ -600,7 +610,7 @@ __global__ __launch_bounds__(NTHREADS) void k_decode2(const DecodeParams P, cons
                 const int st_t = t;
                 const bool stamp_on = STAMP && blockIdx.x == 0 && st_t >= FPC_STAMP_T0 && st_t < FPC_STAMP_T0 + FPC_STAMP_NS;
 #if FPC_PRIO
-                __builtin_amdgcn_s_setprio(0);
+                __builtin_amdgcn_s_setprio(FPC2_WPRIO);
 #endif
                 // ---- X..Y: GRU_B recurrent parts, LPC taps, leaf candidates of both utterances: one round of state reads,
                 //      one eight-way butterfly (GRU_B's three recurrent sums and the tap tree, per utterance), the four

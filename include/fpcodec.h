@@ -285,7 +285,7 @@ FPC_API int fpc_lpcnet_set_chunk_frames(fpc_lpcnet* m, int frames);
  * FPC_LPCNET_PAIRING sets the default of new handles): one utterance per workgroup (k_decode) while B <= the device's
  * compute units; for larger batches -- the grid of B workgroups would run in rounds -- the first part of the batch goes two
  * utterances per workgroup (k_decode2: both walk the sample loop in lockstep and share the weights in registers / LDS, every
- * barrier and every L2 round trip; a round of 2 x CUs utterances costs about 1.7 rounds of k_decode) and the rest, if that
+ * barrier and every L2 round trip; a round of 2 x CUs utterances costs about 1.56 rounds of k_decode) and the rest, if that
  * is cheaper, as one more round of k_decode: all paired for CUs < B <= 2 CUs, one paired round + one plain round for
  * 2 CUs < B <= 3 CUs, and so on.  mode 1: all utterances paired (B >= 2); mode -1: never.  The PCM of an utterance does not
  * depend on the mapping (same operations in the same order; tests).  Models whose update / reset row groups are wider than

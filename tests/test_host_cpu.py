@@ -52,7 +52,7 @@ def test_binding_names_a_library_of_another_abi_version(built, tmp_path, monkeyp
 def test_default_mapping_of_utterances_onto_workgroups(built):
     """fpc_lpcnet_paired_utterances: the split fpc_lpcnet_synthesize makes by default (include/fpcodec.h).  Nothing paired up to the
     CU count; everything up to twice that; then paired rounds plus one plain round where that is cheaper; never dearer than rounds
-    of one utterance per workgroup (a paired round of 2 x CUs counts 1.7 plain rounds)"""
+    of one utterance per workgroup (a paired round of 2 x CUs counts 1.56 plain rounds)"""
     f = built.lib().fpc_lpcnet_paired_utterances
     cus = 256
     assert [f(b, cus) for b in (1, 2, 255, 256)] == [0, 0, 0, 0]
@@ -63,7 +63,7 @@ def test_default_mapping_of_utterances_onto_workgroups(built):
     for b in range(1, 3000, 7):
         npair = f(b, cus)
         assert 0 <= npair <= b and (npair == b or npair % (2 * cus) == 0)
-        cost = 1.7 * -(-npair // (2 * cus)) + -(-(b - npair) // cus)
+        cost = 1.56 * -(-npair // (2 * cus)) + -(-(b - npair) // cus)
         assert cost <= -(-b // cus) + 1e-9, b
 
 
