@@ -158,6 +158,8 @@ void lpcnet_build_info(std::string& out) {
     FPC_TUNE("FPC2_N2", FPC2_N2, 12)
     FPC_TUNE("FPC2_PRIO3", FPC2_PRIO3, 1)
     FPC_TUNE("FPC2_WPRIO", FPC2_WPRIO, 0)
+    FPC_TUNE("FPC2_SPRIO_GB", FPC2_SPRIO_GB, 3)
+    FPC_TUNE("FPC2_SPRIO_FC", FPC2_SPRIO_FC, 3)
     FPC_TUNE("FPC2_GPRIO_PAIR", FPC2_GPRIO_PAIR, 3)
     FPC_TUNE("FPC2_GPRIO_SINGLE", FPC2_GPRIO_SINGLE, 3)
     FPC_TUNE("FPC2_ABL", FPC2_ABL, 0)

@@ -51,6 +51,12 @@ constexpr int PART_HI = 2 * PN;       // planes 2, 3
 #ifndef FPC2_WPRIO
 #define FPC2_WPRIO 0  // priority of the sampler waves' window work (the gate waves run at 3)
 #endif
+#ifndef FPC2_SPRIO_GB
+#define FPC2_SPRIO_GB 3  // priority of the sampler waves in the GRU_B phase ...
+#endif
+#ifndef FPC2_SPRIO_FC
+#define FPC2_SPRIO_FC 3  // ... and in the dual-FC phase (the draw runs at 3)
+#endif
 #ifndef FPC2_PRIO3
 #define FPC2_PRIO3 1
 #endif
@@ -666,7 +672,7 @@ __global__ __launch_bounds__(NTHREADS) void k_decode2(const DecodeParams P, cons
                 L.S[0].cand[sl] = L.S[1].cand[sl] = make_float4(0.0f, 0.0f, __uint_as_float(128u * GA), __uint_as_float(384u * GA));
 #endif
 #if FPC_PRIO
-                __builtin_amdgcn_s_setprio(3);
+                __builtin_amdgcn_s_setprio(FPC2_SPRIO_GB);
 #endif
                 FPC_BARRIER(0)  // Y
                 // ---- Y..Z1: GRU_B of both utterances (one weight register feeds two chains) ----
@@ -753,6 +759,9 @@ __global__ __launch_bounds__(NTHREADS) void k_decode2(const DecodeParams P, cons
                         if ((kl & 7) == 0) (hb ? L.S[1].s2 : L.S[0].s2)[u] = s2_mine;
                     }
                 }
+#if FPC_PRIO
+                if (FPC2_SPRIO_FC != FPC2_SPRIO_GB) __builtin_amdgcn_s_setprio(FPC2_SPRIO_FC);
+#endif
                 FPC_BARRIER(1)  // Z1
                 // ---- Z1..Z2: dual FC of tree node `sl`, both utterances; weights from LDS, read once, two chunks ahead ----
                 {
@@ -808,6 +817,9 @@ __global__ __launch_bounds__(NTHREADS) void k_decode2(const DecodeParams P, cons
                 }
 #undef FPC2_FC_LOADW
                 const float uf = L.F[dw].uframe[i];
+#if FPC_PRIO
+                if (FPC2_SPRIO_FC != 3) __builtin_amdgcn_s_setprio(3);
+#endif
                 FPC_BARRIER(2)  // Z2
                 // ---- voiced frames: leaf probability + sharpening on all 256 lanes, per voiced utterance ----
                 if (voiced) {
