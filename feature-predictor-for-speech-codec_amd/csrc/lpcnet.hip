@@ -154,8 +154,8 @@ void lpcnet_build_info(std::string& out) {
     FPC_TUNE("FPC_NA", FPC_NA, 6)
     FPC_TUNE("FPC_NB", FPC_NB, 4)
     FPC_TUNE("FPC_PCM_WHERE", FPC_PCM_WHERE, 0)
-    FPC_TUNE("FPC2_N1", FPC2_N1, 13)
-    FPC_TUNE("FPC2_N2", FPC2_N2, 12)
+    FPC_TUNE("FPC2_N1", FPC2_N1, 14)
+    FPC_TUNE("FPC2_N2", FPC2_N2, 11)
     FPC_TUNE("FPC2_PRIO3", FPC2_PRIO3, 1)
     FPC_TUNE("FPC2_WPRIO", FPC2_WPRIO, 0)
     FPC_TUNE("FPC2_SPRIO_GB", FPC2_SPRIO_GB, 3)

@@ -61,10 +61,10 @@ constexpr int PART_HI = 2 * PN;       // planes 2, 3
 #define FPC2_PRIO3 1
 #endif
 #ifndef FPC2_N1
-#define FPC2_N1 13  // column steps (of 32: 16 of utterance 0, then 16 of utterance 1) of the sparse product under GRU_B ...
+#define FPC2_N1 14  // column steps (of 32: 16 of utterance 0, then 16 of utterance 1) of the sparse product under GRU_B ...
 #endif
 #ifndef FPC2_N2
-#define FPC2_N2 12  // ... and under the dual FC; the rest under the draw
+#define FPC2_N2 11  // ... and under the dual FC; the rest under the draw
 #endif
 
 // Field order matters (as in DecodeLds): everything a lane addresses with a lane-constant register plus a constant sits in
